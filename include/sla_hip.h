@@ -1,0 +1,165 @@
+/*
+ * sla_hip.h -- batched C-ABI of the MI355X (gfx950) SLA encode hot path.
+ *
+ * Plain C: pointers, sizes, an opaque stream handle.  No torch / C++ types.
+ * Two layers:
+ *
+ *  (1) kernel launchers  sla_hip_launch_*  -- one call = one HIP kernel over a
+ *      batch of descriptors that already live in device memory.  These are
+ *      what replaces the reference's per-block inner functions:
+ *        prepass  : SLAEncoder_CalculateLeftShiftOffset  src/SLAEncoder.c:425-455
+ *                   + silence test                       src/SLAEncoder.c:392-408, 520-528
+ *        lpc      : LPC_CalculateAutoCorrelation         src/SLAPredictor.c:331-388
+ *                   LPC_LevinsonDurbinRecursion          src/SLAPredictor.c:253-328
+ *                   (A0 staging: src/SLAEncoder.c:505-515, 540-543; src/SLAUtility.c:370-412)
+ *                   Sum x^2 of SLALPCCalculator_EstimateCodeLength src/SLAPredictor.c:432-436
+ *                   coefficient quantiser                src/SLAEncoder.c:567-589
+ *        lattice  : SLAEmphasisFilter_PreEmphasisInt32   src/SLAPredictor.c:1741-1765
+ *                   SLALPCSynthesizer_PredictByParcorCoefInt32 src/SLAPredictor.c:557-607
+ *        ltm_acf  : FFT autocorrelation of SLALongTermCalculator_CalculateCoef src/SLAPredictor.c:827-853
+ *        tail     : SLALongTermSynthesizer_PredictInt32  src/SLAPredictor.c:1031-1119
+ *                   SLALMSFilter_PredictInt32            src/SLAPredictor.c:1202-1331
+ *                   SLACoder_CalculateInitialRecursiveRiceParameter src/SLACoder.c:361-385
+ *
+ *  (2) the whole-file driver behind SLAEncoder_EncodeWhole (SLAEncoder.h),
+ *      also callable on PCM that is already resident in HBM
+ *      (sla_hip_analyze_device) -- this is what bench.py times.
+ *
+ * All functions return 0 on success, a negative hipError_t-derived code on a
+ * HIP failure, or a positive SLAApiResult for API-level errors.
+ */
+#ifndef SLA_HIP_H_INCLUDED
+#define SLA_HIP_H_INCLUDED
+
+#include <stdint.h>
+#include "SLA.h"
+#include "SLAEncoder.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sla_hip_stream_t;          /* a hipStream_t, or NULL for the default stream */
+
+/* ---- descriptors (device-resident arrays of these feed the kernels) ----- */
+
+/* One LPC work-group: a window of one channel staged once in LDS, analysed
+ * over `cand_count` sub-ranges ("candidates" of the partition search, or the
+ * single whole range of a chosen block). */
+typedef struct sla_hip_lpc_group {
+  uint64_t pcm_off;        /* first sample of the window inside a channel plane          */
+  uint32_t num_samples;    /* window length W                                              */
+  uint32_t channel;        /* output channel index (after mid/side when MS is on)         */
+  uint32_t win_off;        /* offset of the analysis window table in the window pool, or
+                              SLA_HIP_NO_WINDOW: rectangular, no pre-emphasis (search)     */
+  uint32_t int_shift;      /* right shift of the integer path: 32 - bps + offset_lshift   */
+  uint32_t cand_first;     /* first entry in the candidate table                          */
+  uint32_t cand_count;
+  uint32_t slot_first;     /* output slot of candidate 0; candidate c writes slot_first+c */
+  uint32_t pad_;
+} sla_hip_lpc_group;
+#define SLA_HIP_NO_WINDOW 0xFFFFFFFFu
+/* LDS one LPC work-group may use: window doubles + (order+1) doubles per candidate.
+ * 160 KiB per CU on gfx950, minus a small static allocation. */
+#define SLA_HIP_LDS_BUDGET (160u * 1024u - 256u)
+
+typedef struct sla_hip_lpc_cand {
+  uint32_t start;          /* relative to the group's window */
+  uint32_t len;
+} sla_hip_lpc_cand;
+
+/* One lattice wave: `count` output samples of one (block, channel). */
+typedef struct sla_hip_lattice_chunk {
+  uint64_t blk_off;        /* first sample of the block inside a channel plane */
+  uint32_t blk_len;
+  uint32_t chunk_start;    /* first output sample of this chunk, relative to the block */
+  uint32_t count;
+  uint32_t channel;
+  uint32_t slot;           /* (block, channel) slot: coefficients live at kint[slot*(order+1)] */
+  uint32_t int_shift;
+} sla_hip_lattice_chunk;
+
+/* One (block, channel) of the serial tail (long-term filter + LMS + Rice sum). */
+typedef struct sla_hip_tail_job {
+  uint64_t blk_off;
+  uint32_t blk_len;
+  uint32_t channel;
+  uint32_t pitch;          /* 0 = long-term stage bypassed */
+  int32_t  ltm_coef[5];    /* Q31 taps (<<16 form), longterm_order of them used */
+  uint32_t pad_[2];
+} sla_hip_tail_job;
+
+/* ---- (1) kernel launchers ----------------------------------------------- */
+
+/* OR of every input word + one bit per sample "any channel non-zero after
+ * right-justify / mid-side".  nz_mask has ceil(num_samples/64) words. */
+int sla_hip_launch_prepass(const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_channels,
+                           uint32_t num_samples, uint32_t bits_per_sample, uint32_t mid_side,
+                           uint32_t* d_or_mask, uint64_t* d_nz_mask, sla_hip_stream_t stream);
+
+/* Autocorrelation + Levinson-Durbin for every candidate of every group.
+ * d_out: per slot (order+2) doubles = { r[0], parcor[0..order] }.
+ * When d_code/d_kint/d_rshift are non-NULL (chosen blocks: one candidate per
+ * group covering the whole window) the coefficient quantiser runs too. */
+int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                       const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                       uint32_t max_cands_per_group,
+                       const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
+                       double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
+                       sla_hip_stream_t stream);
+
+/* Integer pre-emphasis + PARCOR lattice; one wave per chunk. */
+int sla_hip_launch_lattice(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                           const sla_hip_lattice_chunk* d_chunks, uint32_t num_chunks,
+                           const int32_t* d_kint, int32_t* d_residual, sla_hip_stream_t stream);
+
+/* Long-term filter + sign-log LMS + folded-residual sum, one lane per job.
+ * d_res_in/d_res_out are channel planes with the same stride as the PCM. */
+int sla_hip_launch_tail(const int32_t* d_res_in, int32_t* d_res_out, uint64_t plane_stride,
+                        const sla_hip_tail_job* d_jobs, uint32_t num_jobs, uint32_t longterm_order,
+                        uint32_t lms_order, uint64_t* d_fold_sum, sla_hip_stream_t stream);
+
+/* ---- (2) whole-file driver ---------------------------------------------- */
+
+/* Per-block results of the last analyze call, copied into caller arrays
+ * (layout identical to the oracle's trace so tests can diff them). */
+typedef struct sla_hip_trace {
+  uint32_t  max_blocks;      /* in  */
+  uint32_t  order_stride;    /* in: parcor_order + 1 */
+  uint32_t  ltm_stride;      /* in: longterm_order   */
+  uint32_t  sample_stride;   /* in: per-channel stride of res_* (>= num_samples) */
+  uint32_t  num_blocks;      /* out */
+  uint32_t  offset_lshift;   /* out */
+  uint32_t* blk_start; uint32_t* blk_nsmpl; uint32_t* blk_type; uint32_t* blk_bytes;
+  double*   parcor; int32_t* code; int32_t* kint;
+  uint32_t* rshift; uint32_t* pitch; int32_t* ltm_coef; uint32_t* rice_init;
+  int32_t*  res_lattice; int32_t* res_final;    /* may be NULL: not copied back */
+} sla_hip_trace;
+
+/* Hot path on PCM resident in device memory: planar int32 [C][plane_stride],
+ * left-justified.  On return the encoder holds, on the device, the final
+ * residual planes and, on the host, the block table and per-block parameters.
+ * `timing_ms` (may be NULL) receives 8 floats of per-stage GPU/host times. */
+int sla_hip_analyze_device(struct SLAEncoder* encoder, const int32_t* d_pcm, uint64_t plane_stride,
+                           uint32_t num_samples, sla_hip_stream_t stream, float* timing_ms);
+
+/* Bit-serial pack of the analysed file into `data` (host): D2H of the final
+ * residual, block headers, Rice body, CRC16 (reference src/SLAEncoder.c:682-798,
+ * src/SLACoder.c:429-467).  Needs a preceding sla_hip_analyze_device. */
+int sla_hip_pack(struct SLAEncoder* encoder, uint8_t* data, uint32_t data_size, uint32_t* output_size);
+
+/* Device pointers of the last analysis (for RCCL gathers / tests). */
+const int32_t* sla_hip_final_residual(const struct SLAEncoder* encoder, uint64_t* plane_stride);
+const int32_t* sla_hip_lattice_residual(const struct SLAEncoder* encoder, uint64_t* plane_stride);
+
+/* Copy the last analysis into caller arrays. */
+int sla_hip_get_trace(struct SLAEncoder* encoder, sla_hip_trace* trace);
+
+/* Name of the device the library bound to ("" when none). */
+const char* sla_hip_device_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SLA_HIP_H_INCLUDED */

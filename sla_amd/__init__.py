@@ -1,0 +1,278 @@
+"""sla_amd -- MI355X-native encode hot path of the SLA lossless audio codec.
+
+The product is the C-ABI shared library ``sla_amd/libsla_hip.so`` (hand-written gfx950 kernels +
+plain-C host, see include/*.h).  This package is only the thin ctypes face used by the tests,
+bench.py and __graft_entry__: it mirrors the reference's encoder interface
+(SLAEncoder_Create / SetWaveFormat / SetEncodeParameter / EncodeWhole / EncodeBlock, reference
+src/include/public/SLAEncoder.h:28-53) one to one.
+
+There is no CPU fallback: loading fails loudly when the library has not been built, and
+``Encoder()`` raises when no HIP device is usable.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsla_hip.so")
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+f64p = C.POINTER(C.c_double)
+
+(WINDOW_RECT, WINDOW_SIN, WINDOW_HANN, WINDOW_BLACKMAN, WINDOW_VORBIS) = range(5)
+(CH_NONE, CH_STEREO_MS) = range(2)
+BLOCK_COMPRESS, BLOCK_SILENT, BLOCK_RAW = 0, 1, 2
+
+API_RESULT = ["OK", "NG", "INVALID_ARGUMENT", "EXCEED_HANDLE_CAPACITY", "INSUFFICIENT_BUFFER_SIZE",
+              "INVAILD_CHPROCESSMETHOD", "FAILED_TO_CALCULATE_COEF", "FAILED_TO_PREDICT",
+              "FAILED_TO_SYNTHESIZE", "INSUFFICIENT_DATA_SIZE", "INVALID_HEADER_FORMAT",
+              "DETECT_DATA_CORRUPTION", "FAILED_TO_FIND_SYNC_CODE", "INVALID_WINDOWFUNCTION_TYPE",
+              "NO_DATA_FRAGMENTS", "PARAMETER_NOT_SET"]
+
+
+class SLAEncoderConfig(C.Structure):
+    _fields_ = [("max_num_channels", C.c_uint32), ("max_num_block_samples", C.c_uint32),
+                ("max_parcor_order", C.c_uint32), ("max_longterm_order", C.c_uint32),
+                ("max_lms_order_per_filter", C.c_uint32), ("verpose_flag", C.c_uint8)]
+
+
+class SLAWaveFormat(C.Structure):
+    _fields_ = [("num_channels", C.c_uint32), ("bit_per_sample", C.c_uint32),
+                ("sampling_rate", C.c_uint32), ("offset_lshift", C.c_uint8)]
+
+
+class SLAEncodeParameter(C.Structure):
+    _fields_ = [("parcor_order", C.c_uint32), ("longterm_order", C.c_uint32),
+                ("lms_order_per_filter", C.c_uint32), ("ch_process_method", C.c_int),
+                ("window_function_type", C.c_int), ("max_num_block_samples", C.c_uint32)]
+
+
+class SLAHeaderInfo(C.Structure):
+    _fields_ = [("wave_format", SLAWaveFormat), ("encode_param", SLAEncodeParameter),
+                ("num_samples", C.c_uint32), ("num_blocks", C.c_uint32),
+                ("max_block_size", C.c_uint32), ("max_bit_per_second", C.c_uint32)]
+
+
+class HipTrace(C.Structure):
+    _fields_ = [
+        ("max_blocks", C.c_uint32), ("order_stride", C.c_uint32),
+        ("ltm_stride", C.c_uint32), ("sample_stride", C.c_uint32),
+        ("num_blocks", C.c_uint32), ("offset_lshift", C.c_uint32),
+        ("blk_start", u32p), ("blk_nsmpl", u32p), ("blk_type", u32p), ("blk_bytes", u32p),
+        ("parcor", f64p), ("code", i32p), ("kint", i32p),
+        ("rshift", u32p), ("pitch", u32p), ("ltm_coef", i32p), ("rice_init", u32p),
+        ("res_lattice", i32p), ("res_final", i32p)]
+
+
+class SlaError(RuntimeError):
+    def __init__(self, code, where):
+        name = API_RESULT[code] if 0 <= code < len(API_RESULT) else ("hipError %d" % (-code))
+        super().__init__("%s failed: %s (%d)" % (where, name, code))
+        self.code = code
+
+
+def build(verbose=False):
+    """Compile sla_amd/libsla_hip.so in-tree (hipcc --offload-arch=gfx950 + gcc)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "all"]
+    subprocess.run(cmd, check=True, stdout=None if verbose else subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(the HIP path has no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.SLAEncoder_Create.restype = C.c_void_p
+        L.SLAEncoder_Create.argtypes = [C.POINTER(SLAEncoderConfig)]
+        L.SLAEncoder_Destroy.argtypes = [C.c_void_p]
+        L.SLAEncoder_Destroy.restype = None
+        L.SLAEncoder_SetWaveFormat.argtypes = [C.c_void_p, C.POINTER(SLAWaveFormat)]
+        L.SLAEncoder_SetEncodeParameter.argtypes = [C.c_void_p, C.POINTER(SLAEncodeParameter)]
+        L.SLAEncoder_EncodeHeader.argtypes = [C.POINTER(SLAHeaderInfo), u8p, C.c_uint32]
+        L.SLAEncoder_EncodeWhole.argtypes = [C.c_void_p, C.POINTER(i32p), C.c_uint32, u8p, C.c_uint32, u32p]
+        L.SLAEncoder_EncodeBlock.argtypes = [C.c_void_p, C.POINTER(i32p), C.c_uint32, u8p, C.c_uint32, u32p]
+        L.sla_hip_analyze_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
+                                             C.POINTER(C.c_float)]
+        L.sla_hip_pack.argtypes = [C.c_void_p, u8p, C.c_uint32, u32p]
+        L.sla_hip_get_trace.argtypes = [C.c_void_p, C.POINTER(HipTrace)]
+        L.sla_hip_final_residual.restype = C.c_void_p
+        L.sla_hip_final_residual.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.sla_hip_lattice_residual.restype = C.c_void_p
+        L.sla_hip_lattice_residual.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.sla_hip_device_name.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+EXPORTED_SYMBOLS = [
+    # include/SLAEncoder.h
+    "SLAEncoder_Create", "SLAEncoder_Destroy", "SLAEncoder_SetWaveFormat", "SLAEncoder_SetEncodeParameter",
+    "SLAEncoder_EncodeHeader", "SLAEncoder_EncodeBlock", "SLAEncoder_EncodeWhole",
+    # include/sla_hip.h
+    "sla_hip_launch_prepass", "sla_hip_launch_lpc", "sla_hip_launch_lattice", "sla_hip_launch_tail",
+    "sla_hip_analyze_device", "sla_hip_pack", "sla_hip_final_residual", "sla_hip_lattice_residual",
+    "sla_hip_get_trace", "sla_hip_device_name",
+]
+
+
+class Trace:
+    """numpy view of the per-block results of the last analysis (same fields as the oracle's trace)."""
+
+    def __init__(self, num_channels, order, ltm_order, num_samples, max_blocks, want_residuals=True):
+        Cn, O, L = num_channels, order + 1, max(ltm_order, 1)
+        z = lambda shape, dt: np.zeros(shape, dtype=dt)
+        self.blk_start = z(max_blocks, np.uint32)
+        self.blk_nsmpl = z(max_blocks, np.uint32)
+        self.blk_type = z(max_blocks, np.uint32)
+        self.blk_bytes = z(max_blocks, np.uint32)
+        self.parcor = z((max_blocks, Cn, O), np.float64)
+        self.code = z((max_blocks, Cn, O), np.int32)
+        self.kint = z((max_blocks, Cn, O), np.int32)
+        self.rshift = z((max_blocks, Cn), np.uint32)
+        self.pitch = z((max_blocks, Cn), np.uint32)
+        self.ltm_coef = z((max_blocks, Cn, L), np.int32)
+        self.rice_init = z((max_blocks, Cn), np.uint32)
+        ns = max(num_samples, 1)
+        self.res_lattice = z((Cn, ns), np.int32) if want_residuals else None
+        self.res_final = z((Cn, ns), np.int32) if want_residuals else None
+        p = lambda a, t: a.ctypes.data_as(t)
+        self.c = HipTrace(
+            max_blocks, O, L, ns, 0, 0,
+            p(self.blk_start, u32p), p(self.blk_nsmpl, u32p), p(self.blk_type, u32p), p(self.blk_bytes, u32p),
+            p(self.parcor, f64p), p(self.code, i32p), p(self.kint, i32p), p(self.rshift, u32p),
+            p(self.pitch, u32p), p(self.ltm_coef, i32p), p(self.rice_init, u32p),
+            p(self.res_lattice, i32p) if want_residuals else None,
+            p(self.res_final, i32p) if want_residuals else None)
+
+    @property
+    def num_blocks(self):
+        return int(self.c.num_blocks)
+
+    @property
+    def offset_lshift(self):
+        return int(self.c.offset_lshift)
+
+
+class Encoder:
+    """Python face of ``struct SLAEncoder`` (reference src/include/public/SLAEncoder.h)."""
+
+    def __init__(self, max_num_channels=8, max_num_block_samples=16384, max_parcor_order=48,
+                 max_longterm_order=5, max_lms_order_per_filter=40):
+        self._lib = lib()
+        cfg = SLAEncoderConfig(max_num_channels, max_num_block_samples, max_parcor_order,
+                               max_longterm_order, max_lms_order_per_filter, 0)
+        self._h = self._lib.SLAEncoder_Create(C.byref(cfg))
+        if not self._h:
+            raise RuntimeError("SLAEncoder_Create failed: no usable HIP device (libsla_hip has no CPU fallback)")
+        self.num_channels = 0
+        self.order = 0
+        self.ltm_order = 0
+        self.num_samples = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.SLAEncoder_Destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, where):
+        if rc != 0:
+            raise SlaError(rc, where)
+
+    def set_wave_format(self, num_channels, bit_per_sample, sampling_rate, offset_lshift=0):
+        wf = SLAWaveFormat(num_channels, bit_per_sample, sampling_rate, offset_lshift)
+        self._check(self._lib.SLAEncoder_SetWaveFormat(self._h, C.byref(wf)), "SLAEncoder_SetWaveFormat")
+        self.num_channels = num_channels
+
+    def set_encode_parameter(self, parcor_order, longterm_order, lms_order_per_filter,
+                             ch_process_method=CH_NONE, window_function_type=WINDOW_SIN,
+                             max_num_block_samples=4096):
+        ep = SLAEncodeParameter(parcor_order, longterm_order, lms_order_per_filter, ch_process_method,
+                                window_function_type, max_num_block_samples)
+        self._check(self._lib.SLAEncoder_SetEncodeParameter(self._h, C.byref(ep)), "SLAEncoder_SetEncodeParameter")
+        self.order, self.ltm_order = parcor_order, longterm_order
+
+    @staticmethod
+    def _planes(pcm):
+        pcm = np.ascontiguousarray(pcm, np.int32)
+        ptrs = (i32p * pcm.shape[0])(*[pcm[c].ctypes.data_as(i32p) for c in range(pcm.shape[0])])
+        return pcm, ptrs
+
+    def encode_whole(self, pcm, capacity=None):
+        """planar left-justified int32 [C][N] on the host -> .sla bytes"""
+        pcm, ptrs = self._planes(pcm)
+        n = pcm.shape[1]
+        cap = capacity if capacity is not None else 8 * pcm.shape[0] * n + 65536
+        out = np.zeros(cap, np.uint8)
+        size = C.c_uint32(0)
+        self._check(self._lib.SLAEncoder_EncodeWhole(self._h, ptrs, n, out.ctypes.data_as(u8p), cap, C.byref(size)),
+                    "SLAEncoder_EncodeWhole")
+        self.num_samples = n
+        return out[:size.value].tobytes()
+
+    def encode_block(self, pcm, capacity=None):
+        pcm, ptrs = self._planes(pcm)
+        n = pcm.shape[1]
+        cap = capacity if capacity is not None else 8 * pcm.shape[0] * n + 4096
+        out = np.zeros(cap, np.uint8)
+        size = C.c_uint32(0)
+        self._check(self._lib.SLAEncoder_EncodeBlock(self._h, ptrs, n, out.ctypes.data_as(u8p), cap, C.byref(size)),
+                    "SLAEncoder_EncodeBlock")
+        self.num_samples = n
+        return out[:size.value].tobytes()
+
+    def analyze_device(self, device_ptr, plane_stride, num_samples, stream=None):
+        """hot path on PCM already resident in HBM; returns the 8 stage timings [ms]"""
+        timing = (C.c_float * 8)()
+        self._check(self._lib.sla_hip_analyze_device(self._h, C.c_void_p(device_ptr), plane_stride, num_samples,
+                                                     C.c_void_p(stream) if stream else None, timing),
+                    "sla_hip_analyze_device")
+        self.num_samples = num_samples
+        return list(timing)
+
+    def pack(self, capacity):
+        out = np.zeros(capacity, np.uint8)
+        size = C.c_uint32(0)
+        self._check(self._lib.sla_hip_pack(self._h, out.ctypes.data_as(u8p), capacity, C.byref(size)), "sla_hip_pack")
+        return out[:size.value].tobytes()
+
+    def trace(self, want_residuals=True):
+        tr = Trace(self.num_channels, self.order, self.ltm_order, self.num_samples,
+                   self.num_samples // 1024 + 8, want_residuals)
+        self._check(self._lib.sla_hip_get_trace(self._h, C.byref(tr.c)), "sla_hip_get_trace")
+        return tr
+
+    def final_residual_ptr(self):
+        stride = C.c_uint64(0)
+        return self._lib.sla_hip_final_residual(self._h, C.byref(stride)), stride.value
+
+
+def encode_header(num_channels, bits, rate, lshift, parcor, ltm, lms, chproc, window, max_block,
+                  num_samples, num_blocks, max_block_size, max_bps):
+    h = SLAHeaderInfo(SLAWaveFormat(num_channels, bits, rate, lshift),
+                      SLAEncodeParameter(parcor, ltm, lms, chproc, window, max_block),
+                      num_samples, num_blocks, max_block_size, max_bps)
+    out = np.zeros(64, np.uint8)
+    rc = lib().SLAEncoder_EncodeHeader(C.byref(h), out.ctypes.data_as(u8p), 64)
+    if rc != 0:
+        raise SlaError(rc, "SLAEncoder_EncodeHeader")
+    return out[:43].tobytes()
+
+
+def device_name():
+    return lib().sla_hip_device_name().decode()

@@ -1,0 +1,1070 @@
+/*
+ * sla_encoder.c -- host orchestration of the MI355X SLA encode path (plain C).
+ *
+ * Drop-in for the reference encoder object (src/SLAEncoder.c): same public
+ * functions and error codes, but instead of walking the file block by block
+ * it runs the whole file as a few batched kernel launches:
+ *
+ *   prepass kernel  -> host: offset_lshift, super-frame table (silence hops)
+ *   lpc kernel      -> host: code lengths (libm log) + Dijkstra per super-frame
+ *   lpc kernel (windowed, + quantiser), lattice kernel
+ *                   -> host: RAW decision, long-term analysis (FFT today on the
+ *                      host -- see DESIGN.md "next rows"), tail jobs
+ *   tail kernel     -> Rice initial parameters
+ *   pack            -> host threads: headers, Rice bodies, CRC16
+ *
+ * Nothing here computes the hot path on the CPU: without a HIP device
+ * SLAEncoder_Create fails.
+ */
+#include "sla_internal.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+#define STATUS_WAVE_FORMAT   (1u << 0)
+#define STATUS_ENCODE_PARAM  (1u << 1)
+#define MAX_ANALYSIS_WINDOW  16384u     /* LDS-resident window: 128 KiB of doubles */
+
+typedef struct { void* ptr; size_t cap; } devbuf_t;
+typedef struct { void* ptr; size_t cap; } pinbuf_t;
+
+typedef struct {
+  uint32_t start, nsmpl, type, bytes;
+} blk_t;
+
+/* per (block, channel) results */
+typedef struct {
+  uint32_t rshift, pitch, rice_init;
+  int32_t  ltm_q[SLAI_MAX_TAPS];
+} blkch_t;
+
+struct SLAEncoder {
+  struct SLAEncoderConfig   cfg;
+  struct SLAWaveFormat      wave_format;
+  struct SLAEncodeParameter encode_param;
+  uint32_t status_flag;
+  int      device;
+  hipStream_t stream;
+  hipEvent_t  ev[12];
+  slai_fft_plan* fft;
+  uint32_t threads;
+
+  /* device workspace */
+  devbuf_t d_pcm, d_res1, d_res2, d_or, d_nz, d_groups, d_cands, d_lpc_out, d_code, d_kint, d_rshift,
+           d_winpool, d_chunks, d_jobs, d_fold;
+  /* pinned host staging */
+  pinbuf_t h_nz, h_groups, h_cands, h_lpc_out, h_code, h_kint, h_rshift, h_chunks, h_jobs, h_fold, h_res, h_pcm;
+  uint32_t* h_or;
+
+  /* window pool: tables for every block length seen so far */
+  double*   win_host; size_t win_count, win_cap;
+  uint32_t* win_len; uint32_t* win_off; uint32_t win_entries, win_entries_cap;
+  SLAWindowFunctionType win_type; int win_dirty;
+
+  /* last analysis */
+  const int32_t* pcm_dev;           /* borrowed or &d_pcm */
+  uint64_t stride;
+  uint32_t num_samples;
+  uint32_t lshift;
+  blk_t*   blk; uint32_t num_blocks, blk_cap;
+  blkch_t* bc;  size_t bc_cap;
+  double*  parcor; int32_t* code; int32_t* kint;   /* [num_blocks*C*(order+1)] */
+  size_t   coef_cap;
+  int      analysed;
+  float    timing[8];
+};
+
+/* ------------------------------------------------------------------ utilities */
+
+static double now_ms(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+static int hiprc(hipError_t e) { return (e == hipSuccess) ? 0 : -(int)e; }
+#define HIPCHK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { return hiprc(e__); } } while (0)
+#define RCCHK(call)  do { int r__ = (call); if (r__ != 0) { return r__; } } while (0)
+
+static int dev_reserve(devbuf_t* b, size_t bytes)
+{
+  if (bytes == 0) { bytes = 16; }
+  if (b->cap >= bytes) { return 0; }
+  if (b->ptr != NULL) { (void)hipFree(b->ptr); b->ptr = NULL; b->cap = 0; }
+  bytes += bytes / 8 + 256;
+  HIPCHK(hipMalloc(&b->ptr, bytes));
+  b->cap = bytes;
+  return 0;
+}
+
+static int pin_reserve(pinbuf_t* b, size_t bytes)
+{
+  if (bytes == 0) { bytes = 16; }
+  if (b->cap >= bytes) { return 0; }
+  if (b->ptr != NULL) { (void)hipHostFree(b->ptr); b->ptr = NULL; b->cap = 0; }
+  bytes += bytes / 8 + 256;
+  HIPCHK(hipHostMalloc(&b->ptr, bytes, hipHostMallocDefault));
+  b->cap = bytes;
+  return 0;
+}
+
+/* run fn(ctx, i) for i in [0,count) on the encoder's host threads */
+typedef struct { void (*fn)(void*, uint32_t); void* ctx; uint32_t count; volatile uint32_t next; } pfor_t;
+static void* pfor_worker(void* arg)
+{
+  pfor_t* p = (pfor_t*)arg;
+  for (;;) {
+    uint32_t i = __atomic_fetch_add(&p->next, 1u, __ATOMIC_RELAXED);
+    if (i >= p->count) { break; }
+    p->fn(p->ctx, i);
+  }
+  return NULL;
+}
+static void parallel_for(uint32_t threads, uint32_t count, void (*fn)(void*, uint32_t), void* ctx)
+{
+  pfor_t p;
+  pthread_t tid[64];
+  uint32_t t, started = 0;
+  p.fn = fn; p.ctx = ctx; p.count = count; p.next = 0;
+  if (threads > 64) { threads = 64; }
+  if (threads > count) { threads = count; }
+  for (t = 1; t < threads; t++) { if (pthread_create(&tid[started], NULL, pfor_worker, &p) == 0) { started++; } }
+  pfor_worker(&p);
+  for (t = 0; t < started; t++) { pthread_join(tid[t], NULL); }
+}
+
+/* ------------------------------------------------------------- create / destroy */
+
+static char g_device_name[256] = "";
+const char* sla_hip_device_name(void) { return g_device_name; }
+
+struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
+{
+  struct SLAEncoder* e;
+  hipDeviceProp_t prop;
+  int ndev = 0, i;
+  const char* env;
+  if (config == NULL) { return NULL; }
+  if (config->max_num_channels == 0 || config->max_num_channels > SLAI_MAX_CHANNELS
+      || config->max_parcor_order > SLAI_MAX_ORDER || config->max_longterm_order > SLAI_MAX_TAPS) { return NULL; }
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    fprintf(stderr, "libsla_hip: no HIP device available -- the encode path has no CPU fallback\n");
+    return NULL;
+  }
+  e = (struct SLAEncoder*)calloc(1, sizeof(*e));
+  if (e == NULL) { return NULL; }
+  e->cfg = *config;
+  if (hipGetDevice(&e->device) != hipSuccess) { free(e); return NULL; }
+  if (hipGetDeviceProperties(&prop, e->device) == hipSuccess) {
+    snprintf(g_device_name, sizeof(g_device_name), "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { free(e); return NULL; }
+  for (i = 0; i < 12; i++) { if (hipEventCreate(&e->ev[i]) != hipSuccess) { free(e); return NULL; } }
+  if (hipHostMalloc((void**)&e->h_or, 64, hipHostMallocDefault) != hipSuccess) { free(e); return NULL; }
+  {
+    uint32_t fft = 1;
+    while (fft < config->max_num_block_samples * 2) { fft <<= 1; }    /* src/SLAEncoder.c:110 */
+    if (fft < 8) { fft = 8; }
+    e->fft = slai_fft_plan_create(fft);
+  }
+  e->threads = (uint32_t)sysconf(_SC_NPROCESSORS_ONLN);
+  if (e->threads < 1) { e->threads = 1; }
+  if (e->threads > 32) { e->threads = 32; }
+  env = getenv("SLA_HIP_THREADS");
+  if (env != NULL && atoi(env) > 0) { e->threads = (uint32_t)atoi(env); }
+  e->win_type = (SLAWindowFunctionType)-1;
+  return e;
+}
+
+void SLAEncoder_Destroy(struct SLAEncoder* e)
+{
+  devbuf_t* d[15];
+  pinbuf_t* h[12];
+  int i;
+  if (e == NULL) { return; }
+  (void)hipStreamSynchronize(e->stream);
+  d[0] = &e->d_pcm; d[1] = &e->d_res1; d[2] = &e->d_res2; d[3] = &e->d_or; d[4] = &e->d_nz; d[5] = &e->d_groups;
+  d[6] = &e->d_cands; d[7] = &e->d_lpc_out; d[8] = &e->d_code; d[9] = &e->d_kint; d[10] = &e->d_rshift;
+  d[11] = &e->d_winpool; d[12] = &e->d_chunks; d[13] = &e->d_jobs; d[14] = &e->d_fold;
+  for (i = 0; i < 15; i++) { if (d[i]->ptr != NULL) { (void)hipFree(d[i]->ptr); } }
+  h[0] = &e->h_nz; h[1] = &e->h_groups; h[2] = &e->h_cands; h[3] = &e->h_lpc_out; h[4] = &e->h_code; h[5] = &e->h_kint;
+  h[6] = &e->h_rshift; h[7] = &e->h_chunks; h[8] = &e->h_jobs; h[9] = &e->h_fold; h[10] = &e->h_res; h[11] = &e->h_pcm;
+  for (i = 0; i < 12; i++) { if (h[i]->ptr != NULL) { (void)hipHostFree(h[i]->ptr); } }
+  if (e->h_or != NULL) { (void)hipHostFree(e->h_or); }
+  for (i = 0; i < 12; i++) { (void)hipEventDestroy(e->ev[i]); }
+  (void)hipStreamDestroy(e->stream);
+  slai_fft_plan_destroy(e->fft);
+  free(e->win_host); free(e->win_len); free(e->win_off);
+  free(e->blk); free(e->bc); free(e->parcor); free(e->code); free(e->kint);
+  free(e);
+}
+
+SLAApiResult SLAEncoder_SetWaveFormat(struct SLAEncoder* e, const struct SLAWaveFormat* wf)
+{
+  if (e == NULL || wf == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (wf->num_channels > e->cfg.max_num_channels || wf->bit_per_sample > 32) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
+  e->wave_format = *wf;
+  e->status_flag |= STATUS_WAVE_FORMAT;
+  e->analysed = 0;
+  return SLA_APIRESULT_OK;
+}
+
+SLAApiResult SLAEncoder_SetEncodeParameter(struct SLAEncoder* e, const struct SLAEncodeParameter* ep)
+{
+  if (e == NULL || ep == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (ep->parcor_order > e->cfg.max_parcor_order || ep->longterm_order > e->cfg.max_longterm_order
+      || ep->lms_order_per_filter > e->cfg.max_lms_order_per_filter
+      || ep->max_num_block_samples > e->cfg.max_num_block_samples
+      || ep->max_num_block_samples < SLAI_MIN_BLOCK) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
+  /* device limits of this implementation: the analysis window lives in LDS */
+  if (ep->max_num_block_samples > MAX_ANALYSIS_WINDOW || ep->parcor_order < 1) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
+  e->encode_param = *ep;
+  e->status_flag |= STATUS_ENCODE_PARAM;
+  e->analysed = 0;
+  return SLA_APIRESULT_OK;
+}
+
+SLAApiResult SLAEncoder_EncodeHeader(const struct SLAHeaderInfo* header, uint8_t* data, uint32_t data_size)
+{
+  return (SLAApiResult)slai_write_header(header, data, data_size);
+}
+
+/* ------------------------------------------------------------------ window pool */
+
+static int window_offset(struct SLAEncoder* e, uint32_t n, uint32_t* off)
+{
+  uint32_t i;
+  if (e->win_type != e->encode_param.window_function_type) {
+    e->win_entries = 0; e->win_count = 0; e->win_type = e->encode_param.window_function_type; e->win_dirty = 1;
+  }
+  for (i = 0; i < e->win_entries; i++) { if (e->win_len[i] == n) { *off = e->win_off[i]; return 0; } }
+  if (e->win_entries == e->win_entries_cap) {
+    e->win_entries_cap = e->win_entries_cap ? e->win_entries_cap * 2 : 16;
+    e->win_len = (uint32_t*)realloc(e->win_len, sizeof(uint32_t) * e->win_entries_cap);
+    e->win_off = (uint32_t*)realloc(e->win_off, sizeof(uint32_t) * e->win_entries_cap);
+  }
+  if (e->win_count + n > e->win_cap) {
+    e->win_cap = (e->win_count + n) * 2;
+    e->win_host = (double*)realloc(e->win_host, sizeof(double) * e->win_cap);
+  }
+  if (e->win_len == NULL || e->win_off == NULL || e->win_host == NULL) { return SLA_APIRESULT_NG; }
+  if (slai_make_window(e->win_type, e->win_host + e->win_count, n) != 0) { return SLA_APIRESULT_INVALID_WINDOWFUNCTION_TYPE; }
+  e->win_len[e->win_entries] = n; e->win_off[e->win_entries] = (uint32_t)e->win_count;
+  *off = (uint32_t)e->win_count;
+  e->win_entries++; e->win_count += n; e->win_dirty = 1;
+  return 0;
+}
+
+/* ------------------------------------------------------------------ block table */
+
+static int blocks_push(struct SLAEncoder* e, uint32_t start, uint32_t nsmpl, uint32_t type)
+{
+  if (e->num_blocks == e->blk_cap) {
+    e->blk_cap = e->blk_cap ? e->blk_cap * 2 : 1024;
+    e->blk = (blk_t*)realloc(e->blk, sizeof(blk_t) * e->blk_cap);
+    if (e->blk == NULL) { return SLA_APIRESULT_NG; }
+  }
+  e->blk[e->num_blocks].start = start; e->blk[e->num_blocks].nsmpl = nsmpl;
+  e->blk[e->num_blocks].type = type; e->blk[e->num_blocks].bytes = 0;
+  e->num_blocks++;
+  return 0;
+}
+
+/* ------------------------------------------------------------ stage 1: planning */
+
+typedef struct { uint32_t start, window, min_blk, shape, slot_base; } sframe_t;
+typedef struct { uint32_t window, min_blk, nodes, ncand, cand_first; uint32_t pair[SLAI_MAX_NODES * SLAI_MAX_NODES]; } shape_t;
+
+typedef struct {
+  struct SLAEncoder* e;
+  const sframe_t* sf; const shape_t* shapes; const sla_hip_lpc_cand* cands; const double* out;
+  uint32_t* parts;       /* [nsf][SLAI_MAX_NODES] */
+  uint32_t* nparts;      /* [nsf] */
+  int*      status;
+} plan_ctx_t;
+
+/* host part of the partition search for one super-frame: edge costs from the device's
+ * (r0, PARCOR) per candidate, then the shortest path (reference src/SLAPredictor.c:1615-1692) */
+static void plan_one(void* vctx, uint32_t idx)
+{
+  plan_ctx_t* c = (plan_ctx_t*)vctx;
+  const struct SLAEncoder* e = c->e;
+  const sframe_t* sf = &c->sf[idx];
+  const shape_t* sh = &c->shapes[sf->shape];
+  const uint32_t C = e->wave_format.num_channels, order = e->encode_param.parcor_order, O2 = order + 2;
+  double adj[SLAI_MAX_NODES * SLAI_MAX_NODES];
+  uint32_t path[SLAI_MAX_NODES], i, j, ch, count, node;
+  for (i = 0; i < sh->nodes; i++) {
+    for (j = 0; j < sh->nodes; j++) {
+      const uint32_t k = sh->pair[i * sh->nodes + j];
+      double est = 0.0;
+      adj[i * sh->nodes + j] = SLAI_BIG_WEIGHT;
+      if (k == 0xFFFFFFFFu) { continue; }
+      for (ch = 0; ch < C; ch++) {
+        const double* o = c->out + (size_t)(sf->slot_base + ch * sh->ncand + k) * O2;
+        const uint32_t len = c->cands[sh->cand_first + k].len;
+        est += len * slai_code_length(o[0], len, e->wave_format.bit_per_sample, o + 1, order);
+      }
+      est += SLAI_EST_BLOCK_HEADER;
+      est += SLAI_PATH_PENALTY;
+      adj[i * sh->nodes + j] = est;
+    }
+  }
+  if (slai_shortest_path(adj, sh->nodes, path) != 0) { c->status[idx] = SLA_APIRESULT_FAILED_TO_CALCULATE_COEF; return; }
+  count = 0;
+  for (node = sh->nodes - 1; node != 0; node = path[node]) {
+    if (path[node] >= node) { c->status[idx] = SLA_APIRESULT_FAILED_TO_CALCULATE_COEF; return; }
+    count++;
+  }
+  node = sh->nodes - 1;
+  for (i = 0; i < count; i++) {
+    uint32_t off = path[node] * SLAI_SEARCH_DELTA, len = (node - path[node]) * SLAI_SEARCH_DELTA;
+    if (len > sf->window - off) { len = sf->window - off; }
+    c->parts[(size_t)idx * SLAI_MAX_NODES + (count - i - 1)] = len;
+    node = path[node];
+  }
+  c->nparts[idx] = count;
+  c->status[idx] = 0;
+}
+
+static int stage_plan(struct SLAEncoder* e)
+{
+  const uint32_t C = e->wave_format.num_channels, bps = e->wave_format.bit_per_sample;
+  const uint32_t order = e->encode_param.parcor_order, O1 = order + 1, O2 = order + 2;
+  const uint32_t ms = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
+  const uint32_t n = e->num_samples, maxb = e->encode_param.max_num_block_samples;
+  const uint64_t nwords = ((uint64_t)n + 63) / 64;
+  sframe_t* sf = NULL; uint32_t nsf = 0, sf_cap = 0;
+  shape_t* shapes = NULL; uint32_t nshapes = 0;
+  sla_hip_lpc_cand* cands; sla_hip_lpc_group* groups;
+  uint32_t ncands = 0, ngroups = 0, nslots = 0, max_cpg = 1, pos, i, j;
+  const uint64_t* nz;
+  double t0;
+  int rc = 0;
+
+  /* ---- prepass --------------------------------------------------------------- */
+  RCCHK(dev_reserve(&e->d_or, 64));
+  RCCHK(dev_reserve(&e->d_nz, (size_t)(nwords + 2) * 8));
+  RCCHK(pin_reserve(&e->h_nz, (size_t)(nwords + 2) * 8));
+  HIPCHK(hipEventRecord(e->ev[0], e->stream));
+  RCCHK(sla_hip_launch_prepass(e->pcm_dev, e->stride, C, n, bps, ms, (uint32_t*)e->d_or.ptr, (uint64_t*)e->d_nz.ptr, e->stream));
+  HIPCHK(hipEventRecord(e->ev[1], e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_or, e->d_or.ptr, 4, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_nz.ptr, e->d_nz.ptr, (size_t)nwords * 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  nz = (const uint64_t*)e->h_nz.ptr;
+  ((uint64_t*)e->h_nz.ptr)[nwords] = 0; ((uint64_t*)e->h_nz.ptr)[nwords + 1] = 0;
+
+  /* offset_lshift = bps - (32 - ntz(OR of all words))          src/SLAEncoder.c:425-455 */
+  {
+    const uint32_t mask = e->h_or[0];
+    e->lshift = 0;
+    if (mask != 0) {
+      const uint32_t ntz = (uint32_t)__builtin_ctz(mask);
+      if (bps < 32 - ntz) { return SLA_APIRESULT_INVALID_ARGUMENT; }   /* samples wider than declared */
+      e->lshift = bps - (32 - ntz);
+    }
+    if (e->lshift >= bps && mask != 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  }
+
+  /* ---- super-frame table (sequential hop over silence runs)   src/SLAEncoder.c:846-869, 392-408 */
+  t0 = now_ms();
+  e->num_blocks = 0;
+  shapes = (shape_t*)malloc(sizeof(shape_t) * 8);
+  if (shapes == NULL) { return SLA_APIRESULT_NG; }
+  for (pos = 0; pos < n;) {
+    const uint32_t remain = n - pos;
+    const uint32_t window = (maxb < remain) ? maxb : remain;
+    const uint32_t min_blk = (SLAI_MIN_BLOCK < remain) ? SLAI_MIN_BLOCK : remain;
+    const uint32_t run = slai_zero_run(nz, pos, window);
+    uint32_t s;
+    if (nsf == sf_cap) {
+      sf_cap = sf_cap ? sf_cap * 2 : 1024;
+      sf = (sframe_t*)realloc(sf, sizeof(sframe_t) * sf_cap);
+      if (sf == NULL) { free(shapes); return SLA_APIRESULT_NG; }
+    }
+    sf[nsf].start = pos; sf[nsf].window = window; sf[nsf].min_blk = min_blk; sf[nsf].slot_base = 0;
+    if (run >= min_blk) {
+      sf[nsf].shape = 0xFFFFFFFFu;      /* one SILENT block of `run` samples, no search */
+      sf[nsf].window = run;
+      pos += run;
+    } else {
+      for (s = 0; s < nshapes; s++) { if (shapes[s].window == window && shapes[s].min_blk == min_blk) { break; } }
+      if (s == nshapes) {
+        if (nshapes >= 8) { shapes = (shape_t*)realloc(shapes, sizeof(shape_t) * (nshapes + 1)); if (shapes == NULL) { free(sf); return SLA_APIRESULT_NG; } }
+        shapes[s].window = window; shapes[s].min_blk = min_blk;
+        shapes[s].nodes = (window + SLAI_SEARCH_DELTA - 1) / SLAI_SEARCH_DELTA + 1;
+        shapes[s].ncand = 0; shapes[s].cand_first = 0;
+        nshapes++;
+      }
+      sf[nsf].shape = s;
+      pos += window;
+    }
+    nsf++;
+  }
+
+  /* candidate table per shape: every (i,j) whose clipped length is allowed   src/SLAPredictor.c:1615-1630 */
+  for (i = 0; i < nshapes; i++) { ncands += shapes[i].nodes * shapes[i].nodes; }
+  RCCHK(pin_reserve(&e->h_cands, sizeof(sla_hip_lpc_cand) * (ncands + 1)));
+  cands = (sla_hip_lpc_cand*)e->h_cands.ptr;
+  ncands = 0;
+  for (i = 0; i < nshapes; i++) {
+    shape_t* sh = &shapes[i];
+    uint32_t a, b;
+    sh->cand_first = ncands;
+    for (a = 0; a < sh->nodes; a++) {
+      for (b = 0; b < sh->nodes; b++) {
+        uint32_t off = a * SLAI_SEARCH_DELTA, len = (b > a) ? (b - a) * SLAI_SEARCH_DELTA : 0;
+        sh->pair[a * sh->nodes + b] = 0xFFFFFFFFu;
+        if (b <= a) { continue; }
+        if (len > sh->window - off) { len = sh->window - off; }
+        if (len < sh->min_blk || len > sh->window) { continue; }
+        sh->pair[a * sh->nodes + b] = sh->ncand;
+        cands[ncands].start = off; cands[ncands].len = len;
+        ncands++; sh->ncand++;
+      }
+    }
+  }
+
+  /* groups: (super-frame, channel) split so that window + r[] fits the LDS budget */
+  {
+    uint32_t total_groups = 0;
+    for (i = 0; i < nsf; i++) {
+      if (sf[i].shape == 0xFFFFFFFFu) { continue; }
+      {
+        const shape_t* sh = &shapes[sf[i].shape];
+        size_t room = (SLA_HIP_LDS_BUDGET / 8 > sh->window) ? (SLA_HIP_LDS_BUDGET / 8 - sh->window) : 0;
+        uint32_t cpg = (uint32_t)(room / O1);
+        if (cpg == 0) { free(sf); free(shapes); return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
+        if (cpg > sh->ncand) { cpg = sh->ncand; }
+        total_groups += C * ((sh->ncand + cpg - 1) / cpg);
+      }
+    }
+    RCCHK(pin_reserve(&e->h_groups, sizeof(sla_hip_lpc_group) * (total_groups + 1)));
+  }
+  groups = (sla_hip_lpc_group*)e->h_groups.ptr;
+  {
+    uint32_t max_window = 1;
+    for (i = 0; i < nsf; i++) {
+      const shape_t* sh;
+      uint32_t cpg, ch, first;
+      size_t room;
+      if (sf[i].shape == 0xFFFFFFFFu) { continue; }
+      sh = &shapes[sf[i].shape];
+      room = SLA_HIP_LDS_BUDGET / 8 - sh->window;
+      cpg = (uint32_t)(room / O1);
+      if (cpg > sh->ncand) { cpg = sh->ncand; }
+      sf[i].slot_base = nslots;
+      for (ch = 0; ch < C; ch++) {
+        for (first = 0; first < sh->ncand; first += cpg) {
+          sla_hip_lpc_group* g = &groups[ngroups++];
+          g->pcm_off = sf[i].start; g->num_samples = sh->window; g->channel = ch;
+          g->win_off = SLA_HIP_NO_WINDOW; g->int_shift = 32 - bps;
+          g->cand_first = sh->cand_first + first;
+          g->cand_count = (sh->ncand - first < cpg) ? (sh->ncand - first) : cpg;
+          g->slot_first = nslots + ch * sh->ncand + first; g->pad_ = 0;
+          if (g->cand_count > max_cpg) { max_cpg = g->cand_count; }
+        }
+      }
+      nslots += C * sh->ncand;
+      if (sh->window > max_window) { max_window = sh->window; }
+    }
+
+    /* ---- search kernel ---------------------------------------------------------- */
+    if (ngroups > 0) {
+      RCCHK(dev_reserve(&e->d_groups, sizeof(sla_hip_lpc_group) * ngroups));
+      RCCHK(dev_reserve(&e->d_cands, sizeof(sla_hip_lpc_cand) * ncands));
+      RCCHK(dev_reserve(&e->d_lpc_out, sizeof(double) * (size_t)nslots * O2));
+      RCCHK(pin_reserve(&e->h_lpc_out, sizeof(double) * (size_t)nslots * O2));
+      HIPCHK(hipMemcpyAsync(e->d_groups.ptr, groups, sizeof(sla_hip_lpc_group) * ngroups, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipMemcpyAsync(e->d_cands.ptr, cands, sizeof(sla_hip_lpc_cand) * ncands, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipEventRecord(e->ev[2], e->stream));
+      rc = sla_hip_launch_lpc(e->pcm_dev, e->stride, ms, order, (const sla_hip_lpc_group*)e->d_groups.ptr, ngroups,
+                              max_window, max_cpg, (const sla_hip_lpc_cand*)e->d_cands.ptr, NULL,
+                              (double*)e->d_lpc_out.ptr, NULL, NULL, NULL, e->stream);
+      if (rc != 0) { free(sf); free(shapes); return rc; }
+      HIPCHK(hipEventRecord(e->ev[3], e->stream));
+      HIPCHK(hipMemcpyAsync(e->h_lpc_out.ptr, e->d_lpc_out.ptr, sizeof(double) * (size_t)nslots * O2, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+    } else {
+      HIPCHK(hipEventRecord(e->ev[2], e->stream));
+      HIPCHK(hipEventRecord(e->ev[3], e->stream));
+    }
+  }
+  e->timing[5] = (float)(now_ms() - t0);
+
+  /* ---- host: code lengths + shortest path per super-frame, then the block table ------- */
+  t0 = now_ms();
+  {
+    plan_ctx_t ctx;
+    uint32_t* parts = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(nsf + 1) * SLAI_MAX_NODES);
+    uint32_t* nparts = (uint32_t*)calloc(nsf + 1, sizeof(uint32_t));
+    int* status = (int*)calloc(nsf + 1, sizeof(int));
+    uint32_t* live = (uint32_t*)malloc(sizeof(uint32_t) * (nsf + 1));
+    sframe_t* lsf = (sframe_t*)malloc(sizeof(sframe_t) * (nsf + 1));
+    uint32_t nlive = 0;
+    if (parts == NULL || nparts == NULL || status == NULL || live == NULL || lsf == NULL) {
+      free(parts); free(nparts); free(status); free(live); free(lsf); free(sf); free(shapes);
+      return SLA_APIRESULT_NG;
+    }
+    for (i = 0; i < nsf; i++) { if (sf[i].shape != 0xFFFFFFFFu) { live[nlive] = i; lsf[nlive] = sf[i]; nlive++; } }
+    ctx.e = e; ctx.sf = lsf; ctx.shapes = shapes; ctx.cands = cands; ctx.out = (const double*)e->h_lpc_out.ptr;
+    ctx.parts = parts; ctx.nparts = nparts; ctx.status = status;
+    parallel_for(e->threads, nlive, plan_one, &ctx);
+    j = 0;
+    for (i = 0; i < nsf && rc == 0; i++) {
+      if (sf[i].shape == 0xFFFFFFFFu) {
+        rc = blocks_push(e, sf[i].start, sf[i].window, SLAI_BLK_SILENT);
+      } else {
+        uint32_t p, at = sf[i].start;
+        if (status[j] != 0) { rc = status[j]; break; }
+        for (p = 0; p < nparts[j] && rc == 0; p++) {
+          const uint32_t len = parts[(size_t)j * SLAI_MAX_NODES + p];
+          const uint32_t type = slai_range_is_zero(nz, at, len) ? SLAI_BLK_SILENT : SLAI_BLK_COMPRESS;
+          rc = blocks_push(e, at, len, type);
+          at += len;
+        }
+        j++;
+      }
+    }
+    free(parts); free(nparts); free(status); free(live); free(lsf);
+  }
+  free(sf); free(shapes);
+  e->timing[5] += (float)(now_ms() - t0);
+  return rc;
+}
+
+/* ------------------------------------------------- stage 2: chosen blocks on the device */
+
+typedef struct {
+  struct SLAEncoder* e;
+  const int32_t* res_host;     /* lattice residual planes on the host */
+  const uint32_t* job_blk; const uint32_t* job_ch;
+} ltm_ctx_t;
+
+static void ltm_one(void* vctx, uint32_t j)
+{
+  ltm_ctx_t* c = (ltm_ctx_t*)vctx;
+  struct SLAEncoder* e = c->e;
+  const uint32_t C = e->wave_format.num_channels, ntaps = e->encode_param.longterm_order;
+  const uint32_t b = c->job_blk[j], ch = c->job_ch[j];
+  blkch_t* bc = &e->bc[(size_t)b * C + ch];
+  double acf[SLAI_LTM_ACF_HEAD + 8], coef[SLAI_MAX_TAPS] = {0, 0, 0, 0, 0};
+  uint32_t t;
+  int ret;
+  {
+    double* work = (double*)malloc(sizeof(double) * slai_fft_plan_size(e->fft));
+    if (work == NULL) { bc->pitch = 0; return; }
+    slai_ltm_autocorr_host(e->fft, work, c->res_host + (size_t)ch * e->num_samples + e->blk[b].start, e->blk[b].nsmpl,
+                           acf, SLAI_LTM_ACF_HEAD);
+    free(work);
+  }
+  ret = slai_ltm_solve(acf, ntaps, &bc->pitch, coef);
+  if (ret != 0 || bc->pitch >= SLAI_LTM_MAX_PERIOD) { bc->pitch = 0; }      /* src/SLAEncoder.c:629-632 */
+  for (t = 0; t < ntaps; t++) {
+    /* Round(coef * 2^15) << 16, x86 conversion semantics       src/SLAEncoder.c:635-640 */
+    const double v = coef[t] * 32768.0;
+    const double rv = (v >= 0.0) ? floor(v + 0.5) : -floor(-v + 0.5);
+    const int32_t q = (!(rv > -2147483649.0 && rv < 2147483648.0)) ? INT32_MIN : (int32_t)rv;
+    bc->ltm_q[t] = (int32_t)((uint32_t)q << 16);
+  }
+}
+
+static int stage_blocks(struct SLAEncoder* e)
+{
+  const uint32_t C = e->wave_format.num_channels, bps = e->wave_format.bit_per_sample;
+  const uint32_t order = e->encode_param.parcor_order, O1 = order + 1, O2 = order + 2;
+  const uint32_t ms = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
+  const uint32_t ntaps = e->encode_param.longterm_order, lms = e->encode_param.lms_order_per_filter;
+  const uint32_t nb = e->num_blocks, shift = 32 - bps + e->lshift;
+  extern uint32_t sla_hip_lattice_chunk_samples(uint32_t order);
+  const uint32_t chunk_samples = sla_hip_lattice_chunk_samples(order);
+  const size_t nslots = (size_t)nb * C;
+  sla_hip_lpc_group* groups; sla_hip_lpc_cand* cands; sla_hip_lattice_chunk* chunks; sla_hip_tail_job* jobs;
+  uint32_t ngroups = 0, nchunks = 0, njobs = 0, max_window = 1, b, ch;
+  uint32_t *job_blk, *job_ch;
+  double t0;
+  int rc;
+
+  /* host result arrays */
+  if (e->bc_cap < nslots + 1) {
+    e->bc_cap = nslots + 1 + nslots / 4;
+    e->bc = (blkch_t*)realloc(e->bc, sizeof(blkch_t) * e->bc_cap);
+  }
+  if (e->coef_cap < (nslots + 1) * O1) {
+    e->coef_cap = (nslots + 1 + nslots / 4) * O1;
+    e->parcor = (double*)realloc(e->parcor, sizeof(double) * e->coef_cap);
+    e->code = (int32_t*)realloc(e->code, sizeof(int32_t) * e->coef_cap);
+    e->kint = (int32_t*)realloc(e->kint, sizeof(int32_t) * e->coef_cap);
+  }
+  if (e->bc == NULL || e->parcor == NULL || e->code == NULL || e->kint == NULL) { return SLA_APIRESULT_NG; }
+  memset(e->bc, 0, sizeof(blkch_t) * (nslots + 1));
+
+  /* descriptors */
+  {
+    size_t total_chunks = 0;
+    for (b = 0; b < nb; b++) {
+      if (e->blk[b].type != SLAI_BLK_SILENT) { total_chunks += (size_t)C * ((e->blk[b].nsmpl + chunk_samples - 1) / chunk_samples); }
+    }
+    RCCHK(pin_reserve(&e->h_groups, sizeof(sla_hip_lpc_group) * (nslots + 1)));
+    RCCHK(pin_reserve(&e->h_cands, sizeof(sla_hip_lpc_cand) * (nslots + 1)));
+    RCCHK(pin_reserve(&e->h_chunks, sizeof(sla_hip_lattice_chunk) * (total_chunks + 1)));
+    RCCHK(pin_reserve(&e->h_jobs, sizeof(sla_hip_tail_job) * (nslots + 1)));
+  }
+  groups = (sla_hip_lpc_group*)e->h_groups.ptr; cands = (sla_hip_lpc_cand*)e->h_cands.ptr;
+  chunks = (sla_hip_lattice_chunk*)e->h_chunks.ptr; jobs = (sla_hip_tail_job*)e->h_jobs.ptr;
+  for (b = 0; b < nb; b++) {
+    const blk_t* k = &e->blk[b];
+    uint32_t woff = 0, at;
+    if (k->type == SLAI_BLK_SILENT) { continue; }
+    if (k->nsmpl > MAX_ANALYSIS_WINDOW) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
+    RCCHK(window_offset(e, k->nsmpl, &woff));
+    for (ch = 0; ch < C; ch++) {
+      sla_hip_lpc_group* g = &groups[ngroups];
+      g->pcm_off = k->start; g->num_samples = k->nsmpl; g->channel = ch; g->win_off = woff; g->int_shift = shift;
+      g->cand_first = ngroups; g->cand_count = 1; g->slot_first = b * C + ch; g->pad_ = 0;
+      cands[ngroups].start = 0; cands[ngroups].len = k->nsmpl;
+      ngroups++;
+      for (at = 0; at < k->nsmpl; at += chunk_samples) {
+        sla_hip_lattice_chunk* c = &chunks[nchunks++];
+        c->blk_off = k->start; c->blk_len = k->nsmpl; c->chunk_start = at;
+        c->count = (k->nsmpl - at < chunk_samples) ? (k->nsmpl - at) : chunk_samples;
+        c->channel = ch; c->slot = b * C + ch; c->int_shift = shift;
+      }
+    }
+    if (k->nsmpl > max_window) { max_window = k->nsmpl; }
+  }
+
+  RCCHK(dev_reserve(&e->d_res1, sizeof(int32_t) * (size_t)C * e->stride));
+  RCCHK(dev_reserve(&e->d_res2, sizeof(int32_t) * (size_t)C * e->stride));
+  RCCHK(dev_reserve(&e->d_lpc_out, sizeof(double) * (nslots + 1) * O2));
+  RCCHK(dev_reserve(&e->d_code, sizeof(int32_t) * (nslots + 1) * O1));
+  RCCHK(dev_reserve(&e->d_kint, sizeof(int32_t) * (nslots + 1) * O1));
+  RCCHK(dev_reserve(&e->d_rshift, sizeof(uint32_t) * (nslots + 1)));
+  RCCHK(pin_reserve(&e->h_lpc_out, sizeof(double) * (nslots + 1) * O2));
+  RCCHK(pin_reserve(&e->h_code, sizeof(int32_t) * (nslots + 1) * O1));
+  RCCHK(pin_reserve(&e->h_kint, sizeof(int32_t) * (nslots + 1) * O1));
+  RCCHK(pin_reserve(&e->h_rshift, sizeof(uint32_t) * (nslots + 1)));
+  HIPCHK(hipEventRecord(e->ev[4], e->stream));
+  HIPCHK(hipEventRecord(e->ev[5], e->stream));
+  HIPCHK(hipEventRecord(e->ev[6], e->stream));
+  if (ngroups > 0) {
+    if (e->win_dirty) {
+      RCCHK(dev_reserve(&e->d_winpool, sizeof(double) * e->win_count));
+      HIPCHK(hipMemcpyAsync(e->d_winpool.ptr, e->win_host, sizeof(double) * e->win_count, hipMemcpyHostToDevice, e->stream));
+      e->win_dirty = 0;
+    }
+    RCCHK(dev_reserve(&e->d_groups, sizeof(sla_hip_lpc_group) * ngroups));
+    RCCHK(dev_reserve(&e->d_cands, sizeof(sla_hip_lpc_cand) * ngroups));
+    RCCHK(dev_reserve(&e->d_chunks, sizeof(sla_hip_lattice_chunk) * nchunks));
+    HIPCHK(hipMemcpyAsync(e->d_groups.ptr, groups, sizeof(sla_hip_lpc_group) * ngroups, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_cands.ptr, cands, sizeof(sla_hip_lpc_cand) * ngroups, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_chunks.ptr, chunks, sizeof(sla_hip_lattice_chunk) * nchunks, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(e->d_code.ptr, 0, sizeof(int32_t) * (nslots + 1) * O1, e->stream));
+    HIPCHK(hipMemsetAsync(e->d_kint.ptr, 0, sizeof(int32_t) * (nslots + 1) * O1, e->stream));
+    HIPCHK(hipMemsetAsync(e->d_rshift.ptr, 0, sizeof(uint32_t) * (nslots + 1), e->stream));
+    HIPCHK(hipMemsetAsync(e->d_lpc_out.ptr, 0, sizeof(double) * (nslots + 1) * O2, e->stream));
+    HIPCHK(hipEventRecord(e->ev[4], e->stream));
+    RCCHK(sla_hip_launch_lpc(e->pcm_dev, e->stride, ms, order, (const sla_hip_lpc_group*)e->d_groups.ptr, ngroups,
+                             max_window, 1, (const sla_hip_lpc_cand*)e->d_cands.ptr, (const double*)e->d_winpool.ptr,
+                             (double*)e->d_lpc_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
+                             (uint32_t*)e->d_rshift.ptr, e->stream));
+    HIPCHK(hipEventRecord(e->ev[5], e->stream));
+    RCCHK(sla_hip_launch_lattice(e->pcm_dev, e->stride, ms, order, (const sla_hip_lattice_chunk*)e->d_chunks.ptr, nchunks,
+                                 (const int32_t*)e->d_kint.ptr, (int32_t*)e->d_res1.ptr, e->stream));
+    HIPCHK(hipEventRecord(e->ev[6], e->stream));
+    HIPCHK(hipMemcpyAsync(e->h_lpc_out.ptr, e->d_lpc_out.ptr, sizeof(double) * nslots * O2, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->h_code.ptr, e->d_code.ptr, sizeof(int32_t) * nslots * O1, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->h_kint.ptr, e->d_kint.ptr, sizeof(int32_t) * nslots * O1, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->h_rshift.ptr, e->d_rshift.ptr, sizeof(uint32_t) * nslots, hipMemcpyDeviceToHost, e->stream));
+    /* long-term analysis input (host FFT in this round) */
+    RCCHK(pin_reserve(&e->h_res, sizeof(int32_t) * (size_t)C * e->num_samples));
+    for (ch = 0; ch < C; ch++) {
+      HIPCHK(hipMemcpyAsync((int32_t*)e->h_res.ptr + (size_t)ch * e->num_samples, (int32_t*)e->d_res1.ptr + (size_t)ch * e->stride,
+                            sizeof(int32_t) * e->num_samples, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+
+  /* ---- host: RAW decision per block (any channel's estimate >= 0.95)   src/SLAEncoder.c:553-565 */
+  t0 = now_ms();
+  job_blk = (uint32_t*)malloc(sizeof(uint32_t) * (nslots + 1));
+  job_ch = (uint32_t*)malloc(sizeof(uint32_t) * (nslots + 1));
+  if (job_blk == NULL || job_ch == NULL) { free(job_blk); free(job_ch); return SLA_APIRESULT_NG; }
+  for (b = 0; b < nb; b++) {
+    blk_t* k = &e->blk[b];
+    if (k->type == SLAI_BLK_SILENT) { continue; }
+    for (ch = 0; ch < C; ch++) {
+      const size_t slot = (size_t)b * C + ch;
+      const double* o = (const double*)e->h_lpc_out.ptr + slot * O2;
+      double est;
+      memcpy(e->parcor + slot * O1, o + 1, sizeof(double) * O1);
+      memcpy(e->code + slot * O1, (const int32_t*)e->h_code.ptr + slot * O1, sizeof(int32_t) * O1);
+      memcpy(e->kint + slot * O1, (const int32_t*)e->h_kint.ptr + slot * O1, sizeof(int32_t) * O1);
+      e->bc[slot].rshift = ((const uint32_t*)e->h_rshift.ptr)[slot];
+      est = slai_code_length(o[0], k->nsmpl, bps, o + 1, order);
+      est = (8 * est) / bps;
+      if (est >= SLAI_RAW_THRESHOLD) { k->type = SLAI_BLK_RAW; break; }
+    }
+    if (k->type == SLAI_BLK_COMPRESS) {
+      for (ch = 0; ch < C; ch++) { job_blk[njobs] = b; job_ch[njobs] = ch; njobs++; }
+    }
+  }
+
+  /* ---- host: long-term analysis (pitch + taps) per compressed (block, channel) ---------- */
+  {
+    ltm_ctx_t lc;
+    lc.e = e; lc.res_host = (const int32_t*)e->h_res.ptr; lc.job_blk = job_blk; lc.job_ch = job_ch;
+    parallel_for(e->threads, njobs, ltm_one, &lc);
+  }
+  e->timing[6] = (float)(now_ms() - t0);
+
+  /* ---- tail kernel: long-term filter + LMS + folded sum --------------------------------- */
+  HIPCHK(hipEventRecord(e->ev[7], e->stream));
+  HIPCHK(hipEventRecord(e->ev[8], e->stream));
+  if (njobs > 0) {
+    uint32_t j, t;
+    const uint64_t* fold;
+    for (j = 0; j < njobs; j++) {
+      const blk_t* k = &e->blk[job_blk[j]];
+      const blkch_t* bc = &e->bc[(size_t)job_blk[j] * C + job_ch[j]];
+      jobs[j].blk_off = k->start; jobs[j].blk_len = k->nsmpl; jobs[j].channel = job_ch[j]; jobs[j].pitch = bc->pitch;
+      for (t = 0; t < SLAI_MAX_TAPS; t++) { jobs[j].ltm_coef[t] = bc->ltm_q[t]; }
+      jobs[j].pad_[0] = jobs[j].pad_[1] = 0;
+    }
+    RCCHK(dev_reserve(&e->d_jobs, sizeof(sla_hip_tail_job) * njobs));
+    RCCHK(dev_reserve(&e->d_fold, sizeof(uint64_t) * njobs));
+    RCCHK(pin_reserve(&e->h_fold, sizeof(uint64_t) * njobs));
+    HIPCHK(hipMemcpyAsync(e->d_jobs.ptr, jobs, sizeof(sla_hip_tail_job) * njobs, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipEventRecord(e->ev[7], e->stream));
+    rc = sla_hip_launch_tail((const int32_t*)e->d_res1.ptr, (int32_t*)e->d_res2.ptr, e->stride,
+                             (const sla_hip_tail_job*)e->d_jobs.ptr, njobs, ntaps, lms, (uint64_t*)e->d_fold.ptr, e->stream);
+    if (rc != 0) { free(job_blk); free(job_ch); return rc; }
+    HIPCHK(hipEventRecord(e->ev[8], e->stream));
+    HIPCHK(hipMemcpyAsync(e->h_fold.ptr, e->d_fold.ptr, sizeof(uint64_t) * njobs, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    fold = (const uint64_t*)e->h_fold.ptr;
+    for (j = 0; j < njobs; j++) {
+      /* mean of the folded residual, at least 1                 src/SLACoder.c:371-384 */
+      const uint64_t mean = fold[j] / e->blk[job_blk[j]].nsmpl;
+      e->bc[(size_t)job_blk[j] * C + job_ch[j]].rice_init = (uint32_t)(mean > 1 ? mean : 1);
+    }
+  }
+  free(job_blk); free(job_ch);
+  return 0;
+}
+
+static int check_ready(const struct SLAEncoder* e)
+{
+  if (!(e->status_flag & STATUS_WAVE_FORMAT) || !(e->status_flag & STATUS_ENCODE_PARAM)) { return SLA_APIRESULT_PARAMETER_NOT_SET; }
+  if (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS && e->wave_format.num_channels != 2) {
+    return SLA_APIRESULT_INVAILD_CHPROCESSMETHOD;
+  }
+  if ((int)e->encode_param.window_function_type < 0
+      || (int)e->encode_param.window_function_type > (int)SLA_WINDOWFUNCTIONTYPE_VORBIS) { return SLA_APIRESULT_INVALID_WINDOWFUNCTION_TYPE; }
+  {
+    const uint32_t l = e->encode_param.lms_order_per_filter;
+    if (!(l == 4 || l == 8 || l == 16 || l == 32)) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
+    if (!(e->encode_param.longterm_order & 1u)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  }
+  return 0;
+}
+
+static void collect_timing(struct SLAEncoder* e, double t_start)
+{
+  float ms = 0.f;
+  e->timing[0] = (hipEventElapsedTime(&ms, e->ev[0], e->ev[1]) == hipSuccess) ? ms : -1.f;
+  e->timing[1] = (hipEventElapsedTime(&ms, e->ev[2], e->ev[3]) == hipSuccess) ? ms : -1.f;
+  e->timing[2] = (hipEventElapsedTime(&ms, e->ev[4], e->ev[5]) == hipSuccess) ? ms : -1.f;
+  e->timing[3] = (hipEventElapsedTime(&ms, e->ev[5], e->ev[6]) == hipSuccess) ? ms : -1.f;
+  e->timing[4] = (hipEventElapsedTime(&ms, e->ev[7], e->ev[8]) == hipSuccess) ? ms : -1.f;
+  e->timing[7] = (float)(now_ms() - t_start);
+}
+
+int sla_hip_analyze_device(struct SLAEncoder* e, const int32_t* d_pcm, uint64_t plane_stride,
+                           uint32_t num_samples, sla_hip_stream_t stream, float* timing_ms)
+{
+  const double t_start = now_ms();
+  int rc;
+  if (e == NULL || d_pcm == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  RCCHK(check_ready(e));
+  if (plane_stride < num_samples) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (stream != NULL) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); }   /* producer of d_pcm */
+  e->analysed = 0;
+  e->pcm_dev = d_pcm; e->stride = plane_stride; e->num_samples = num_samples;
+  memset(e->timing, 0, sizeof(e->timing));
+  rc = stage_plan(e);
+  if (rc == 0) { rc = stage_blocks(e); }
+  if (rc != 0) { (void)hipStreamSynchronize(e->stream); return rc; }
+  e->wave_format.offset_lshift = (uint8_t)e->lshift;
+  collect_timing(e, t_start);
+  if (timing_ms != NULL) { memcpy(timing_ms, e->timing, sizeof(e->timing)); }
+  e->analysed = 1;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ pack */
+
+typedef struct {
+  struct SLAEncoder* e;
+  const int32_t* res;          /* final residual planes on host, stride = num_samples */
+  const int32_t* const* pcm;   /* host PCM planes (for RAW blocks), may be NULL */
+  uint8_t** bufs; uint32_t* sizes;
+} pack_ctx_t;
+
+static void pack_one(void* vctx, uint32_t b)
+{
+  pack_ctx_t* c = (pack_ctx_t*)vctx;
+  struct SLAEncoder* e = c->e;
+  const uint32_t C = e->wave_format.num_channels, O1 = e->encode_param.parcor_order + 1;
+  const blk_t* k = &e->blk[b];
+  slai_block_params bp;
+  uint32_t rshift[SLAI_MAX_CHANNELS], pitch[SLAI_MAX_CHANNELS], rice[SLAI_MAX_CHANNELS], ch, s;
+  int32_t ltm[SLAI_MAX_CHANNELS * SLAI_MAX_TAPS];
+  int32_t* raw[SLAI_MAX_CHANNELS] = {0};
+  uint32_t cap = 64 + C * (8 + 2 * O1 + 16);
+  uint8_t* buf;
+  memset(&bp, 0, sizeof(bp));
+  bp.num_samples = k->nsmpl; bp.type = k->type; bp.num_channels = C; bp.order = O1 - 1;
+  bp.ntaps = e->encode_param.longterm_order; bp.bps = e->wave_format.bit_per_sample; bp.lshift = e->lshift;
+  bp.mid_side = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
+  for (ch = 0; ch < C; ch++) {
+    const blkch_t* bc = &e->bc[(size_t)b * C + ch];
+    rshift[ch] = bc->rshift; pitch[ch] = bc->pitch; rice[ch] = bc->rice_init;
+    memcpy(&ltm[ch * SLAI_MAX_TAPS], bc->ltm_q, sizeof(int32_t) * SLAI_MAX_TAPS);
+  }
+  bp.code = e->code + (size_t)b * C * O1; bp.rshift = rshift; bp.pitch = pitch; bp.ltm_q = ltm; bp.rice_init = rice;
+  if (k->type == SLAI_BLK_COMPRESS) {
+    for (ch = 0; ch < C; ch++) { bp.res[ch] = c->res + (size_t)ch * e->num_samples + k->start; }
+    cap += 8 * C * k->nsmpl;
+  } else if (k->type == SLAI_BLK_RAW) {
+    const uint32_t shift = 32 - bp.bps + e->lshift;
+    for (ch = 0; ch < C; ch++) { raw[ch] = (int32_t*)malloc(sizeof(int32_t) * k->nsmpl); bp.res[ch] = raw[ch]; }
+    for (s = 0; s < k->nsmpl; s++) {
+      if (bp.mid_side) {
+        const int32_t l = c->pcm[0][k->start + s] >> shift, r = c->pcm[1][k->start + s] >> shift;
+        raw[0][s] = (int32_t)((uint32_t)l + (uint32_t)r) >> 1;
+        raw[1][s] = (int32_t)((uint32_t)l - (uint32_t)r);
+      } else {
+        for (ch = 0; ch < C; ch++) { raw[ch][s] = c->pcm[ch][k->start + s] >> shift; }
+      }
+    }
+    cap += 8 * C * k->nsmpl;
+  }
+  for (;;) {
+    buf = (uint8_t*)malloc(cap);
+    if (buf == NULL) { c->sizes[b] = 0; break; }
+    c->sizes[b] = slai_pack_block(&bp, buf, cap);
+    if (c->sizes[b] != 0 || cap > (1u << 30)) { break; }
+    free(buf); buf = NULL;
+    cap *= 4;                       /* pathological residuals: unary runs can be long */
+  }
+  c->bufs[b] = buf;
+  for (ch = 0; ch < C; ch++) { free(raw[ch]); }
+}
+
+static int pack_impl(struct SLAEncoder* e, const int32_t* const* host_pcm, uint8_t* data, uint32_t data_size, uint32_t* output_size)
+{
+  const uint32_t C = e->wave_format.num_channels, n = e->num_samples;
+  struct SLAHeaderInfo hdr;
+  pack_ctx_t ctx;
+  uint32_t b, ch, cur = SLA_HEADER_SIZE, maxblk = 0, maxbps = 0;
+  const int32_t* planes[SLAI_MAX_CHANNELS];
+  int need_raw = 0, rc = 0;
+  if (!e->analysed) { return SLA_APIRESULT_PARAMETER_NOT_SET; }
+  if (data == NULL || output_size == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (data_size < SLA_HEADER_SIZE) { return SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE; }
+  /* D2H of the final residual */
+  RCCHK(pin_reserve(&e->h_res, sizeof(int32_t) * (size_t)C * (n + 1)));
+  for (ch = 0; ch < C && n > 0 && e->d_res2.ptr != NULL; ch++) {
+    HIPCHK(hipMemcpyAsync((int32_t*)e->h_res.ptr + (size_t)ch * n, (int32_t*)e->d_res2.ptr + (size_t)ch * e->stride,
+                          sizeof(int32_t) * n, hipMemcpyDeviceToHost, e->stream));
+  }
+  for (b = 0; b < e->num_blocks; b++) { if (e->blk[b].type == SLAI_BLK_RAW) { need_raw = 1; } }
+  if (need_raw && host_pcm == NULL) {
+    RCCHK(pin_reserve(&e->h_pcm, sizeof(int32_t) * (size_t)C * (n + 1)));
+    for (ch = 0; ch < C; ch++) {
+      HIPCHK(hipMemcpyAsync((int32_t*)e->h_pcm.ptr + (size_t)ch * n, e->pcm_dev + (size_t)ch * e->stride,
+                            sizeof(int32_t) * n, hipMemcpyDeviceToHost, e->stream));
+      planes[ch] = (const int32_t*)e->h_pcm.ptr + (size_t)ch * n;
+    }
+    host_pcm = planes;
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+
+  ctx.e = e; ctx.res = (const int32_t*)e->h_res.ptr; ctx.pcm = host_pcm;
+  ctx.bufs = (uint8_t**)calloc(e->num_blocks + 1, sizeof(uint8_t*));
+  ctx.sizes = (uint32_t*)calloc(e->num_blocks + 1, sizeof(uint32_t));
+  if (ctx.bufs == NULL || ctx.sizes == NULL) { free(ctx.bufs); free(ctx.sizes); return SLA_APIRESULT_NG; }
+  parallel_for(e->threads, e->num_blocks, pack_one, &ctx);
+
+  for (b = 0; b < e->num_blocks; b++) {
+    uint32_t bps_blk;
+    if (ctx.bufs[b] == NULL || ctx.sizes[b] == 0) { rc = SLA_APIRESULT_NG; break; }
+    if (cur >= data_size || ctx.sizes[b] > data_size - cur) { rc = SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE; break; }
+    memcpy(data + cur, ctx.bufs[b], ctx.sizes[b]);
+    e->blk[b].bytes = ctx.sizes[b];
+    cur += ctx.sizes[b];
+    if (ctx.sizes[b] > maxblk) { maxblk = ctx.sizes[b]; }
+    bps_blk = (8 * ctx.sizes[b] * e->wave_format.sampling_rate) / e->blk[b].nsmpl;     /* src/SLAEncoder.c:895 */
+    if (bps_blk > maxbps) { maxbps = bps_blk; }
+  }
+  for (b = 0; b < e->num_blocks; b++) { free(ctx.bufs[b]); }
+  free(ctx.bufs); free(ctx.sizes);
+  if (rc != 0) { return rc; }
+  hdr.wave_format = e->wave_format; hdr.wave_format.offset_lshift = (uint8_t)e->lshift;
+  hdr.encode_param = e->encode_param; hdr.num_samples = n; hdr.num_blocks = e->num_blocks;
+  hdr.max_block_size = maxblk; hdr.max_bit_per_second = maxbps;
+  rc = slai_write_header(&hdr, data, data_size);
+  *output_size = cur;
+  return rc;
+}
+
+int sla_hip_pack(struct SLAEncoder* e, uint8_t* data, uint32_t data_size, uint32_t* output_size)
+{
+  if (e == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  return pack_impl(e, NULL, data, data_size, output_size);
+}
+
+/* -------------------------------------------------------------- public encode API */
+
+static int upload_pcm(struct SLAEncoder* e, const int32_t* const* input, uint32_t n)
+{
+  const uint32_t C = e->wave_format.num_channels;
+  uint32_t ch;
+  const uint64_t stride = ((uint64_t)n + 63) & ~(uint64_t)63;
+  RCCHK(dev_reserve(&e->d_pcm, sizeof(int32_t) * (size_t)C * (stride + 64)));
+  for (ch = 0; ch < C; ch++) {
+    if (input[ch] == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+    HIPCHK(hipMemcpyAsync((int32_t*)e->d_pcm.ptr + (size_t)ch * stride, input[ch], sizeof(int32_t) * n, hipMemcpyHostToDevice, e->stream));
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->pcm_dev = (const int32_t*)e->d_pcm.ptr; e->stride = stride; e->num_samples = n;
+  return 0;
+}
+
+SLAApiResult SLAEncoder_EncodeWhole(struct SLAEncoder* e, const int32_t* const* input, uint32_t num_samples,
+                                    uint8_t* data, uint32_t data_size, uint32_t* output_size)
+{
+  int rc;
+  if (e == NULL || input == NULL || data == NULL || output_size == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if ((rc = check_ready(e)) != 0) { return (SLAApiResult)rc; }
+  if (data_size < SLA_HEADER_SIZE) { return SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE; }
+  if ((rc = upload_pcm(e, input, num_samples)) != 0) { return (rc > 0) ? (SLAApiResult)rc : SLA_APIRESULT_NG; }
+  rc = sla_hip_analyze_device(e, e->pcm_dev, e->stride, num_samples, NULL, NULL);
+  if (rc == 0) { rc = pack_impl(e, input, data, data_size, output_size); }
+  return (rc >= 0) ? (SLAApiResult)rc : SLA_APIRESULT_NG;
+}
+
+/* One block with the encoder's current offset_lshift; no partition search (src/SLAEncoder.c:458-801). */
+SLAApiResult SLAEncoder_EncodeBlock(struct SLAEncoder* e, const int32_t* const* input, uint32_t num_samples,
+                                    uint8_t* data, uint32_t data_size, uint32_t* output_size)
+{
+  const int32_t* planes[SLAI_MAX_CHANNELS];
+  uint8_t* tmp;
+  uint32_t C, ch, size = 0, cap;
+  uint64_t nwords;
+  int rc;
+  if (e == NULL || input == NULL || data == NULL || output_size == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (!(e->status_flag & STATUS_WAVE_FORMAT) || !(e->status_flag & STATUS_ENCODE_PARAM)) { return SLA_APIRESULT_PARAMETER_NOT_SET; }
+  if (num_samples > e->cfg.max_num_block_samples || num_samples > MAX_ANALYSIS_WINDOW) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
+  if (data_size <= SLA_BLOCK_HEADER_SIZE) { return SLA_APIRESULT_INSUFFICIENT_DATA_SIZE; }
+  if ((rc = check_ready(e)) != 0) { return (SLAApiResult)rc; }
+  if (num_samples == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  C = e->wave_format.num_channels;
+  if ((rc = upload_pcm(e, input, num_samples)) != 0) { return (rc > 0) ? (SLAApiResult)rc : SLA_APIRESULT_NG; }
+  e->analysed = 0;
+  e->lshift = e->wave_format.offset_lshift;
+  memset(e->timing, 0, sizeof(e->timing));
+  /* silence test through the prepass mask */
+  nwords = ((uint64_t)num_samples + 63) / 64;
+  if (dev_reserve(&e->d_or, 64) || dev_reserve(&e->d_nz, (size_t)(nwords + 2) * 8) || pin_reserve(&e->h_nz, (size_t)(nwords + 2) * 8)) { return SLA_APIRESULT_NG; }
+  rc = sla_hip_launch_prepass(e->pcm_dev, e->stride, C, num_samples, e->wave_format.bit_per_sample,
+                              e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS,
+                              (uint32_t*)e->d_or.ptr, (uint64_t*)e->d_nz.ptr, e->stream);
+  if (rc != 0) { return SLA_APIRESULT_NG; }
+  if (hipMemcpyAsync(e->h_nz.ptr, e->d_nz.ptr, (size_t)nwords * 8, hipMemcpyDeviceToHost, e->stream) != hipSuccess
+      || hipStreamSynchronize(e->stream) != hipSuccess) { return SLA_APIRESULT_NG; }
+  ((uint64_t*)e->h_nz.ptr)[nwords] = 0;
+  e->num_blocks = 0;
+  if (blocks_push(e, 0, num_samples, slai_range_is_zero((const uint64_t*)e->h_nz.ptr, 0, num_samples) ? SLAI_BLK_SILENT : SLAI_BLK_COMPRESS) != 0) {
+    return SLA_APIRESULT_NG;
+  }
+  { int i; for (i = 0; i < 4; i++) { (void)hipEventRecord(e->ev[i], e->stream); } }
+  rc = stage_blocks(e);
+  if (rc != 0) { return (rc > 0) ? (SLAApiResult)rc : SLA_APIRESULT_NG; }
+  e->analysed = 1;
+  /* pack into a scratch image (header + block) and hand back the block bytes only */
+  cap = SLA_HEADER_SIZE + 64 + 16 * C * num_samples + 4096;
+  tmp = (uint8_t*)malloc(cap);
+  if (tmp == NULL) { return SLA_APIRESULT_NG; }
+  for (ch = 0; ch < C; ch++) { planes[ch] = input[ch]; }
+  rc = pack_impl(e, planes, tmp, cap, &size);
+  if (rc == 0) {
+    size -= SLA_HEADER_SIZE;
+    if (size > data_size) { rc = SLA_APIRESULT_INSUFFICIENT_DATA_SIZE; }
+    else { memcpy(data, tmp + SLA_HEADER_SIZE, size); *output_size = size; }
+  }
+  free(tmp);
+  return (rc >= 0) ? (SLAApiResult)rc : SLA_APIRESULT_NG;
+}
+
+/* ------------------------------------------------------------------- introspection */
+
+const int32_t* sla_hip_final_residual(const struct SLAEncoder* e, uint64_t* plane_stride)
+{
+  if (e == NULL || !e->analysed) { return NULL; }
+  if (plane_stride != NULL) { *plane_stride = e->stride; }
+  return (const int32_t*)e->d_res2.ptr;
+}
+
+const int32_t* sla_hip_lattice_residual(const struct SLAEncoder* e, uint64_t* plane_stride)
+{
+  if (e == NULL || !e->analysed) { return NULL; }
+  if (plane_stride != NULL) { *plane_stride = e->stride; }
+  return (const int32_t*)e->d_res1.ptr;
+}
+
+int sla_hip_get_trace(struct SLAEncoder* e, sla_hip_trace* tr)
+{
+  uint32_t C, O1, b, ch, t;
+  if (e == NULL || tr == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (!e->analysed) { return SLA_APIRESULT_PARAMETER_NOT_SET; }
+  C = e->wave_format.num_channels; O1 = e->encode_param.parcor_order + 1;
+  if (tr->max_blocks < e->num_blocks || tr->order_stride < O1 || tr->sample_stride < e->num_samples
+      || (tr->ltm_stride < e->encode_param.longterm_order)) { return SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE; }
+  tr->num_blocks = e->num_blocks; tr->offset_lshift = e->lshift;
+  for (b = 0; b < e->num_blocks; b++) {
+    tr->blk_start[b] = e->blk[b].start; tr->blk_nsmpl[b] = e->blk[b].nsmpl;
+    tr->blk_type[b] = e->blk[b].type; tr->blk_bytes[b] = e->blk[b].bytes;
+    for (ch = 0; ch < C; ch++) {
+      const size_t slot = (size_t)b * C + ch;
+      const blkch_t* bc = &e->bc[slot];
+      if (e->blk[b].type != SLAI_BLK_COMPRESS) { tr->rshift[slot] = 0; tr->pitch[slot] = 0; tr->rice_init[slot] = 0; continue; }
+      for (t = 0; t < O1; t++) {
+        tr->parcor[slot * tr->order_stride + t] = e->parcor[slot * O1 + t];
+        tr->code[slot * tr->order_stride + t] = e->code[slot * O1 + t];
+        tr->kint[slot * tr->order_stride + t] = e->kint[slot * O1 + t];
+      }
+      tr->rshift[slot] = bc->rshift; tr->pitch[slot] = bc->pitch; tr->rice_init[slot] = bc->rice_init;
+      for (t = 0; t < e->encode_param.longterm_order; t++) { tr->ltm_coef[slot * tr->ltm_stride + t] = bc->ltm_q[t]; }
+    }
+  }
+  for (ch = 0; ch < C && e->num_samples > 0; ch++) {
+    if (tr->res_lattice != NULL && e->d_res1.ptr != NULL) {
+      HIPCHK(hipMemcpy(tr->res_lattice + (size_t)ch * tr->sample_stride, (int32_t*)e->d_res1.ptr + (size_t)ch * e->stride,
+                       sizeof(int32_t) * e->num_samples, hipMemcpyDeviceToHost));
+    }
+    if (tr->res_final != NULL && e->d_res2.ptr != NULL) {
+      HIPCHK(hipMemcpy(tr->res_final + (size_t)ch * tr->sample_stride, (int32_t*)e->d_res2.ptr + (size_t)ch * e->stride,
+                       sizeof(int32_t) * e->num_samples, hipMemcpyDeviceToHost));
+    }
+  }
+  return 0;
+}

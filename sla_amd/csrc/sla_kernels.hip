@@ -1,0 +1,453 @@
+// sla_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the SLA encode hot path.
+//
+// Written for 64-lane wavefronts, 160 KiB LDS per CU, no MFMA (there is no dense
+// contraction anywhere on this path: FP64 VALU chains + int32 VALU).  Built with
+// -ffp-contract=off: every FP64 product and sum below is rounded separately, in the
+// order written, because the PARCOR codes that reach the bit stream come from
+// Round(k * 2^(q-1)) of these doubles (reference src/SLAEncoder.c:578-582) and the
+// reference x86-64 build has no FMA.
+//
+// Kernel                      replaces (reference file:line)
+//   k_prepass                 src/SLAEncoder.c:425-455 (OR of all words), :392-408 / :520-528 (silence)
+//   k_lpc                     src/SLAPredictor.c:331-388 (autocorrelation, paired-product order),
+//                             :253-328 (Levinson-Durbin), src/SLAEncoder.c:505-515,540-543 (staging),
+//                             src/SLAUtility.c:370-412 (mid/side), src/SLAEncoder.c:567-589 (quantiser)
+//   k_lattice                 src/SLAPredictor.c:1741-1765 (pre-emphasis), :557-607 (PARCOR lattice)
+//   k_tail                    src/SLAPredictor.c:1031-1119 (long-term filter), :1202-1331 (sign-log LMS),
+//                             src/SLACoder.c:361-385 (mean of folded residual)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+#include "sla_hip.h"
+
+#define SLA_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// shared helpers
+// ---------------------------------------------------------------------------------------------
+
+// right-justified integer sample of output channel `ch` (mid/side when ms != 0)
+__device__ __forceinline__ int32_t load_int(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
+                                            uint32_t ch, uint64_t idx, uint32_t shift)
+{
+  if (!ms) { return pcm[(uint64_t)ch * stride + idx] >> shift; }
+  int32_t l = pcm[idx] >> shift, r = pcm[stride + idx] >> shift;
+  // mid = (L+R)>>1 (arithmetic, wrapping sum), side = L-R      src/SLAUtility.c:403-411
+  return (ch == 0) ? ((int32_t)((uint32_t)l + (uint32_t)r) >> 1) : (int32_t)((uint32_t)l - (uint32_t)r);
+}
+
+// analysis sample: (double)in * 2^-31, mid = (l+r)/2, side = l-r   src/SLAEncoder.c:507, src/SLAUtility.c:382-387
+__device__ __forceinline__ double load_f64(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
+                                           uint32_t ch, uint64_t idx)
+{
+  const double scale = 4.656612873077392578125e-10;   // 2^-31, exact
+  if (!ms) { return (double)pcm[(uint64_t)ch * stride + idx] * scale; }
+  double l = (double)pcm[idx] * scale, r = (double)pcm[stride + idx] * scale;
+  return (ch == 0) ? ((l + r) / 2) : (l - r);
+}
+
+__device__ __forceinline__ uint32_t umax_wave(uint32_t v)
+{
+  for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(v, off); v = (o > v) ? o : v; }
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_prepass: one 64-bit "non-zero" word per 64 samples + OR of every raw word
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_prepass(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t nch, uint32_t n,
+               uint32_t shift, uint32_t ms, uint32_t* __restrict__ or_mask, uint64_t* __restrict__ nz_mask)
+{
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint64_t nwords = ((uint64_t)n + 63) / 64;
+  uint32_t acc = 0;
+  // each wave owns 64 consecutive mask words = 4096 samples, read fully coalesced
+  for (uint32_t w = 0; w < 64; w++) {
+    uint64_t word = wave * 64 + w;
+    if (word >= nwords) { break; }
+    uint64_t idx = word * 64 + lane;
+    bool nz = false;
+    if (idx < n) {
+      for (uint32_t c = 0; c < nch; c++) { acc |= (uint32_t)pcm[(uint64_t)c * stride + idx]; }
+      for (uint32_t c = 0; c < nch; c++) { nz = nz || (load_int(pcm, stride, ms, c, idx, shift) != 0); }
+    }
+    uint64_t bits = __ballot(nz);
+    if (lane == 0) { nz_mask[word] = bits; }
+  }
+  for (int off = 32; off > 0; off >>= 1) { acc |= __shfl_xor(acc, off); }
+  if (lane == 0 && acc != 0) { atomicOr(or_mask, acc); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_lpc: autocorrelation chains + Levinson-Durbin (+ quantiser) per LDS-staged window
+//
+// LDS: x[x_region] doubles | r[cands*(order+1)];  x_region >= max(W, 2*cands*(order+2)) because the
+// Levinson work vectors a[], v[] overlay the sample window once the chains are done.
+// One thread owns one (candidate, lag) chain at a time: the sum over a lag is a strictly
+// sequential FP64 accumulation (the reference's order decides the rounding), so the available
+// parallelism is (candidates x lags x groups), not the samples of one sum.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double chain_lag0(const double* __restrict__ xs, uint32_t n)
+{
+  double acc = 0.0;
+  for (uint32_t i = 0; i < n; i++) { double v = xs[i]; acc += v * v; }
+  return acc;
+}
+
+// lag >= 1, lag < n.  Order of terms: for i in [0,lag): for l in {0,2lag,..,span-2lag}:
+//   x[l+lag+i]*(x[l+i]+x[l+2lag+i]);  then the leftover products x[span+lag+i]*x[span+i].
+__device__ __forceinline__ double chain_lag(const double* __restrict__ xs, uint32_t n, uint32_t lag)
+{
+  const uint32_t lag2 = lag << 1;
+  const uint32_t groups = ((3 * lag) < n) ? (1 + (n - 3 * lag) / lag2) : 0;
+  const uint32_t span = groups * lag2;
+  double acc = 0.0;
+  // flattened (i, l) walk so that lanes with different lags stay in one loop
+  uint32_t steps = groups * lag, i = 0, l = 0;
+  for (uint32_t s = 0; s < steps; s++) {
+    double c = xs[l + lag + i];
+    double e = xs[l + i] + xs[l + lag2 + i];
+    acc += c * e;
+    l += lag2;
+    if (l >= span) { l = 0; i++; }
+  }
+  const uint32_t rest = n - span - lag;
+  const double* t = xs + span;
+  for (uint32_t k = 0; k < rest; k++) { acc += t[lag + k] * t[k]; }
+  return acc;
+}
+
+// x86 cvttsd2si semantics of (int32_t)double (reference quantiser runs on x86-64)
+__device__ __forceinline__ int32_t f64_to_i32_x86(double v)
+{
+  if (!(v > -2147483649.0 && v < 2147483648.0)) { return (int32_t)0x80000000; }
+  return (int32_t)v;
+}
+
+__global__ __launch_bounds__(256)
+void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
+           const sla_hip_lpc_group* __restrict__ groups, const sla_hip_lpc_cand* __restrict__ cands,
+           const double* __restrict__ window_pool, double* __restrict__ out,
+           int32_t* __restrict__ out_code, int32_t* __restrict__ out_kint, uint32_t* __restrict__ out_rshift,
+           uint32_t x_region)
+{
+  extern __shared__ double lds[];
+  const sla_hip_lpc_group g = groups[blockIdx.x];
+  const uint32_t W = g.num_samples, nc = g.cand_count, O1 = order + 1, O2 = order + 2;
+  double* x = lds;                 // [x_region]: staged samples; re-used as Levinson scratch afterwards
+  double* r = x + x_region;        // [nc*O1]
+  double* av = x;                  // [nc*O2] overlay (x is dead once every chain has finished)
+  double* vv = x + nc * O2;        // [nc*O2] overlay
+  const sla_hip_lpc_cand* cd = cands + g.cand_first;
+  const bool windowed = (g.win_off != SLA_HIP_NO_WINDOW);
+  const double* win = window_pool + (windowed ? g.win_off : 0);
+  __shared__ uint32_t s_maxabs[4];
+
+  // ---- stage the window (A0 + A4): convert, mid/side, window, pre-emphasis --------------------
+  uint32_t maxabs = 0;
+  for (uint32_t s = threadIdx.x; s < W; s += blockDim.x) {
+    double cur = load_f64(pcm, stride, ms, g.channel, g.pcm_off + s);
+    if (windowed) {
+      cur *= win[s];
+      double prev = (s > 0) ? load_f64(pcm, stride, ms, g.channel, g.pcm_off + s - 1) * win[s - 1] : 0.0;
+      cur -= prev * 0.96875;        // (2^5-1)*2^-5, src/SLAPredictor.c:1803-1809
+    }
+    x[s] = cur;
+    if (out_code != nullptr) {
+      int32_t v = load_int(pcm, stride, ms, g.channel, g.pcm_off + s, g.int_shift);
+      uint32_t a = (v > 0) ? (uint32_t)v : (0u - (uint32_t)v);
+      maxabs = (a > maxabs) ? a : maxabs;
+    }
+  }
+  if (out_code != nullptr) {
+    maxabs = umax_wave(maxabs);
+    if ((threadIdx.x & 63) == 0) { s_maxabs[threadIdx.x >> 6] = maxabs; }
+  }
+  __syncthreads();
+
+  // ---- autocorrelation chains -----------------------------------------------------------------
+  const uint32_t nchains = nc * O1;
+  for (uint32_t chain = threadIdx.x; chain < nchains; chain += blockDim.x) {
+    const uint32_t c = chain / O1, lag = chain - c * O1;
+    const uint32_t start = cd[c].start, n = cd[c].len;
+    const double* xs = x + start;
+    double acc = 0.0;
+    if (lag < n) { acc = (lag == 0) ? chain_lag0(xs, n) : chain_lag(xs, n, lag); }
+    r[chain] = acc;
+  }
+  __syncthreads();
+
+  // ---- Levinson-Durbin, one thread per candidate ----------------------------------------------
+  for (uint32_t c = threadIdx.x; c < nc; c += blockDim.x) {
+    const uint32_t n = cd[c].len;
+    const double* rc = r + c * O1;
+    double* a = av + c * O2;
+    double* v = vv + c * O2;
+    double* o = out + (uint64_t)(g.slot_first + c) * O2;
+    o[0] = rc[0];
+    if (n < order || fabs(rc[0]) < (double)FLT_EPSILON) {
+      for (uint32_t i = 0; i < O1; i++) { o[1 + i] = 0.0; }
+    } else {
+      for (uint32_t i = 0; i < O2; i++) { a[i] = 0.0; v[i] = 0.0; }
+      a[0] = 1.0;
+      a[1] = -rc[1] / rc[0];
+      o[1] = 0.0;
+      o[2] = rc[1] / rc[0];
+      double e = rc[0] + rc[1] * a[1];
+      for (uint32_t d = 1; d < order; d++) {
+        double gamma = 0.0;
+        for (uint32_t i = 0; i < d + 1; i++) { gamma += a[i] * rc[d + 1 - i]; }
+        gamma /= (-e);
+        e = (1.0 - gamma * gamma) * e;
+        for (uint32_t i = 0; i < d; i++) { v[d - i] = a[i + 1]; }
+        v[0] = 0.0; v[d + 1] = 1.0;
+        a[0] = 1.0; a[d + 1] = 0.0;
+        for (uint32_t i = 0; i < d + 2; i++) { a[i] = a[i] + gamma * v[i]; }
+        o[2 + d] = -gamma;
+      }
+    }
+  }
+
+  // ---- coefficient quantiser (chosen blocks only: one candidate per group); serial in the
+  //      thread that ran the recursion, so it reads its own stores ------------------------------
+  if (out_code != nullptr && threadIdx.x == 0) {
+    uint32_t m = s_maxabs[0];
+    for (uint32_t w = 1; w < (blockDim.x >> 6); w++) { m = (s_maxabs[w] > m) ? s_maxabs[w] : m; }
+    // bit width = ceil(log2(max|x|)) + 1, at least 1                  src/SLAUtility.c:677-696
+    const uint32_t l2c = (m > 1) ? (32u - (uint32_t)__builtin_clz(m - 1u)) : 0u;
+    const uint32_t bitwidth = (m > 0) ? (l2c + 1u) : 1u;
+    const uint32_t rshift = (bitwidth > 16) ? (bitwidth - 16) : 0;
+    const uint64_t slot = g.slot_first;
+    const double* o = out + slot * O2;
+    out_rshift[slot] = rshift; out_code[slot * O1] = 0; out_kint[slot * O1] = 0;
+    for (uint32_t ord = 1; ord <= order; ord++) {
+      const uint32_t q = (ord < 4) ? 16 : 8;
+      const int32_t lim = 1 << (q - 1);
+      double k = o[1 + ord] * (double)lim;
+      double rk = (k >= 0.0) ? floor(k + 0.5) : -floor(-k + 0.5);
+      int32_t code = f64_to_i32_x86(rk);
+      code = (code < -lim) ? -lim : code;
+      code = (code > lim - 1) ? (lim - 1) : code;
+      out_code[slot * O1 + ord] = code;
+      out_kint[slot * O1 + ord] = (int32_t)((uint32_t)code << (16u - q)) >> rshift;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_lattice: one wave per chunk; every lane keeps T consecutive samples of the forward and
+// backward prediction errors in registers, stage m needs b_{m-1}[n-1] of the previous lane
+// (one DPP-able shuffle per stage).  The first H lanes re-compute `order` samples of history
+// (the lattice is feed-forward: output n depends on inputs n-order..n only), so chunks are
+// independent and need no LDS and no barrier.
+// ---------------------------------------------------------------------------------------------
+#define LAT_T 16
+__device__ __forceinline__ int32_t lat_term(int32_t k, int32_t v)
+{
+  return (int32_t)((uint32_t)k * (uint32_t)v + 16384u) >> 15;
+}
+
+__global__ __launch_bounds__(256)
+void k_lattice(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
+               const sla_hip_lattice_chunk* __restrict__ chunks, uint32_t num_chunks,
+               const int32_t* __restrict__ kint, int32_t* __restrict__ residual)
+{
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t cid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (cid >= num_chunks) { return; }
+  const sla_hip_lattice_chunk ck = chunks[cid];
+  const uint32_t halo_lanes = (order + LAT_T - 1) / LAT_T;
+  // sample index (relative to block) of this lane's first element; negative = before the block
+  const int64_t first = (int64_t)ck.chunk_start + ((int64_t)lane - (int64_t)halo_lanes) * LAT_T;
+  int32_t f[LAT_T], b[LAT_T];
+  // pre-emphasised input: y[n] = x[n] - ((x[n-1]*31)>>5), x[-1] = 0, zero outside the block
+  int32_t prev = 0;
+  {
+    int64_t p = first - 1;
+    if (p >= 0 && p < (int64_t)ck.blk_len) { prev = load_int(pcm, stride, ms, ck.channel, ck.blk_off + p, ck.int_shift); }
+  }
+#pragma unroll
+  for (int i = 0; i < LAT_T; i++) {
+    int64_t p = first + i;
+    int32_t cur = 0;
+    if (p >= 0 && p < (int64_t)ck.blk_len) { cur = load_int(pcm, stride, ms, ck.channel, ck.blk_off + p, ck.int_shift); }
+    int32_t y = (int32_t)((uint32_t)cur - (uint32_t)((int32_t)((uint32_t)prev * 31u) >> 5));
+    f[i] = y; b[i] = y;
+    prev = cur;
+  }
+  const int32_t* kc = kint + (uint64_t)ck.slot * (order + 1);
+  for (uint32_t m = 1; m <= order; m++) {
+    const int32_t k = kc[m];                       // wave-uniform -> scalar load
+    int32_t carry = __shfl_up(b[LAT_T - 1], 1);    // b_{m-1} of the sample just before this lane's run
+    if (lane == 0) { carry = 0; }
+#pragma unroll
+    for (int i = LAT_T - 1; i >= 1; i--) {
+      int32_t nf = (int32_t)((uint32_t)f[i] - (uint32_t)lat_term(k, b[i - 1]));
+      int32_t nb = (int32_t)((uint32_t)b[i - 1] - (uint32_t)lat_term(k, f[i]));
+      f[i] = nf; b[i] = nb;
+    }
+    {
+      int32_t nf = (int32_t)((uint32_t)f[0] - (uint32_t)lat_term(k, carry));
+      int32_t nb = (int32_t)((uint32_t)carry - (uint32_t)lat_term(k, f[0]));
+      f[0] = nf; b[0] = nb;
+    }
+  }
+  if (lane >= halo_lanes) {
+    int32_t* dst = residual + (uint64_t)ck.channel * stride + ck.blk_off;
+#pragma unroll
+    for (int i = 0; i < LAT_T; i++) {
+      int64_t p = first + i;
+      if (p >= (int64_t)ck.chunk_start && p < (int64_t)ck.chunk_start + ck.count) { dst[p] = f[i]; }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tail: long-term filter -> sign-log LMS -> folded sum.  The LMS is serial in time (every
+// sample updates all 2*ORDER coefficients from the error it just produced), so one lane walks
+// one (block, channel); parallelism is across blocks x channels.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t sgn(int32_t v) { return (v > 0) - (v < 0); }
+
+template <int ORDER>
+__global__ __launch_bounds__(64)
+void k_tail(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, uint64_t stride,
+            const sla_hip_tail_job* __restrict__ jobs, uint32_t num_jobs, uint32_t ntaps,
+            uint64_t* __restrict__ fold_sum)
+{
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= num_jobs) { return; }
+  const sla_hip_tail_job job = jobs[j];
+  const int32_t* in = res_in + (uint64_t)job.channel * stride + job.blk_off;
+  int32_t* out = res_out + (uint64_t)job.channel * stride + job.blk_off;
+  const uint32_t n = job.blk_len;
+  const uint32_t delay = job.pitch + (ntaps >> 1);
+  const bool use_ltm = (job.pitch >= 3);
+
+  int32_t cf[ORDER], ci[ORDER], hx[ORDER], hp[ORDER];   // hx[0] / hp[0] = most recent
+#pragma unroll
+  for (int i = 0; i < ORDER; i++) { cf[i] = 0; ci[i] = 0; hx[i] = 0; hp[i] = 0; }
+  uint64_t fsum = 0;
+
+  for (uint32_t s = 0; s < n; s++) {
+    // long-term stage: first `delay` samples pass through        src/SLAPredictor.c:1063-1099
+    int32_t v = in[s];
+    if (use_ltm && s >= delay) {
+      int64_t acc = (int64_t)1 << 30;
+      for (uint32_t t = 0; t < ntaps; t++) { acc += (int64_t)job.ltm_coef[t] * (int64_t)in[s - delay + t]; }
+      v = (int32_t)((uint32_t)v - (uint32_t)(int32_t)(acc >> 31));
+    }
+    // LMS stage: first ORDER samples prime both histories         src/SLAPredictor.c:1233-1255
+    int32_t e = v, pred_hist = v;
+    if (n >= (uint32_t)ORDER && s >= (uint32_t)ORDER) {
+      uint32_t pred = 1u << 9;
+#pragma unroll
+      for (int i = 0; i < ORDER; i++) {
+        pred += (uint32_t)cf[i] * (uint32_t)hx[i];
+        pred += (uint32_t)ci[i] * (uint32_t)hp[i];
+      }
+      int32_t p = (int32_t)pred >> 10;
+      e = (int32_t)((uint32_t)v - (uint32_t)p);
+      uint32_t mag = (e > 0) ? (uint32_t)e : (0u - (uint32_t)e);
+      int32_t lg = mag ? (int32_t)(32 - __builtin_clz(mag)) : 0;        // ceil(log2(|e|+1))
+      int32_t step = sgn(e) * (lg >> 1);                                // ((lg<<4)>>5), table src/SLAPredictor.c:123-144
+#pragma unroll
+      for (int i = 0; i < ORDER; i++) {
+        cf[i] += step * sgn(hx[i]);
+        ci[i] += step * sgn(hp[i]);
+      }
+      pred_hist = p;
+    }
+#pragma unroll
+    for (int i = ORDER - 1; i >= 1; i--) { hx[i] = hx[i - 1]; hp[i] = hp[i - 1]; }
+    hx[0] = v; hp[0] = pred_hist;
+    out[s] = e;
+    fsum += (e < 0) ? ~((uint32_t)e << 1) : ((uint32_t)e << 1);          // zig-zag fold, src/SLAUtility.h:37
+  }
+  fold_sum[j] = fsum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers (C-ABI, see include/sla_hip.h)
+// ---------------------------------------------------------------------------------------------
+static inline int hip_rc(hipError_t e) { return (e == hipSuccess) ? 0 : -(int)e; }
+
+extern "C" int sla_hip_launch_prepass(const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_channels,
+                                      uint32_t num_samples, uint32_t bits_per_sample, uint32_t mid_side,
+                                      uint32_t* d_or_mask, uint64_t* d_nz_mask, sla_hip_stream_t stream)
+{
+  if (d_pcm == nullptr || d_or_mask == nullptr || d_nz_mask == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (num_channels == 0 || num_channels > 8 || bits_per_sample == 0 || bits_per_sample > 32
+      || plane_stride < num_samples || (mid_side && num_channels != 2)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(d_or_mask, 0, sizeof(uint32_t), st);
+  if (e != hipSuccess) { return hip_rc(e); }
+  if (num_samples == 0) { return 0; }
+  uint64_t nwords = ((uint64_t)num_samples + 63) / 64;
+  uint32_t nblocks = (uint32_t)((nwords + 255) / 256);
+  hipLaunchKernelGGL(k_prepass, dim3(nblocks), dim3(256), 0, st, d_pcm, plane_stride, num_channels, num_samples,
+                     32u - bits_per_sample, mid_side, d_or_mask, d_nz_mask);
+  return hip_rc(hipGetLastError());
+}
+
+extern "C" int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                                  const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                                  uint32_t max_cands_per_group,
+                                  const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
+                                  double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
+                                  sla_hip_stream_t stream)
+{
+  if (d_pcm == nullptr || d_groups == nullptr || d_cands == nullptr || d_out == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (order < 1 || order > 255 || max_window == 0 || max_cands_per_group == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if ((d_code != nullptr) != (d_kint != nullptr) || (d_code != nullptr) != (d_rshift != nullptr)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (d_code != nullptr && max_cands_per_group != 1) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (num_groups == 0) { return 0; }
+  size_t x_region = (size_t)max_window;
+  if (x_region < 2 * (size_t)max_cands_per_group * (order + 2)) { x_region = 2 * (size_t)max_cands_per_group * (order + 2); }
+  size_t lds = sizeof(double) * (x_region + (size_t)max_cands_per_group * (order + 1));
+  if (lds > SLA_HIP_LDS_BUDGET) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
+  hipError_t e = hipFuncSetAttribute((const void*)k_lpc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { return hip_rc(e); }
+  hipLaunchKernelGGL(k_lpc, dim3(num_groups), dim3(256), lds, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
+                     d_groups, d_cands, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)x_region);
+  return hip_rc(hipGetLastError());
+}
+
+extern "C" int sla_hip_launch_lattice(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                                      const sla_hip_lattice_chunk* d_chunks, uint32_t num_chunks,
+                                      const int32_t* d_kint, int32_t* d_residual, sla_hip_stream_t stream)
+{
+  if (d_pcm == nullptr || d_chunks == nullptr || d_kint == nullptr || d_residual == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (order < 1 || order > 255 || (order + LAT_T - 1) / LAT_T >= 32) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (num_chunks == 0) { return 0; }
+  hipLaunchKernelGGL(k_lattice, dim3((num_chunks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_pcm, plane_stride,
+                     mid_side, order, d_chunks, num_chunks, d_kint, d_residual);
+  return hip_rc(hipGetLastError());
+}
+
+extern "C" uint32_t sla_hip_lattice_chunk_samples(uint32_t order)
+{
+  return (SLA_WAVE - (order + LAT_T - 1) / LAT_T) * LAT_T;
+}
+
+extern "C" int sla_hip_launch_tail(const int32_t* d_res_in, int32_t* d_res_out, uint64_t plane_stride,
+                                   const sla_hip_tail_job* d_jobs, uint32_t num_jobs, uint32_t longterm_order,
+                                   uint32_t lms_order, uint64_t* d_fold_sum, sla_hip_stream_t stream)
+{
+  if (d_res_in == nullptr || d_res_out == nullptr || d_jobs == nullptr || d_fold_sum == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (longterm_order > 5 || !(longterm_order & 1)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (num_jobs == 0) { return 0; }
+  dim3 grid((num_jobs + 63) / 64), block(64);
+  hipStream_t st = (hipStream_t)stream;
+  switch (lms_order) {
+    case 4:  hipLaunchKernelGGL(k_tail<4>,  grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum); break;
+    case 8:  hipLaunchKernelGGL(k_tail<8>,  grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum); break;
+    case 16: hipLaunchKernelGGL(k_tail<16>, grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum); break;
+    case 32: hipLaunchKernelGGL(k_tail<32>, grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum); break;
+    default: return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY;
+  }
+  return hip_rc(hipGetLastError());
+}

@@ -1,0 +1,315 @@
+/*
+ * sla_ltm.c -- long-term (pitch) predictor analysis, host side.
+ *
+ * The reference derives the pitch and the 1/3/5 taps from an FFT-based
+ * autocorrelation of the lattice residual (src/SLAPredictor.c:791-980) using
+ * a Numerical-Recipes style real FFT whose twiddles come from a trigonometric
+ * recurrence seeded by libm sin() (src/SLAUtility.c:220-312).  To stay
+ * bit-exact the twiddle sequences are generated here, once per FFT size, by
+ * the same recurrence in host double arithmetic (slai_fft_plan); the
+ * butterflies then only multiply/add doubles in a fixed order.
+ *
+ * The peak picking and the tiny Toeplitz solve (x87 long double residual,
+ * src/SLAUtility.c:627-657) stay on the host: a few hundred flops per block.
+ */
+#include "sla_internal.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct slai_fft_plan {
+  uint32_t fft_size;        /* real length n (power of two) */
+  /* complex FFT of n/2 points: for stage with half-span `mmax` (2,4,..,n/2) the twiddles of
+   * butterfly group k=0..mmax/2-1 are at tw[dir][mmax/2 - 1 + k] (dir 0 forward, 1 inverse) */
+  double* tw_re[2];
+  double* tw_im[2];
+  /* real post/pre-processing twiddles for i = 2 .. n/4 at index i-2 */
+  double* rt_re[2];
+  double* rt_im[2];
+};
+
+static void fill_stage_twiddles(double* re, double* im, uint32_t n, int isign)
+{
+  uint32_t mmax;
+  for (mmax = 2; mmax < n; mmax <<= 1) {
+    const double theta = isign * (6.28318530717959 / (double)mmax);
+    double wtemp = sin(0.5 * theta);
+    const double wpr = -2.0 * wtemp * wtemp;
+    const double wpi = sin(theta);
+    double wr = 1.0, wi = 0.0;
+    uint32_t k, base = mmax / 2 - 1;
+    for (k = 0; k < mmax / 2; k++) {
+      re[base + k] = wr; im[base + k] = wi;
+      wtemp = wr;
+      wr = wtemp * wpr - wi * wpi + wr;
+      wi = wi * wpr + wtemp * wpi + wi;
+    }
+  }
+}
+
+static void fill_real_twiddles(double* re, double* im, uint32_t n, int isign)
+{
+  double theta = 3.141592653589793 / (double)(n >> 1);
+  double wtemp, wpr, wpi, wr, wi;
+  uint32_t i;
+  if (isign != 1) { theta = -theta; }
+  wtemp = sin(0.5 * theta);
+  wpr = -2.0 * wtemp * wtemp;
+  wpi = sin(theta);
+  wr = 1.0 + wpr;
+  wi = wpi;
+  for (i = 2; i <= (n >> 2); i++) {
+    re[i - 2] = wr; im[i - 2] = wi;
+    wtemp = wr;
+    wr = wtemp * wpr - wi * wpi + wr;
+    wi = wi * wpr + wtemp * wpi + wi;
+  }
+}
+
+slai_fft_plan* slai_fft_plan_create(uint32_t fft_size)
+{
+  slai_fft_plan* p;
+  int d;
+  if (fft_size < 8 || (fft_size & (fft_size - 1))) { return NULL; }
+  p = (slai_fft_plan*)calloc(1, sizeof(*p));
+  if (p == NULL) { return NULL; }
+  p->fft_size = fft_size;
+  for (d = 0; d < 2; d++) {
+    p->tw_re[d] = (double*)malloc(sizeof(double) * (fft_size / 2));
+    p->tw_im[d] = (double*)malloc(sizeof(double) * (fft_size / 2));
+    p->rt_re[d] = (double*)malloc(sizeof(double) * (fft_size / 4));
+    p->rt_im[d] = (double*)malloc(sizeof(double) * (fft_size / 4));
+    fill_stage_twiddles(p->tw_re[d], p->tw_im[d], fft_size, d == 0 ? 1 : -1);
+    fill_real_twiddles(p->rt_re[d], p->rt_im[d], fft_size, d == 0 ? 1 : -1);
+  }
+  return p;
+}
+
+void slai_fft_plan_destroy(slai_fft_plan* p)
+{
+  int d;
+  if (p == NULL) { return; }
+  for (d = 0; d < 2; d++) { free(p->tw_re[d]); free(p->tw_im[d]); free(p->rt_re[d]); free(p->rt_im[d]); }
+  free(p);
+}
+
+/* in-place complex FFT over z[0..2*npts) (re,im interleaved), decimation in time */
+static void complex_fft(const slai_fft_plan* p, double* z, uint32_t npts, int dir)
+{
+  const uint32_t n = npts << 1;
+  uint32_t i, j = 0, m, mmax;
+  for (i = 0; i < n; i += 2) {              /* bit-reversal permutation */
+    if (j > i) {
+      double t;
+      t = z[j]; z[j] = z[i]; z[i] = t;
+      t = z[j + 1]; z[j + 1] = z[i + 1]; z[i + 1] = t;
+    }
+    m = npts;
+    while (m >= 2 && j >= m) { j -= m; m >>= 1; }
+    j += m;
+  }
+  for (mmax = 2; mmax < n; mmax <<= 1) {
+    const uint32_t step = mmax << 1, base = mmax / 2 - 1;
+    uint32_t k;
+    for (k = 0; k < mmax / 2; k++) {
+      const double wr = p->tw_re[dir][base + k], wi = p->tw_im[dir][base + k];
+      for (i = 2 * k; i < n; i += step) {
+        const uint32_t q = i + mmax;
+        const double tr = wr * z[q] - wi * z[q + 1];
+        const double ti = wr * z[q + 1] + wi * z[q];
+        z[q] = z[i] - tr;
+        z[q + 1] = z[i + 1] - ti;
+        z[i] += tr;
+        z[i + 1] += ti;
+      }
+    }
+  }
+}
+
+/* real FFT (dir 0) / its un-normalised inverse (dir 1) of d[0..n) */
+static void real_fft(const slai_fft_plan* p, double* d, int dir)
+{
+  const uint32_t n = p->fft_size;
+  const double c1 = 0.5, c2 = (dir == 0) ? -0.5 : 0.5;
+  uint32_t i;
+  if (dir == 0) { complex_fft(p, d, n >> 1, 0); }
+  for (i = 2; i <= (n >> 2); i++) {
+    const uint32_t i1 = 2 * i - 2, i2 = i1 + 1, i3 = n - i1, i4 = i3 + 1;   /* 0-based */
+    const double wr = p->rt_re[dir][i - 2], wi = p->rt_im[dir][i - 2];
+    const double h1r = c1 * (d[i1] + d[i3]);
+    const double h1i = c1 * (d[i2] - d[i4]);
+    const double h2r = -c2 * (d[i2] + d[i4]);
+    const double h2i = c2 * (d[i1] - d[i3]);
+    d[i1] = h1r + wr * h2r - wi * h2i;
+    d[i2] = h1i + wr * h2i + wi * h2r;
+    d[i3] = h1r - wr * h2r + wi * h2i;
+    d[i4] = -h1i + wr * h2i + wi * h2r;
+  }
+  if (dir == 0) {
+    const double h = d[0];
+    d[0] = h + d[1];
+    d[1] = h - d[1];
+  } else {
+    const double h = d[0];
+    d[0] = c1 * (h + d[1]);
+    d[1] = c1 * (h - d[1]);
+    complex_fft(p, d, n >> 1, 1);
+  }
+}
+
+/* Wiener-Khinchin autocorrelation as the reference computes it
+ * (src/SLAPredictor.c:827-853) */
+uint32_t slai_fft_plan_size(const slai_fft_plan* p) { return p->fft_size; }
+
+/* `d` is caller scratch of fft_size doubles (the plan itself is read-only and shared by threads) */
+void slai_ltm_autocorr_host(const slai_fft_plan* p, double* d, const int32_t* res, uint32_t n, double* acf_head, uint32_t head)
+{
+  const uint32_t fft = p->fft_size;
+  uint32_t i;
+  for (i = 0; i < fft; i++) { d[i] = (i < n) ? (double)res[i] * ldexp(1.0, -31) : 0.0; }
+  real_fft(p, d, 0);
+  d[0] *= d[0];
+  d[1] *= d[1];
+  for (i = 1; i < fft / 2; i++) {
+    const double re = d[2 * i], im = d[2 * i + 1];
+    d[2 * i] = re * re + im * im;
+    d[2 * i + 1] = 0.0;
+  }
+  real_fft(p, d, 1);
+  memcpy(acf_head, d, sizeof(double) * head);
+}
+
+/* ---- tiny dense solve (reference src/SLAUtility.c:487-674) ---------------- */
+#define NT SLAI_MAX_TAPS
+static int lu_factor(double A[NT][NT], uint32_t dim, uint32_t* perm, double* scale)
+{
+  uint32_t row, col, k, imax;
+  double big, sum;
+  for (row = 0; row < dim; row++) {
+    big = 0.0;
+    for (col = 0; col < dim; col++) { if (fabs(A[row][col]) > big) { big = fabs(A[row][col]); } }
+    if (fabs(big) <= FLT_EPSILON) { return -1; }
+    scale[row] = 1.0f / big;
+  }
+  for (col = 0; col < dim; col++) {
+    for (row = 0; row < col; row++) {
+      sum = A[row][col];
+      for (k = 0; k < row; k++) { sum -= A[row][k] * A[k][col]; }
+      A[row][col] = sum;
+    }
+    big = 0.0;
+    imax = row;
+    for (row = col; row < dim; row++) {
+      sum = A[row][col];
+      for (k = 0; k < col; k++) { sum -= A[row][k] * A[k][col]; }
+      A[row][col] = sum;
+      if ((scale[row] * fabs(sum)) >= big) { big = scale[row] * fabs(sum); imax = row; }
+    }
+    if (col != imax) {
+      for (k = 0; k < dim; k++) { const double t = A[imax][k]; A[imax][k] = A[col][k]; A[col][k] = t; }
+      scale[imax] = scale[col];
+    }
+    perm[col] = imax;
+    if (fabs(A[col][col]) <= FLT_EPSILON) { return -1; }
+    if (col != dim - 1) {
+      const double inv = 1.0f / A[col][col];
+      for (row = col + 1; row < dim; row++) { A[row][col] *= inv; }
+    }
+  }
+  return 0;
+}
+
+static void lu_substitute(double A[NT][NT], double* b, uint32_t dim, const uint32_t* perm)
+{
+  uint32_t row, col, first_nz = 0;
+  double sum;
+  for (row = 0; row < dim; row++) {
+    const uint32_t pv = perm[row];
+    sum = b[pv];
+    b[pv] = b[row];
+    if (first_nz != 0) {
+      for (col = first_nz; col < row; col++) { sum -= A[row][col] * b[col]; }
+    } else if (sum != 0.0) {
+      first_nz = row;
+    }
+    b[row] = sum;
+  }
+  for (row = dim; row-- > 0;) {
+    sum = b[row];
+    for (col = row + 1; col < dim; col++) { sum -= A[row][col] * b[col]; }
+    b[row] = sum / A[row][row];
+  }
+}
+
+static int toeplitz_solve(const double R[NT][NT], double* b, uint32_t dim, uint32_t refinements)
+{
+  double A[NT][NT], x[NT], err[NT], scale[NT];
+  uint32_t perm[NT], row, col, it;
+  memcpy(A, R, sizeof(A));
+  memcpy(x, b, sizeof(double) * dim);
+  if (lu_factor(A, dim, perm, scale) != 0) { return -1; }
+  lu_substitute(A, x, dim, perm);
+  for (it = 0; it < refinements; it++) {
+    for (row = 0; row < dim; row++) {
+      long double e = -b[row];                      /* extended precision, as the reference */
+      for (col = 0; col < dim; col++) { e += R[row][col] * x[col]; }
+      err[row] = (double)e;
+    }
+    lu_substitute(A, err, dim, perm);
+    for (row = 0; row < dim; row++) { x[row] -= err[row]; }
+  }
+  memcpy(b, x, sizeof(double) * dim);
+  return 0;
+}
+
+/* pitch = first local maximum between zero crossings that reaches the global maximum of those
+ * maxima; taps = Wiener solution around it (reference src/SLAPredictor.c:855-979).
+ * `acf` holds at least SLAI_LTM_ACF_HEAD lags. */
+int slai_ltm_solve(const double* acf, uint32_t ntaps, uint32_t* pitch, double* coef)
+{
+  uint32_t cand[SLAI_LTM_MAX_PERIOD], ncand = 0, i, chosen;
+  double top = 0.0;
+  if (fabs(acf[0]) <= FLT_MIN) {
+    *pitch = 0;
+    for (i = 0; i < ntaps; i++) { coef[i] = 0.0; }
+    return 0;
+  }
+  i = 1;
+  while (i < SLAI_LTM_MAX_PERIOD && ncand < SLAI_LTM_MAX_PERIOD) {
+    uint32_t up, down, j, arg = 0;
+    double val = 0.0;
+    for (up = i; up < SLAI_LTM_MAX_PERIOD; up++) { if (acf[up - 1] < 0.0 && acf[up] > 0.0) { break; } }
+    for (down = up + 1; down < SLAI_LTM_MAX_PERIOD; down++) { if (acf[down] > 0.0 && acf[down + 1] < 0.0) { break; } }
+    for (j = up; j <= down; j++) {
+      if (acf[j] > acf[j - 1] && acf[j] > acf[j + 1] && acf[j] > val) { arg = j; val = acf[j]; }
+    }
+    if (arg != 0) {
+      cand[ncand++] = arg;
+      if (val > top) { top = val; }
+    }
+    i = down + 1;
+  }
+  if (ncand == 0) { return 4; }
+  for (i = 0; i < ncand; i++) { if (acf[cand[i]] >= 1.0f * top) { break; } }
+  if (i == ncand) { return 4; }
+  chosen = cand[i];
+  if (chosen < ntaps / 2 + 1) { return 4; }
+  {
+    double R[NT][NT], vec[NT], mag = 0.0;
+    uint32_t j, k;
+    memset(R, 0, sizeof(R));
+    for (j = 0; j < ntaps; j++) { for (k = 0; k < ntaps; k++) { R[j][k] = acf[(j >= k) ? (j - k) : (k - j)]; } }
+    for (j = 0; j < ntaps; j++) { vec[j] = acf[j + chosen - ntaps / 2]; }
+    if (toeplitz_solve((const double (*)[NT])R, vec, ntaps, 2) != 0) { return 4; }
+    for (j = 0; j < ntaps; j++) { mag += fabs(vec[j]); }
+    if (mag >= 1.0) {
+      for (j = 0; j < ntaps; j++) { vec[j] = 0.0; }
+      vec[ntaps / 2] = acf[chosen] / acf[0];
+    }
+    *pitch = chosen;
+    for (j = 0; j < ntaps; j++) { coef[j] = vec[j]; }
+  }
+  return 0;
+}
