@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- encode Msamples/s of the SLA LPC+residual hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5] [--seconds S]
+
+One "step" = one pass of the hot path (sla_hip_analyze_device: prepass -> partition-search LPC ->
+block LPC + quantiser -> PARCOR lattice -> long-term + LMS + Rice parameter) over one batch of
+synthetic PCM that is already resident in HBM when the timed region starts.  N > 1: launched by
+torch.distributed.run, one rank per GPU, every rank encodes its own shard of the (N x larger)
+job (frames are independent -> weak scaling) and the residual stream is re-assembled by one RCCL
+all-gather per step, as the north star prescribes.
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np      # noqa: E402
+
+# name: (channels, bits, rate, seconds, order, ltm, lms, ms, window, max_block, capacity)
+CONFIGS = {
+    "C2": (1, 16, 48000, 600, 16, 1, 8, 0, 1, 4096, (1, 4096, 16, 1, 8)),
+    "C3": (2, 24, 48000, 3600, 32, 3, 8, 1, 1, 4096, (2, 4096, 32, 3, 8)),
+    "C4": (2, 16, 48000, 10, 16, 1, 8, 1, 1, 4096, (2, 4096, 16, 1, 8)),
+    "C5": (8, 24, 96000, 1800, 48, 3, 8, 0, 1, 8192, (8, 8192, 48, 3, 8)),
+}
+WORKLOAD_NAME = {
+    "C2": "synthetic 48 kHz 16-bit mono, 10 min, order-16 LPC, 4096-sample frames",
+    "C3": "48 kHz 24-bit stereo, 60 min, order-32 LPC, 4096-sample frames (MS)",
+    "C4": "48 kHz 16-bit stereo clip, order-16 LPC, 4096-sample frames (MS)",
+    "C5": "96 kHz 24-bit 8-channel, 30 min, order-48 LPC, 8192-sample frames",
+}
+KERNEL_NAMES = ["k_prepass", "k_lpc (partition search)", "k_lpc (chosen blocks)", "k_lattice", "k_tail"]
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+ALGO_BYTES_PER_SAMPLE = 8      # 4 B int32 PCM read + 4 B int32 final residual written
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--seconds", type=float, default=None, help="override the audio duration")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import sla_amd
+    import slalibs as S
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    nch, bits, rate, seconds, order, ltm, lms, ms, win, maxb, cap = CONFIGS[args.config]
+    if args.seconds is not None:
+        seconds = args.seconds
+    n = int(rate * seconds)
+    # every rank encodes its own, different shard (seed by rank)
+    pcm = S.synth_pcm(nch, n, bits, rate, seed=12345 + rank)
+    stride = (n + 63) // 64 * 64
+    d_pcm = torch.zeros((nch, stride), dtype=torch.int32, device="cuda")
+    d_pcm[:, :n] = torch.from_numpy(pcm).cuda()
+    d_lat = torch.zeros((nch, stride), dtype=torch.int32, device="cuda")
+    d_fin = torch.zeros((nch, stride), dtype=torch.int32, device="cuda")
+    gathered = torch.empty((world, nch, stride), dtype=torch.int32, device="cuda") if world > 1 else None
+
+    enc = sla_amd.Encoder(*cap)
+    enc.set_wave_format(nch, bits, rate)
+    enc.set_encode_parameter(order, ltm, lms, ms, win, maxb)
+    enc.bind_residual_planes(d_lat.data_ptr(), d_fin.data_ptr(), stride)
+    torch.cuda.synchronize()
+
+    def step():
+        t = enc.analyze_device(d_pcm.data_ptr(), stride, n)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, d_fin)      # RCCL over xGMI: re-assemble the residual stream
+        return t
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    kernel_ms = np.zeros(8)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        kernel_ms += np.array(step())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kernel_ms /= max(args.steps, 1)
+
+    total_samples = float(n) * nch * world * args.steps
+    value = total_samples / elapsed / 1e6
+
+    out = {
+        "metric": "encode Msamples/s (LPC+residual path), bit-exact vs oracle",
+        "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64+int32",
+        "data": "synthetic",
+        "config": {"workload": WORKLOAD_NAME[args.config] + (" x%d ranks" % world if world > 1 else ""),
+                   "name": args.config, "channels": nch, "bits": bits, "rate": rate, "seconds": seconds,
+                   "parcor_order": order, "longterm_order": ltm, "lms_order": lms,
+                   "max_block_samples": maxb, "samples_per_step_per_gpu": n * nch,
+                   "parallelism": "frames sharded over %d GPU(s), RCCL all-gather of residuals" % world},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (HIP-event durations measured inside the library, on the
+        #      stream the kernels run on) ---------------------------------------------------------------
+        dom = int(np.argmax(kernel_ms[:5]))
+        algo_bytes = float(n) * nch * ALGO_BYTES_PER_SAMPLE
+        achieved = algo_bytes / (kernel_ms[dom] * 1e-3) / 1e9 if kernel_ms[dom] > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": round(achieved, 2),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                           "traffic": None, "kernel_ms": round(float(kernel_ms[dom]), 4),
+                           "algorithmic_bytes_per_launch": algo_bytes}
+        out["stage_ms"] = {"k_prepass": round(float(kernel_ms[0]), 4), "k_lpc_search": round(float(kernel_ms[1]), 4),
+                           "k_lpc_blocks": round(float(kernel_ms[2]), 4), "k_lattice": round(float(kernel_ms[3]), 4),
+                           "k_tail": round(float(kernel_ms[4]), 4), "host_plan": round(float(kernel_ms[5]), 4),
+                           "host_longterm": round(float(kernel_ms[6]), 4), "analyze_total": round(float(kernel_ms[7]), 4)}
+        out["device"] = sla_amd.device_name()
+
+        # ---- end-to-end .sla encode from host PCM (PCIe + host bit-pack included); never `value` ------
+        if not args.no_e2e and world == 1:
+            enc2 = sla_amd.Encoder(*cap)
+            enc2.set_wave_format(nch, bits, rate)
+            enc2.set_encode_parameter(order, ltm, lms, ms, win, maxb)
+            m = min(n, rate * 120)
+            sub = np.ascontiguousarray(pcm[:, :m])
+            enc2.encode_whole(sub)
+            t1 = time.perf_counter()
+            data = enc2.encode_whole(sub)
+            e2e = time.perf_counter() - t1
+            out["end_to_end"] = {"msamples_s": round(m * nch / e2e / 1e6, 3), "samples": m * nch,
+                                 "sla_bytes": len(data), "note": "host PCM -> .sla bytes incl. PCIe and host Rice pack"}
+            enc2.close()
+
+        # ---- CPU baseline on this box's host cores, same workload, bounded sample -------------------
+        if not args.no_cpu_baseline and world == 1:
+            p = S.make_params(nch, bits, rate, order, ltm, lms, ms, win, maxb, cap=cap)
+            ref = S.ref()
+            checker, kind = (ref, "reference") if ref is not None else (S.oracle(), "port")
+            m = min(n, int(rate * 600 / nch))            # about 10-30 s of single-thread CPU work
+            sub = np.ascontiguousarray(pcm[:, :m])
+            t1 = time.perf_counter()
+            ret, data = checker.encode_whole(p, sub)
+            cpu_s = time.perf_counter() - t1
+            assert ret == 0
+            out["cpu_baseline"] = {"value": round(m * nch / cpu_s / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+                                   "kind": kind, "seconds": round(cpu_s, 2),
+                                   "sample": "first %d samples x %d ch of the same workload, full single-thread "
+                                             "EncodeWhole (%s)" % (m, nch, "unmodified reference, oracle/_ref"
+                                                                   if kind == "reference" else "oracle restatement")}
+            out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+
+    enc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

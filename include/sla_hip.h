@@ -152,6 +152,12 @@ int sla_hip_pack(struct SLAEncoder* encoder, uint8_t* data, uint32_t data_size, 
 const int32_t* sla_hip_final_residual(const struct SLAEncoder* encoder, uint64_t* plane_stride);
 const int32_t* sla_hip_lattice_residual(const struct SLAEncoder* encoder, uint64_t* plane_stride);
 
+/* Make the analysis write its residual planes into caller-owned device memory ([C][plane_stride]
+ * int32 each; plane_stride must equal the one later passed to sla_hip_analyze_device).  Used when
+ * the planes feed a collective (RCCL all-gather of the residual stream).  NULL, NULL unbinds. */
+int sla_hip_bind_residual_planes(struct SLAEncoder* encoder, int32_t* d_lattice, int32_t* d_final,
+                                 uint64_t plane_stride);
+
 /* Copy the last analysis into caller arrays. */
 int sla_hip_get_trace(struct SLAEncoder* encoder, sla_hip_trace* trace);
 

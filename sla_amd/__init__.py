@@ -109,6 +109,7 @@ def lib():
         L.sla_hip_final_residual.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.sla_hip_lattice_residual.restype = C.c_void_p
         L.sla_hip_lattice_residual.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.sla_hip_bind_residual_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.sla_hip_device_name.restype = C.c_char_p
         _lib = L
     return _lib
@@ -121,7 +122,7 @@ EXPORTED_SYMBOLS = [
     # include/sla_hip.h
     "sla_hip_launch_prepass", "sla_hip_launch_lpc", "sla_hip_launch_lattice", "sla_hip_launch_tail",
     "sla_hip_analyze_device", "sla_hip_pack", "sla_hip_final_residual", "sla_hip_lattice_residual",
-    "sla_hip_get_trace", "sla_hip_device_name",
+    "sla_hip_get_trace", "sla_hip_device_name", "sla_hip_bind_residual_planes",
 ]
 
 
@@ -244,6 +245,10 @@ class Encoder:
                     "sla_hip_analyze_device")
         self.num_samples = num_samples
         return list(timing)
+
+    def bind_residual_planes(self, lattice_ptr, final_ptr, plane_stride):
+        self._check(self._lib.sla_hip_bind_residual_planes(self._h, C.c_void_p(lattice_ptr), C.c_void_p(final_ptr),
+                                                           plane_stride), "sla_hip_bind_residual_planes")
 
     def pack(self, capacity):
         out = np.zeros(capacity, np.uint8)

@@ -66,6 +66,9 @@ struct SLAEncoder {
   uint32_t* win_len; uint32_t* win_off; uint32_t win_entries, win_entries_cap;
   SLAWindowFunctionType win_type; int win_dirty;
 
+  /* caller-owned residual planes (e.g. torch tensors that feed an RCCL all-gather), optional */
+  int32_t* user_res1; int32_t* user_res2; uint64_t user_stride;
+
   /* last analysis */
   const int32_t* pcm_dev;           /* borrowed or &d_pcm */
   uint64_t stride;
@@ -78,6 +81,9 @@ struct SLAEncoder {
   int      analysed;
   float    timing[8];
 };
+
+#define RES1(e) ((e)->user_res1 != NULL ? (e)->user_res1 : (int32_t*)(e)->d_res1.ptr)
+#define RES2(e) ((e)->user_res2 != NULL ? (e)->user_res2 : (int32_t*)(e)->d_res2.ptr)
 
 /* ------------------------------------------------------------------ utilities */
 
@@ -641,8 +647,11 @@ static int stage_blocks(struct SLAEncoder* e)
     if (k->nsmpl > max_window) { max_window = k->nsmpl; }
   }
 
-  RCCHK(dev_reserve(&e->d_res1, sizeof(int32_t) * (size_t)C * e->stride));
-  RCCHK(dev_reserve(&e->d_res2, sizeof(int32_t) * (size_t)C * e->stride));
+  if (e->user_res1 != NULL && e->user_stride != e->stride) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (e->user_res1 == NULL) {
+    RCCHK(dev_reserve(&e->d_res1, sizeof(int32_t) * (size_t)C * e->stride));
+    RCCHK(dev_reserve(&e->d_res2, sizeof(int32_t) * (size_t)C * e->stride));
+  }
   RCCHK(dev_reserve(&e->d_lpc_out, sizeof(double) * (nslots + 1) * O2));
   RCCHK(dev_reserve(&e->d_code, sizeof(int32_t) * (nslots + 1) * O1));
   RCCHK(dev_reserve(&e->d_kint, sizeof(int32_t) * (nslots + 1) * O1));
@@ -677,7 +686,7 @@ static int stage_blocks(struct SLAEncoder* e)
                              (uint32_t*)e->d_rshift.ptr, e->stream));
     HIPCHK(hipEventRecord(e->ev[5], e->stream));
     RCCHK(sla_hip_launch_lattice(e->pcm_dev, e->stride, ms, order, (const sla_hip_lattice_chunk*)e->d_chunks.ptr, nchunks,
-                                 (const int32_t*)e->d_kint.ptr, (int32_t*)e->d_res1.ptr, e->stream));
+                                 (const int32_t*)e->d_kint.ptr, RES1(e), e->stream));
     HIPCHK(hipEventRecord(e->ev[6], e->stream));
     HIPCHK(hipMemcpyAsync(e->h_lpc_out.ptr, e->d_lpc_out.ptr, sizeof(double) * nslots * O2, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(e->h_code.ptr, e->d_code.ptr, sizeof(int32_t) * nslots * O1, hipMemcpyDeviceToHost, e->stream));
@@ -686,7 +695,7 @@ static int stage_blocks(struct SLAEncoder* e)
     /* long-term analysis input (host FFT in this round) */
     RCCHK(pin_reserve(&e->h_res, sizeof(int32_t) * (size_t)C * e->num_samples));
     for (ch = 0; ch < C; ch++) {
-      HIPCHK(hipMemcpyAsync((int32_t*)e->h_res.ptr + (size_t)ch * e->num_samples, (int32_t*)e->d_res1.ptr + (size_t)ch * e->stride,
+      HIPCHK(hipMemcpyAsync((int32_t*)e->h_res.ptr + (size_t)ch * e->num_samples, RES1(e) + (size_t)ch * e->stride,
                             sizeof(int32_t) * e->num_samples, hipMemcpyDeviceToHost, e->stream));
     }
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -743,7 +752,7 @@ static int stage_blocks(struct SLAEncoder* e)
     RCCHK(pin_reserve(&e->h_fold, sizeof(uint64_t) * njobs));
     HIPCHK(hipMemcpyAsync(e->d_jobs.ptr, jobs, sizeof(sla_hip_tail_job) * njobs, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipEventRecord(e->ev[7], e->stream));
-    rc = sla_hip_launch_tail((const int32_t*)e->d_res1.ptr, (int32_t*)e->d_res2.ptr, e->stride,
+    rc = sla_hip_launch_tail(RES1(e), RES2(e), e->stride,
                              (const sla_hip_tail_job*)e->d_jobs.ptr, njobs, ntaps, lms, (uint64_t*)e->d_fold.ptr, e->stream);
     if (rc != 0) { free(job_blk); free(job_ch); return rc; }
     HIPCHK(hipEventRecord(e->ev[8], e->stream));
@@ -882,8 +891,8 @@ static int pack_impl(struct SLAEncoder* e, const int32_t* const* host_pcm, uint8
   if (data_size < SLA_HEADER_SIZE) { return SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE; }
   /* D2H of the final residual */
   RCCHK(pin_reserve(&e->h_res, sizeof(int32_t) * (size_t)C * (n + 1)));
-  for (ch = 0; ch < C && n > 0 && e->d_res2.ptr != NULL; ch++) {
-    HIPCHK(hipMemcpyAsync((int32_t*)e->h_res.ptr + (size_t)ch * n, (int32_t*)e->d_res2.ptr + (size_t)ch * e->stride,
+  for (ch = 0; ch < C && n > 0 && RES2(e) != NULL; ch++) {
+    HIPCHK(hipMemcpyAsync((int32_t*)e->h_res.ptr + (size_t)ch * n, RES2(e) + (size_t)ch * e->stride,
                           sizeof(int32_t) * n, hipMemcpyDeviceToHost, e->stream));
   }
   for (b = 0; b < e->num_blocks; b++) { if (e->blk[b].type == SLAI_BLK_RAW) { need_raw = 1; } }
@@ -1021,14 +1030,22 @@ const int32_t* sla_hip_final_residual(const struct SLAEncoder* e, uint64_t* plan
 {
   if (e == NULL || !e->analysed) { return NULL; }
   if (plane_stride != NULL) { *plane_stride = e->stride; }
-  return (const int32_t*)e->d_res2.ptr;
+  return RES2(e);
 }
 
 const int32_t* sla_hip_lattice_residual(const struct SLAEncoder* e, uint64_t* plane_stride)
 {
   if (e == NULL || !e->analysed) { return NULL; }
   if (plane_stride != NULL) { *plane_stride = e->stride; }
-  return (const int32_t*)e->d_res1.ptr;
+  return RES1(e);
+}
+
+int sla_hip_bind_residual_planes(struct SLAEncoder* e, int32_t* d_lattice, int32_t* d_final, uint64_t plane_stride)
+{
+  if (e == NULL || ((d_lattice == NULL) != (d_final == NULL))) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  e->user_res1 = d_lattice; e->user_res2 = d_final; e->user_stride = plane_stride;
+  e->analysed = 0;
+  return 0;
 }
 
 int sla_hip_get_trace(struct SLAEncoder* e, sla_hip_trace* tr)
@@ -1057,12 +1074,12 @@ int sla_hip_get_trace(struct SLAEncoder* e, sla_hip_trace* tr)
     }
   }
   for (ch = 0; ch < C && e->num_samples > 0; ch++) {
-    if (tr->res_lattice != NULL && e->d_res1.ptr != NULL) {
-      HIPCHK(hipMemcpy(tr->res_lattice + (size_t)ch * tr->sample_stride, (int32_t*)e->d_res1.ptr + (size_t)ch * e->stride,
+    if (tr->res_lattice != NULL && RES1(e) != NULL) {
+      HIPCHK(hipMemcpy(tr->res_lattice + (size_t)ch * tr->sample_stride, RES1(e) + (size_t)ch * e->stride,
                        sizeof(int32_t) * e->num_samples, hipMemcpyDeviceToHost));
     }
-    if (tr->res_final != NULL && e->d_res2.ptr != NULL) {
-      HIPCHK(hipMemcpy(tr->res_final + (size_t)ch * tr->sample_stride, (int32_t*)e->d_res2.ptr + (size_t)ch * e->stride,
+    if (tr->res_final != NULL && RES2(e) != NULL) {
+      HIPCHK(hipMemcpy(tr->res_final + (size_t)ch * tr->sample_stride, RES2(e) + (size_t)ch * e->stride,
                        sizeof(int32_t) * e->num_samples, hipMemcpyDeviceToHost));
     }
   }

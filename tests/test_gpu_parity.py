@@ -1,0 +1,401 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI of
+libsla_hip.so, must be bit-identical to the CPU oracle -- .sla bytes, block tables, PARCOR doubles
+(bit patterns), transmitted codes, lattice coefficients, residual planes, Rice parameters -- on the
+committed golden vectors, on seeded inputs covering the reference's own round-trip matrix
+(reference test/test_SLAEncodeDecode.c:558-1172), on the edge cases (silence, ragged tails, RAW
+fallback, leading-silence frame shifts) and, at BASELINE.json's full sizes, through round trips and
+prefix consistency.  Nothing here reads /root/reference."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+import slalibs as S
+import waveforms as W
+from test_oracle_golden import CASES as GOLDEN_CASES, check_trace_against_golden, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import sla_amd
+    sla_amd.lib()
+    return sla_amd
+
+
+def hip_encode(hip, p, pcm, want_residuals=True):
+    enc = hip.Encoder(p.cap_channels, p.cap_block_samples, p.cap_parcor_order, p.cap_longterm_order, p.cap_lms_order)
+    try:
+        enc.set_wave_format(p.num_channels, p.bits_per_sample, p.sampling_rate)
+        enc.set_encode_parameter(p.parcor_order, p.longterm_order, p.lms_order, p.ch_process_method,
+                                 p.window_type, p.max_block_samples)
+        data = enc.encode_whole(pcm)
+        return data, enc.trace(want_residuals)
+    finally:
+        enc.close()
+
+
+def assert_same_as_oracle(oracle, hip, p, pcm, roundtrip=True):
+    ret, want, to = oracle.encode_trace(p, pcm)
+    assert ret == 0
+    got, tg = hip_encode(hip, p, pcm)
+    nb = to.num_blocks
+    assert tg.num_blocks == nb and tg.offset_lshift == to.offset_lshift
+    for f in ("blk_start", "blk_nsmpl", "blk_type", "blk_bytes"):
+        assert np.array_equal(getattr(tg, f)[:nb], getattr(to, f)[:nb]), f
+    comp = to.blk_type[:nb] == 0
+    assert np.array_equal(tg.parcor[:nb].view(np.uint64)[comp], to.parcor[:nb].view(np.uint64)[comp])
+    for f in ("code", "kint", "rshift", "pitch", "rice_init"):
+        assert np.array_equal(getattr(tg, f)[:nb][comp], getattr(to, f)[:nb][comp]), f
+    used = (to.pitch[:nb] >= 3) & comp[:, None]
+    assert np.array_equal(tg.ltm_coef[:nb][used], to.ltm_coef[:nb][used])
+    for b in np.nonzero(comp)[0]:
+        s, n = int(to.blk_start[b]), int(to.blk_nsmpl[b])
+        assert np.array_equal(tg.res_lattice[:, s:s + n], to.res_lattice[:, s:s + n]), ("lattice", b)
+        assert np.array_equal(tg.res_final[:, s:s + n], to.res_final[:, s:s + n]), ("final", b)
+    assert got == want
+    if roundtrip:
+        rd, dec, _ = oracle.decode_whole(p, got, pcm.shape[1])
+        assert rd == 0 and np.array_equal(dec, pcm)
+    return got
+
+
+# ------------------------------------------------------------------ golden vectors
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_golden_vectors(hip, name):
+    g, p, pcm = load_case(name)
+    data, tr = hip_encode(hip, p, pcm)
+    check_trace_against_golden(g, tr, data)
+    sha = lambda a: hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+    comp_only = (g["blk_type"] == 0).all()
+    if comp_only:
+        assert sha(tr.res_lattice) == str(g["res_lattice_sha1"])
+        assert sha(tr.res_final) == str(g["res_final_sha1"])
+
+
+# ------------------------------------------------------------------ oracle, seeded inputs
+
+@pytest.mark.parametrize("name", W.NAMES)
+@pytest.mark.parametrize("nch", [1, 2, 8])
+@pytest.mark.parametrize("bits", [8, 16, 24])
+@pytest.mark.parametrize("lshift", [0, 8])
+def test_roundtrip_matrix(oracle, hip, name, nch, bits, lshift):
+    """the reference's own round-trip matrix: {parcor 4, ltm 1, lms 4, SIN, max block 16384}"""
+    if lshift >= bits:
+        pytest.skip("no bits left")
+    n = 8192 + 517
+    pcm = W.gen(name, nch, n, bits, lshift=lshift, seed=nch * 100 + bits)
+    p = S.make_params(nch, bits, 44100, 4, 1, 4, 0, 1, 16384)
+    assert_same_as_oracle(oracle, hip, p, pcm)
+
+
+CONFIGS = {
+    "C2": (1, 16, 48000, 16, 1, 8, 0, 1, 4096, (1, 4096, 16, 1, 8)),
+    "C3": (2, 24, 48000, 32, 3, 8, 1, 1, 4096, (2, 4096, 32, 3, 8)),
+    "C4": (2, 16, 48000, 16, 1, 8, 1, 1, 4096, (2, 4096, 16, 1, 8)),
+    "C5": (8, 24, 96000, 48, 3, 8, 0, 1, 8192, (8, 8192, 48, 3, 8)),
+}
+
+
+@pytest.mark.parametrize("cfg", sorted(CONFIGS))
+@pytest.mark.parametrize("kind", ["synth", "synth_gaps", "music"])
+def test_baseline_configs(oracle, hip, cfg, kind):
+    nch, bits, rate, order, ltm, lms, ms, win, mb, cap = CONFIGS[cfg]
+    n = 150000 if cfg != "C5" else 70000
+    if kind == "music":
+        pcm = W.music_like(nch, n, bits, seed=5)
+    else:
+        pcm = S.synth_pcm(nch, n, bits, rate, gaps=(kind == "synth_gaps"))
+        if kind == "synth_gaps":
+            pcm[:, :3000] = 0
+            pcm[:, 9000:14000] = 0
+    p = S.make_params(nch, bits, rate, order, ltm, lms, ms, win, mb, cap=cap)
+    assert_same_as_oracle(oracle, hip, p, pcm)
+
+
+@pytest.mark.parametrize("preset", [(8, 1, 4, 0, 0, 4096), (8, 1, 8, 1, 1, 12288), (16, 1, 8, 1, 1, 12288),
+                                    (32, 3, 8, 1, 1, 12288), (32, 3, 8, 1, 1, 16384)])
+@pytest.mark.parametrize("nch", [1, 2])
+def test_cli_presets(oracle, hip, preset, nch):
+    """the reference CLI's five presets under its capacity {8,16384,48,5,40} (src/main.c:63-70,94-99)"""
+    po, lt, lm, ms, win, mb = preset
+    pcm = W.music_like(nch, 60000, 16, seed=nch)
+    p = S.make_params(nch, 16, 44100, po, lt, lm, ms if nch == 2 else 0, win, mb)
+    assert_same_as_oracle(oracle, hip, p, pcm)
+
+
+@pytest.mark.parametrize("wtype", range(5))
+def test_window_types(oracle, hip, wtype):
+    pcm = W.music_like(1, 20000, 16, seed=wtype)
+    p = S.make_params(1, 16, 48000, 16, 1, 8, 0, wtype, 4096)
+    assert_same_as_oracle(oracle, hip, p, pcm)
+
+
+@pytest.mark.parametrize("lms", [4, 8, 16, 32])
+@pytest.mark.parametrize("ltm", [1, 3, 5])
+def test_tail_orders(oracle, hip, lms, ltm):
+    pcm = W.music_like(2, 20000, 24, seed=lms + ltm)
+    p = S.make_params(2, 24, 48000, 16, ltm, lms, 1, 1, 4096)
+    assert_same_as_oracle(oracle, hip, p, pcm)
+
+
+def test_pitched_signal_uses_longterm(oracle, hip):
+    rng = np.random.default_rng(3)
+    base = rng.integers(-6000, 6000, 131)
+    x = (np.tile(base, 400)[:40000] + rng.integers(-300, 300, 40000)).astype(np.int64)
+    pcm = np.ascontiguousarray((x << 16).astype(np.int32)[None, :])
+    p = S.make_params(1, 16, 48000, 8, 3, 8, 0, 1, 4096)
+    assert_same_as_oracle(oracle, hip, p, pcm)
+    _, tr = hip_encode(hip, p, pcm, want_residuals=False)
+    assert (tr.pitch[:tr.num_blocks] >= 3).any()
+
+
+# ------------------------------------------------------------------ edge cases
+
+@pytest.mark.parametrize("n", [1, 15, 17, 100, 1023, 2047, 2048, 2049, 4096, 4096 + 15, 4096 + 17, 8192 + 1023, 12345])
+def test_ragged_lengths(oracle, hip, n):
+    pcm = W.music_like(1, n, 16, seed=n)
+    p = S.make_params(1, 16, 48000, 16, 1, 8, 0, 1, 4096, cap=(1, 4096, 16, 1, 8))
+    assert_same_as_oracle(oracle, hip, p, pcm)
+
+
+def test_leading_silence_shifts_frames(oracle, hip):
+    """3000 leading zeros -> one SILENT block of 3000 samples, later frames shifted"""
+    pcm = S.synth_pcm(1, 20000, 16)
+    pcm[:, :3000] = 0
+    p = S.make_params(1, 16, 48000, 16, 1, 8, 0, 1, 4096, cap=(1, 4096, 16, 1, 8))
+    assert_same_as_oracle(oracle, hip, p, pcm)
+    _, tr = hip_encode(hip, p, pcm, want_residuals=False)
+    assert list(tr.blk_start[:tr.num_blocks]) == [0, 3000, 7096, 11192, 15288, 19384]
+    assert tr.blk_type[0] == 1 and tr.blk_bytes[0] == 11
+
+
+def test_all_silent_file(oracle, hip):
+    pcm = np.zeros((2, 30000), np.int32)
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096)
+    assert_same_as_oracle(oracle, hip, p, pcm)
+
+
+def test_silence_inside_a_frame(oracle, hip):
+    pcm = W.music_like(2, 30000, 16, seed=4)
+    pcm[:, 5000:9500] = 0
+    pcm[:, 20000:20900] = 0
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096)
+    assert_same_as_oracle(oracle, hip, p, pcm)
+
+
+def test_raw_fallback(oracle, hip):
+    pcm = W.gen("white", 2, 20000, 16, seed=2)
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096)
+    got = assert_same_as_oracle(oracle, hip, p, pcm)
+    _, tr = hip_encode(hip, p, pcm, want_residuals=False)
+    assert (tr.blk_type[:tr.num_blocks] == 2).any()
+    assert len(got) > 0
+
+
+def test_full_scale_24bit_side_channel(oracle, hip):
+    """MS on full-scale 24-bit input: 25-bit side channel -> rshift 9, wrapping lattice products"""
+    rng = np.random.default_rng(9)
+    l = (np.sin(np.arange(30000) * 0.05) * (2 ** 23 - 1)).astype(np.int64)
+    r = -l + rng.integers(-1000, 1000, 30000)
+    r = np.clip(r, -2 ** 23, 2 ** 23 - 1)
+    pcm = np.ascontiguousarray((np.stack([l, r]) << 8).astype(np.int32))
+    p = S.make_params(2, 24, 48000, 32, 3, 8, 1, 1, 4096)
+    assert_same_as_oracle(oracle, hip, p, pcm)
+    _, tr = hip_encode(hip, p, pcm, want_residuals=False)
+    assert tr.rshift[:tr.num_blocks].max() >= 9
+
+
+def test_offset_lshift_detected(oracle, hip):
+    pcm = (W.music_like(2, 20000, 16, seed=6) >> 20) << 20      # only the top 12 bits used
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 0, 1, 4096)
+    assert_same_as_oracle(oracle, hip, p, pcm)
+    _, tr = hip_encode(hip, p, pcm, want_residuals=False)
+    assert tr.offset_lshift == 4
+
+
+def test_encode_block_1024_frames_a_wav(oracle, hip):
+    """BASELINE config 0 (plumbing): a.wav, order 8, 1024-sample EncodeBlock calls under a header
+    whose max block is 2048 -- through the same-signature SLAEncoder_EncodeBlock"""
+    import os
+    pcm, bits, rate = S.read_wav(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "a.wav"))
+    pcm = pcm[:, :40000]
+    p = S.make_params(1, bits, rate, 8, 1, 4, 0, 1, 2048, cap=(1, 2048, 8, 1, 4))
+    ret, want = oracle.encode_fixed_blocks(p, pcm, 1024)
+    assert ret == 0
+    enc = hip.Encoder(1, 2048, 8, 1, 4)
+    enc.set_wave_format(1, bits, rate)
+    enc.set_encode_parameter(8, 1, 4, 0, 1, 2048)
+    blocks = [enc.encode_block(pcm[:, s:s + 1024]) for s in range(0, pcm.shape[1], 1024)]
+    enc.close()
+    body = b"".join(blocks)
+    assert body == want[43:]
+    maxbps = max(8 * len(b) * rate // min(1024, pcm.shape[1] - i * 1024) for i, b in enumerate(blocks))
+    hdr = hip.encode_header(1, bits, rate, 0, 8, 1, 4, 0, 1, 2048, pcm.shape[1], len(blocks),
+                            max(len(b) for b in blocks), maxbps)
+    assert hdr == want[:43]
+    rd, dec, _ = oracle.decode_whole(p, hdr + body, pcm.shape[1])
+    assert rd == 0 and np.array_equal(dec, pcm)
+
+
+def test_api_error_codes(hip):
+    enc = hip.Encoder(2, 4096, 16, 1, 8)
+    with pytest.raises(hip.SlaError) as e:
+        enc.encode_whole(np.zeros((1, 100), np.int32))
+    assert e.value.code == 15                                   # PARAMETER_NOT_SET
+    with pytest.raises(hip.SlaError) as e:
+        enc.set_wave_format(3, 16, 48000)
+    assert e.value.code == 3                                    # EXCEED_HANDLE_CAPACITY
+    enc.set_wave_format(1, 16, 48000)
+    with pytest.raises(hip.SlaError) as e:
+        enc.set_encode_parameter(32, 1, 8, 0, 1, 4096)
+    assert e.value.code == 3
+    with pytest.raises(hip.SlaError) as e:
+        enc.set_encode_parameter(16, 1, 8, 0, 1, 1024)
+    assert e.value.code == 3
+    enc.set_encode_parameter(16, 1, 8, hip.CH_STEREO_MS, 1, 4096)
+    with pytest.raises(hip.SlaError) as e:
+        enc.encode_whole(np.zeros((1, 5000), np.int32))
+    assert e.value.code == 5                                    # INVAILD_CHPROCESSMETHOD
+    enc.set_encode_parameter(16, 1, 8, 0, 1, 4096)
+    with pytest.raises(hip.SlaError) as e:
+        enc.encode_whole(W.music_like(1, 20000, 16), capacity=1000)
+    assert e.value.code == 4                                    # INSUFFICIENT_BUFFER_SIZE
+    enc.close()
+
+
+def test_encoder_handle_is_reusable(oracle, hip):
+    """one handle, several files and parameter changes (window pool / workspace reuse)"""
+    enc = hip.Encoder(2, 8192, 32, 3, 8)
+    for i, (nch, bits, order, win, mb, n) in enumerate([(1, 16, 16, 1, 4096, 30000), (2, 24, 32, 2, 8192, 50000),
+                                                        (1, 16, 16, 1, 4096, 9000), (2, 16, 8, 4, 2048, 20000)]):
+        pcm = W.music_like(nch, n, bits, seed=i)
+        enc.set_wave_format(nch, bits, 48000)
+        enc.set_encode_parameter(order, 1, 8, 0, win, mb)
+        got = enc.encode_whole(pcm)
+        p = S.make_params(nch, bits, 48000, order, 1, 8, 0, win, mb, cap=(2, 8192, 32, 3, 8))
+        assert got == oracle.encode_whole(p, pcm)[1]
+    enc.close()
+
+
+# ------------------------------------------------------------------ kernel launchers (C-ABI, torch = device memory)
+
+def test_lattice_launcher_wraps_like_int32(oracle, hip):
+    """SURVEY H4 through sla_hip_launch_lattice: full-range data and coefficients overflow int32"""
+    import torch
+    L = hip.lib()
+    rng = np.random.default_rng(7)
+    n, order = 5000, 32
+    x = rng.integers(-2 ** 31, 2 ** 31 - 1, n, dtype=np.int64).astype(np.int32)
+    kint = rng.integers(-32768, 32767, order + 1, dtype=np.int64).astype(np.int32)
+    kint[0] = 0
+    want = oracle.lattice_predict(oracle.preemph_i32(x), kint)
+    L.sla_hip_lattice_chunk_samples.restype = C.c_uint32
+    per = L.sla_hip_lattice_chunk_samples(order)
+
+    class Chunk(C.Structure):
+        _fields_ = [("blk_off", C.c_uint64), ("blk_len", C.c_uint32), ("chunk_start", C.c_uint32),
+                    ("count", C.c_uint32), ("channel", C.c_uint32), ("slot", C.c_uint32), ("int_shift", C.c_uint32)]
+    chunks = (Chunk * ((n + per - 1) // per))()
+    for i in range(len(chunks)):
+        chunks[i] = Chunk(0, n, i * per, min(per, n - i * per), 0, 0, 0)
+    d_pcm = torch.from_numpy(x).cuda()
+    d_k = torch.from_numpy(kint).cuda()
+    d_chunks = torch.frombuffer(bytearray(bytes(chunks)), dtype=torch.uint8).cuda()
+    d_res = torch.zeros(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    rc = L.sla_hip_launch_lattice(C.c_void_p(d_pcm.data_ptr()), C.c_uint64(n), 0, order, C.c_void_p(d_chunks.data_ptr()),
+                                  len(chunks), C.c_void_p(d_k.data_ptr()), C.c_void_p(d_res.data_ptr()), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d_res.cpu().numpy(), want)
+
+
+def test_lpc_launcher_candidates(oracle, hip):
+    """sla_hip_launch_lpc on an un-windowed window with several sub-ranges == oracle autocorr+Levinson"""
+    import torch
+    L = hip.lib()
+    order, W_ = 16, 4096
+    pcm = W.music_like(1, W_, 24, seed=12)[0]
+    cand = [(0, 2048), (0, 3072), (0, 4096), (1024, 2048), (1024, 3072), (2048, 2048), (100, 37), (5, 9)]
+
+    class Group(C.Structure):
+        _fields_ = [("pcm_off", C.c_uint64)] + [(n, C.c_uint32) for n in (
+            "num_samples", "channel", "win_off", "int_shift", "cand_first", "cand_count", "slot_first", "pad_")]
+    groups = (Group * 1)(Group(0, W_, 0, 0xFFFFFFFF, 8, 0, len(cand), 0, 0))
+    cands = np.array(cand, np.uint32)
+    d_pcm = torch.from_numpy(pcm).cuda()
+    d_g = torch.frombuffer(bytearray(bytes(groups)), dtype=torch.uint8).cuda()
+    d_c = torch.from_numpy(cands).cuda()
+    d_out = torch.zeros(len(cand) * (order + 2), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    rc = L.sla_hip_launch_lpc(C.c_void_p(d_pcm.data_ptr()), C.c_uint64(W_), 0, order, C.c_void_p(d_g.data_ptr()), 1,
+                              W_, len(cand), C.c_void_p(d_c.data_ptr()), None, C.c_void_p(d_out.data_ptr()),
+                              None, None, None, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy().reshape(len(cand), order + 2)
+    x = pcm.astype(np.float64) * 2.0 ** -31
+    for i, (s, n) in enumerate(cand):
+        xs = x[s:s + n]
+        r0 = oracle.autocorr(xs, 1)[0]
+        _, par = oracle.parcor(xs, order)
+        assert out[i, 0].hex() == r0.hex()
+        assert np.array_equal(out[i, 1:].view(np.uint64), par.view(np.uint64)), (i, s, n)
+
+
+# ------------------------------------------------------------------ BASELINE sizes: size-independent properties
+
+def _full_size_check(oracle, hip, p, pcm, prefix_frames):
+    got, tr = hip_encode(hip, p, pcm, want_residuals=False)
+    n = pcm.shape[1]
+    nb = tr.num_blocks
+    assert int(tr.blk_nsmpl[:nb].sum()) == n and (tr.blk_start[1:nb] == np.cumsum(tr.blk_nsmpl[:nb - 1])).all()
+    assert len(got) == 43 + int(tr.blk_bytes[:nb].sum())
+    # (1) encode -> decode round trip to the original PCM (oracle decoder checks every block CRC16)
+    rd, dec, hdr = oracle.decode_whole(p, got, n)
+    assert rd == 0 and hdr[9] == nb and np.array_equal(dec, pcm)
+    # (2) prefix consistency: blocks are independent, so the oracle's encode of the first frames
+    #     must reproduce the first bytes of the big file exactly
+    m = prefix_frames * p.max_block_samples
+    ret, want, to = oracle.encode_trace(p, np.ascontiguousarray(pcm[:, :m]))
+    assert ret == 0 and to.offset_lshift == tr.offset_lshift
+    assert want[43:] == got[43:len(want)]
+    assert np.array_equal(tr.parcor[:to.num_blocks].view(np.uint64), to.parcor[:to.num_blocks].view(np.uint64))
+
+
+def test_full_size_c2(oracle, hip):
+    """BASELINE config 1: 48 kHz 16-bit mono, 10 min, order 16, 4096-sample frames"""
+    pcm = S.synth_pcm(1, 48000 * 600, 16, 48000)
+    p = S.make_params(1, 16, 48000, 16, 1, 8, 0, 1, 4096, cap=(1, 4096, 16, 1, 8))
+    _full_size_check(oracle, hip, p, pcm, 40)
+
+
+def test_c3_shape_five_minutes(oracle, hip):
+    """BASELINE config 2 shape (48 kHz 24-bit stereo, order 32, MS), 5 of its 60 minutes"""
+    pcm = S.synth_pcm(2, 48000 * 300, 24, 48000)
+    p = S.make_params(2, 24, 48000, 32, 3, 8, 1, 1, 4096, cap=(2, 4096, 32, 3, 8))
+    _full_size_check(oracle, hip, p, pcm, 20)
+
+
+def test_c5_shape_one_minute(oracle, hip):
+    """BASELINE config 4 shape (96 kHz 24-bit 8 channels, order 48, 8192 frames), 1 of its 30 minutes"""
+    pcm = S.synth_pcm(8, 96000 * 60, 24, 96000)
+    p = S.make_params(8, 24, 96000, 48, 3, 8, 0, 1, 8192, cap=(8, 8192, 48, 3, 8))
+    _full_size_check(oracle, hip, p, pcm, 6)
+
+
+def test_c4_batch_of_clips(oracle, hip):
+    """BASELINE config 3 shape: a batch of independent stereo clips through one encoder handle"""
+    enc = hip.Encoder(2, 4096, 16, 1, 8)
+    enc.set_wave_format(2, 16, 48000)
+    enc.set_encode_parameter(16, 1, 8, hip.CH_STEREO_MS, 1, 4096)
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096, cap=(2, 4096, 16, 1, 8))
+    for seed in range(12):
+        pcm = S.synth_pcm(2, 48000, 16, 48000, seed=1000 + seed)
+        got = enc.encode_whole(pcm)
+        assert got == oracle.encode_whole(p, pcm)[1]
+    enc.close()
