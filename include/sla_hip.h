@@ -79,6 +79,13 @@ typedef struct sla_hip_lattice_chunk {
   uint32_t int_shift;
 } sla_hip_lattice_chunk;
 
+/* One (block, channel) of the long-term analysis FFT. */
+typedef struct sla_hip_acf_job {
+  uint64_t blk_off;
+  uint32_t blk_len;
+  uint32_t channel;
+} sla_hip_acf_job;
+
 /* One (block, channel) of the serial tail (long-term filter + LMS + Rice sum). */
 typedef struct sla_hip_tail_job {
   uint64_t blk_off;
@@ -113,6 +120,16 @@ int sla_hip_launch_lattice(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
                            const sla_hip_lattice_chunk* d_chunks, uint32_t num_chunks,
                            const int32_t* d_kint, int32_t* d_residual, sla_hip_stream_t stream);
 
+/* First `head` lags of the autocorrelation of each job's residual, computed exactly as the reference's
+ * real-FFT route does (zero-padded to fft_size, forward, |.|^2, inverse).  d_twiddles holds the
+ * 3*fft_size doubles produced by the host with the reference's recurrence (layout: sla_kernels.hip).
+ * fft_size*8 bytes must fit SLA_HIP_LDS_BUDGET, otherwise d_scratch (scratch_slots x fft_size doubles
+ * of device memory) is used as the work area. */
+int sla_hip_launch_ltm_acf(const int32_t* d_residual, uint64_t plane_stride,
+                           const sla_hip_acf_job* d_jobs, uint32_t num_jobs, uint32_t fft_size,
+                           const double* d_twiddles, double* d_scratch, uint32_t scratch_slots,
+                           double* d_acf_head, uint32_t head, sla_hip_stream_t stream);
+
 /* Long-term filter + sign-log LMS + folded-residual sum, one lane per job.
  * d_res_in/d_res_out are channel planes with the same stride as the PCM. */
 int sla_hip_launch_tail(const int32_t* d_res_in, int32_t* d_res_out, uint64_t plane_stride,
@@ -139,7 +156,9 @@ typedef struct sla_hip_trace {
 /* Hot path on PCM resident in device memory: planar int32 [C][plane_stride],
  * left-justified.  On return the encoder holds, on the device, the final
  * residual planes and, on the host, the block table and per-block parameters.
- * `timing_ms` (may be NULL) receives 8 floats of per-stage GPU/host times. */
+ * `timing_ms` (may be NULL) receives 12 floats [ms]: HIP-event durations of k_prepass, k_lpc (search),
+ * k_lpc (blocks), k_lattice, k_tail; host wall time of planning and of the long-term solve; total
+ * wall time; HIP-event duration of k_ltm_acf; 3 reserved. */
 int sla_hip_analyze_device(struct SLAEncoder* encoder, const int32_t* d_pcm, uint64_t plane_stride,
                            uint32_t num_samples, sla_hip_stream_t stream, float* timing_ms);
 

@@ -121,6 +121,7 @@ EXPORTED_SYMBOLS = [
     "SLAEncoder_EncodeHeader", "SLAEncoder_EncodeBlock", "SLAEncoder_EncodeWhole",
     # include/sla_hip.h
     "sla_hip_launch_prepass", "sla_hip_launch_lpc", "sla_hip_launch_lattice", "sla_hip_launch_tail",
+    "sla_hip_launch_ltm_acf",
     "sla_hip_analyze_device", "sla_hip_pack", "sla_hip_final_residual", "sla_hip_lattice_residual",
     "sla_hip_get_trace", "sla_hip_device_name", "sla_hip_bind_residual_planes",
 ]
@@ -238,8 +239,8 @@ class Encoder:
         return out[:size.value].tobytes()
 
     def analyze_device(self, device_ptr, plane_stride, num_samples, stream=None):
-        """hot path on PCM already resident in HBM; returns the 8 stage timings [ms]"""
-        timing = (C.c_float * 8)()
+        """hot path on PCM already resident in HBM; returns the 12 stage timings [ms]"""
+        timing = (C.c_float * 12)()
         self._check(self._lib.sla_hip_analyze_device(self._h, C.c_void_p(device_ptr), plane_stride, num_samples,
                                                      C.c_void_p(stream) if stream else None, timing),
                     "sla_hip_analyze_device")

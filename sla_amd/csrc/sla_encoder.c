@@ -56,9 +56,10 @@ struct SLAEncoder {
 
   /* device workspace */
   devbuf_t d_pcm, d_res1, d_res2, d_or, d_nz, d_groups, d_cands, d_lpc_out, d_code, d_kint, d_rshift,
-           d_winpool, d_chunks, d_jobs, d_fold;
+           d_winpool, d_chunks, d_jobs, d_fold, d_acf_jobs, d_acf, d_acf_scratch, d_twiddle;
+  int twiddle_ready;
   /* pinned host staging */
-  pinbuf_t h_nz, h_groups, h_cands, h_lpc_out, h_code, h_kint, h_rshift, h_chunks, h_jobs, h_fold, h_res, h_pcm;
+  pinbuf_t h_nz, h_groups, h_cands, h_lpc_out, h_code, h_kint, h_rshift, h_chunks, h_jobs, h_fold, h_res, h_pcm, h_acf_jobs, h_acf;
   uint32_t* h_or;
 
   /* window pool: tables for every block length seen so far */
@@ -79,7 +80,7 @@ struct SLAEncoder {
   double*  parcor; int32_t* code; int32_t* kint;   /* [num_blocks*C*(order+1)] */
   size_t   coef_cap;
   int      analysed;
-  float    timing[8];
+  float    timing[12];
 };
 
 #define RES1(e) ((e)->user_res1 != NULL ? (e)->user_res1 : (int32_t*)(e)->d_res1.ptr)
@@ -190,18 +191,20 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
 
 void SLAEncoder_Destroy(struct SLAEncoder* e)
 {
-  devbuf_t* d[15];
-  pinbuf_t* h[12];
+  devbuf_t* d[19];
+  pinbuf_t* h[14];
   int i;
   if (e == NULL) { return; }
   (void)hipStreamSynchronize(e->stream);
   d[0] = &e->d_pcm; d[1] = &e->d_res1; d[2] = &e->d_res2; d[3] = &e->d_or; d[4] = &e->d_nz; d[5] = &e->d_groups;
   d[6] = &e->d_cands; d[7] = &e->d_lpc_out; d[8] = &e->d_code; d[9] = &e->d_kint; d[10] = &e->d_rshift;
   d[11] = &e->d_winpool; d[12] = &e->d_chunks; d[13] = &e->d_jobs; d[14] = &e->d_fold;
-  for (i = 0; i < 15; i++) { if (d[i]->ptr != NULL) { (void)hipFree(d[i]->ptr); } }
+  d[15] = &e->d_acf_jobs; d[16] = &e->d_acf; d[17] = &e->d_acf_scratch; d[18] = &e->d_twiddle;
+  for (i = 0; i < 19; i++) { if (d[i]->ptr != NULL) { (void)hipFree(d[i]->ptr); } }
   h[0] = &e->h_nz; h[1] = &e->h_groups; h[2] = &e->h_cands; h[3] = &e->h_lpc_out; h[4] = &e->h_code; h[5] = &e->h_kint;
   h[6] = &e->h_rshift; h[7] = &e->h_chunks; h[8] = &e->h_jobs; h[9] = &e->h_fold; h[10] = &e->h_res; h[11] = &e->h_pcm;
-  for (i = 0; i < 12; i++) { if (h[i]->ptr != NULL) { (void)hipHostFree(h[i]->ptr); } }
+  h[12] = &e->h_acf_jobs; h[13] = &e->h_acf;
+  for (i = 0; i < 14; i++) { if (h[i]->ptr != NULL) { (void)hipHostFree(h[i]->ptr); } }
   if (e->h_or != NULL) { (void)hipHostFree(e->h_or); }
   for (i = 0; i < 12; i++) { (void)hipEventDestroy(e->ev[i]); }
   (void)hipStreamDestroy(e->stream);
@@ -550,28 +553,20 @@ static int stage_plan(struct SLAEncoder* e)
 
 typedef struct {
   struct SLAEncoder* e;
-  const int32_t* res_host;     /* lattice residual planes on the host */
-  const uint32_t* job_blk; const uint32_t* job_ch;
+  const double* acf;           /* [ngroups][SLAI_LTM_ACF_HEAD] autocorrelation heads from k_ltm_acf */
+  const uint32_t* job_blk; const uint32_t* job_ch; const uint32_t* job_grp;
 } ltm_ctx_t;
 
+/* pitch + taps of one (block, channel) from the device's autocorrelation head */
 static void ltm_one(void* vctx, uint32_t j)
 {
   ltm_ctx_t* c = (ltm_ctx_t*)vctx;
   struct SLAEncoder* e = c->e;
   const uint32_t C = e->wave_format.num_channels, ntaps = e->encode_param.longterm_order;
-  const uint32_t b = c->job_blk[j], ch = c->job_ch[j];
-  blkch_t* bc = &e->bc[(size_t)b * C + ch];
-  double acf[SLAI_LTM_ACF_HEAD + 8], coef[SLAI_MAX_TAPS] = {0, 0, 0, 0, 0};
+  blkch_t* bc = &e->bc[(size_t)c->job_blk[j] * C + c->job_ch[j]];
+  double coef[SLAI_MAX_TAPS] = {0, 0, 0, 0, 0};
   uint32_t t;
-  int ret;
-  {
-    double* work = (double*)malloc(sizeof(double) * slai_fft_plan_size(e->fft));
-    if (work == NULL) { bc->pitch = 0; return; }
-    slai_ltm_autocorr_host(e->fft, work, c->res_host + (size_t)ch * e->num_samples + e->blk[b].start, e->blk[b].nsmpl,
-                           acf, SLAI_LTM_ACF_HEAD);
-    free(work);
-  }
-  ret = slai_ltm_solve(acf, ntaps, &bc->pitch, coef);
+  const int ret = slai_ltm_solve(c->acf + (size_t)c->job_grp[j] * SLAI_LTM_ACF_HEAD, ntaps, &bc->pitch, coef);
   if (ret != 0 || bc->pitch >= SLAI_LTM_MAX_PERIOD) { bc->pitch = 0; }      /* src/SLAEncoder.c:629-632 */
   for (t = 0; t < ntaps; t++) {
     /* Round(coef * 2^15) << 16, x86 conversion semantics       src/SLAEncoder.c:635-640 */
@@ -593,8 +588,10 @@ static int stage_blocks(struct SLAEncoder* e)
   const uint32_t chunk_samples = sla_hip_lattice_chunk_samples(order);
   const size_t nslots = (size_t)nb * C;
   sla_hip_lpc_group* groups; sla_hip_lpc_cand* cands; sla_hip_lattice_chunk* chunks; sla_hip_tail_job* jobs;
+  sla_hip_acf_job* acf_jobs;
   uint32_t ngroups = 0, nchunks = 0, njobs = 0, max_window = 1, b, ch;
-  uint32_t *job_blk, *job_ch;
+  uint32_t *job_blk, *job_ch, *job_grp, *grp_of_slot;
+  const uint32_t fft_size = slai_fft_plan_size(e->fft);
   double t0;
   int rc;
 
@@ -622,7 +619,9 @@ static int stage_blocks(struct SLAEncoder* e)
     RCCHK(pin_reserve(&e->h_cands, sizeof(sla_hip_lpc_cand) * (nslots + 1)));
     RCCHK(pin_reserve(&e->h_chunks, sizeof(sla_hip_lattice_chunk) * (total_chunks + 1)));
     RCCHK(pin_reserve(&e->h_jobs, sizeof(sla_hip_tail_job) * (nslots + 1)));
+    RCCHK(pin_reserve(&e->h_acf_jobs, sizeof(sla_hip_acf_job) * (nslots + 1)));
   }
+  acf_jobs = (sla_hip_acf_job*)e->h_acf_jobs.ptr;
   groups = (sla_hip_lpc_group*)e->h_groups.ptr; cands = (sla_hip_lpc_cand*)e->h_cands.ptr;
   chunks = (sla_hip_lattice_chunk*)e->h_chunks.ptr; jobs = (sla_hip_tail_job*)e->h_jobs.ptr;
   for (b = 0; b < nb; b++) {
@@ -636,6 +635,7 @@ static int stage_blocks(struct SLAEncoder* e)
       g->pcm_off = k->start; g->num_samples = k->nsmpl; g->channel = ch; g->win_off = woff; g->int_shift = shift;
       g->cand_first = ngroups; g->cand_count = 1; g->slot_first = b * C + ch; g->pad_ = 0;
       cands[ngroups].start = 0; cands[ngroups].len = k->nsmpl;
+      acf_jobs[ngroups].blk_off = k->start; acf_jobs[ngroups].blk_len = k->nsmpl; acf_jobs[ngroups].channel = ch;
       ngroups++;
       for (at = 0; at < k->nsmpl; at += chunk_samples) {
         sla_hip_lattice_chunk* c = &chunks[nchunks++];
@@ -663,6 +663,8 @@ static int stage_blocks(struct SLAEncoder* e)
   HIPCHK(hipEventRecord(e->ev[4], e->stream));
   HIPCHK(hipEventRecord(e->ev[5], e->stream));
   HIPCHK(hipEventRecord(e->ev[6], e->stream));
+  HIPCHK(hipEventRecord(e->ev[9], e->stream));
+  HIPCHK(hipEventRecord(e->ev[10], e->stream));
   if (ngroups > 0) {
     if (e->win_dirty) {
       RCCHK(dev_reserve(&e->d_winpool, sizeof(double) * e->win_count));
@@ -692,11 +694,32 @@ static int stage_blocks(struct SLAEncoder* e)
     HIPCHK(hipMemcpyAsync(e->h_code.ptr, e->d_code.ptr, sizeof(int32_t) * nslots * O1, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(e->h_kint.ptr, e->d_kint.ptr, sizeof(int32_t) * nslots * O1, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(e->h_rshift.ptr, e->d_rshift.ptr, sizeof(uint32_t) * nslots, hipMemcpyDeviceToHost, e->stream));
-    /* long-term analysis input (host FFT in this round) */
-    RCCHK(pin_reserve(&e->h_res, sizeof(int32_t) * (size_t)C * e->num_samples));
-    for (ch = 0; ch < C; ch++) {
-      HIPCHK(hipMemcpyAsync((int32_t*)e->h_res.ptr + (size_t)ch * e->num_samples, RES1(e) + (size_t)ch * e->stride,
-                            sizeof(int32_t) * e->num_samples, hipMemcpyDeviceToHost, e->stream));
+    /* long-term analysis: FFT autocorrelation heads of every lattice residual */
+    if (!e->twiddle_ready) {
+      double* tw = (double*)malloc(sizeof(double) * 3 * (size_t)fft_size);
+      if (tw == NULL) { return SLA_APIRESULT_NG; }
+      slai_fft_plan_export(e->fft, tw);
+      RCCHK(dev_reserve(&e->d_twiddle, sizeof(double) * 3 * (size_t)fft_size));
+      HIPCHK(hipMemcpy(e->d_twiddle.ptr, tw, sizeof(double) * 3 * (size_t)fft_size, hipMemcpyHostToDevice));
+      free(tw);
+      e->twiddle_ready = 1;
+    }
+    {
+      uint32_t slots = 0;
+      if (sizeof(double) * (size_t)fft_size > SLA_HIP_LDS_BUDGET) {
+        slots = (ngroups < 512) ? ngroups : 512;
+        RCCHK(dev_reserve(&e->d_acf_scratch, sizeof(double) * (size_t)fft_size * slots));
+      }
+      RCCHK(dev_reserve(&e->d_acf_jobs, sizeof(sla_hip_acf_job) * ngroups));
+      RCCHK(dev_reserve(&e->d_acf, sizeof(double) * (size_t)ngroups * SLAI_LTM_ACF_HEAD));
+      RCCHK(pin_reserve(&e->h_acf, sizeof(double) * (size_t)ngroups * SLAI_LTM_ACF_HEAD));
+      HIPCHK(hipMemcpyAsync(e->d_acf_jobs.ptr, acf_jobs, sizeof(sla_hip_acf_job) * ngroups, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipEventRecord(e->ev[9], e->stream));
+      RCCHK(sla_hip_launch_ltm_acf(RES1(e), e->stride, (const sla_hip_acf_job*)e->d_acf_jobs.ptr, ngroups, fft_size,
+                                   (const double*)e->d_twiddle.ptr, (double*)e->d_acf_scratch.ptr, slots,
+                                   (double*)e->d_acf.ptr, SLAI_LTM_ACF_HEAD, e->stream));
+      HIPCHK(hipEventRecord(e->ev[10], e->stream));
+      HIPCHK(hipMemcpyAsync(e->h_acf.ptr, e->d_acf.ptr, sizeof(double) * (size_t)ngroups * SLAI_LTM_ACF_HEAD, hipMemcpyDeviceToHost, e->stream));
     }
     HIPCHK(hipStreamSynchronize(e->stream));
   }
@@ -705,7 +728,15 @@ static int stage_blocks(struct SLAEncoder* e)
   t0 = now_ms();
   job_blk = (uint32_t*)malloc(sizeof(uint32_t) * (nslots + 1));
   job_ch = (uint32_t*)malloc(sizeof(uint32_t) * (nslots + 1));
-  if (job_blk == NULL || job_ch == NULL) { free(job_blk); free(job_ch); return SLA_APIRESULT_NG; }
+  job_grp = (uint32_t*)malloc(sizeof(uint32_t) * (nslots + 1));
+  grp_of_slot = (uint32_t*)malloc(sizeof(uint32_t) * (nslots + 1));
+  if (job_blk == NULL || job_ch == NULL || job_grp == NULL || grp_of_slot == NULL) {
+    free(job_blk); free(job_ch); free(job_grp); free(grp_of_slot); return SLA_APIRESULT_NG;
+  }
+  {
+    uint32_t g;
+    for (g = 0; g < ngroups; g++) { grp_of_slot[groups[g].slot_first] = g; }
+  }
   for (b = 0; b < nb; b++) {
     blk_t* k = &e->blk[b];
     if (k->type == SLAI_BLK_SILENT) { continue; }
@@ -722,14 +753,14 @@ static int stage_blocks(struct SLAEncoder* e)
       if (est >= SLAI_RAW_THRESHOLD) { k->type = SLAI_BLK_RAW; break; }
     }
     if (k->type == SLAI_BLK_COMPRESS) {
-      for (ch = 0; ch < C; ch++) { job_blk[njobs] = b; job_ch[njobs] = ch; njobs++; }
+      for (ch = 0; ch < C; ch++) { job_blk[njobs] = b; job_ch[njobs] = ch; job_grp[njobs] = grp_of_slot[(size_t)b * C + ch]; njobs++; }
     }
   }
 
   /* ---- host: long-term analysis (pitch + taps) per compressed (block, channel) ---------- */
   {
     ltm_ctx_t lc;
-    lc.e = e; lc.res_host = (const int32_t*)e->h_res.ptr; lc.job_blk = job_blk; lc.job_ch = job_ch;
+    lc.e = e; lc.acf = (const double*)e->h_acf.ptr; lc.job_blk = job_blk; lc.job_ch = job_ch; lc.job_grp = job_grp;
     parallel_for(e->threads, njobs, ltm_one, &lc);
   }
   e->timing[6] = (float)(now_ms() - t0);
@@ -754,7 +785,7 @@ static int stage_blocks(struct SLAEncoder* e)
     HIPCHK(hipEventRecord(e->ev[7], e->stream));
     rc = sla_hip_launch_tail(RES1(e), RES2(e), e->stride,
                              (const sla_hip_tail_job*)e->d_jobs.ptr, njobs, ntaps, lms, (uint64_t*)e->d_fold.ptr, e->stream);
-    if (rc != 0) { free(job_blk); free(job_ch); return rc; }
+    if (rc != 0) { free(job_blk); free(job_ch); free(job_grp); free(grp_of_slot); return rc; }
     HIPCHK(hipEventRecord(e->ev[8], e->stream));
     HIPCHK(hipMemcpyAsync(e->h_fold.ptr, e->d_fold.ptr, sizeof(uint64_t) * njobs, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -762,10 +793,14 @@ static int stage_blocks(struct SLAEncoder* e)
     for (j = 0; j < njobs; j++) {
       /* mean of the folded residual, at least 1                 src/SLACoder.c:371-384 */
       const uint64_t mean = fold[j] / e->blk[job_blk[j]].nsmpl;
-      e->bc[(size_t)job_blk[j] * C + job_ch[j]].rice_init = (uint32_t)(mean > 1 ? mean : 1);
+      const uint32_t init = (uint32_t)(mean > 1 ? mean : 1);
+      /* the coder keeps the parameter as a 32-bit 24.8 fixed-point word (src/SLACoder.c:14,19):
+       * store the value that survives that round trip, which is also what is transmitted */
+      const uint32_t kept = (uint32_t)((((uint64_t)(uint32_t)(init << 8)) + 128u) >> 8);
+      e->bc[(size_t)job_blk[j] * C + job_ch[j]].rice_init = kept ? kept : 1u;
     }
   }
-  free(job_blk); free(job_ch);
+  free(job_blk); free(job_ch); free(job_grp); free(grp_of_slot);
   return 0;
 }
 
@@ -793,6 +828,7 @@ static void collect_timing(struct SLAEncoder* e, double t_start)
   e->timing[2] = (hipEventElapsedTime(&ms, e->ev[4], e->ev[5]) == hipSuccess) ? ms : -1.f;
   e->timing[3] = (hipEventElapsedTime(&ms, e->ev[5], e->ev[6]) == hipSuccess) ? ms : -1.f;
   e->timing[4] = (hipEventElapsedTime(&ms, e->ev[7], e->ev[8]) == hipSuccess) ? ms : -1.f;
+  e->timing[8] = (hipEventElapsedTime(&ms, e->ev[9], e->ev[10]) == hipSuccess) ? ms : -1.f;
   e->timing[7] = (float)(now_ms() - t_start);
 }
 

@@ -51,9 +51,8 @@ int      slai_range_is_zero(const uint64_t* nz_mask, uint64_t from, uint64_t cou
 typedef struct slai_fft_plan slai_fft_plan;
 slai_fft_plan* slai_fft_plan_create(uint32_t fft_size);
 void           slai_fft_plan_destroy(slai_fft_plan* plan);
-/* autocorrelation (first `head` lags) of an int32 residual via the reference's real FFT */
 uint32_t       slai_fft_plan_size(const slai_fft_plan* plan);
-void slai_ltm_autocorr_host(const slai_fft_plan* plan, double* work, const int32_t* res, uint32_t n, double* acf_head, uint32_t head);
+void           slai_fft_plan_export(const slai_fft_plan* plan, double* out /* 3*fft_size doubles */);
 /* pitch + Q31 taps from the autocorrelation head; returns 0 ok, 4 analysis failed */
 int  slai_ltm_solve(const double* acf, uint32_t ntaps, uint32_t* pitch, double* coef);
 #define SLAI_LTM_ACF_HEAD (SLAI_LTM_MAX_PERIOD + 8)

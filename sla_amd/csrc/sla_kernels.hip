@@ -371,6 +371,127 @@ void k_tail(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, u
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_ltm_acf: autocorrelation of the lattice residual by the reference's real FFT
+// (src/SLAPredictor.c:827-853, src/SLAUtility.c:220-312): forward real FFT -> |.|^2 -> inverse.
+// One workgroup per (block, channel); the F doubles live in LDS (F <= 16384) or, for the largest
+// encoder capacity, in an L2-resident global scratch slot.  Bit-exactness: twiddles are NOT
+// evaluated here -- the host generates them once with the reference's sin()-seeded recurrence --
+// and every butterfly is the same mul/mul/sub, mul/mul/add, sub, sub, add, add sequence; the order
+// of butterflies inside a stage is free because they touch disjoint elements.
+// Twiddle buffer layout (doubles): [0,F/2) stage re fwd | [F/2,F) stage im fwd | [F,3F/2) re inv |
+// [3F/2,2F) im inv | [2F,2F+F/4) real-pass re fwd | +F/4 im fwd | +F/4 re inv | +F/4 im inv.
+// ---------------------------------------------------------------------------------------------
+#define ACF_THREADS 512
+
+__device__ __forceinline__ void acf_stages(double* z, uint32_t log2npts, const double* __restrict__ twr,
+                                           const double* __restrict__ twi)
+{
+  const uint32_t npts = 1u << log2npts;
+  uint32_t log2h = 0;
+  for (uint32_t mmax = 2; mmax < 2 * npts; mmax <<= 1, log2h++) {
+    const uint32_t h = mmax >> 1, base = h - 1;
+    for (uint32_t b = threadIdx.x; b < (npts >> 1); b += ACF_THREADS) {
+      const uint32_t k = b & (h - 1), blk = b >> log2h;
+      const uint32_t i = 2 * k + blk * 2 * mmax, q = i + mmax;
+      const double wr = twr[base + k], wi = twi[base + k];
+      const double zq0 = z[q], zq1 = z[q + 1], zi0 = z[i], zi1 = z[i + 1];
+      const double tr = wr * zq0 - wi * zq1;
+      const double ti = wr * zq1 + wi * zq0;
+      z[q] = zi0 - tr;
+      z[q + 1] = zi1 - ti;
+      z[i] = zi0 + tr;
+      z[i + 1] = zi1 + ti;
+    }
+    __syncthreads();
+  }
+}
+
+// the h1/h2 recombination pass shared by the forward and the inverse real transform
+__device__ __forceinline__ void acf_real_pass(double* d, uint32_t F, double c2, const double* __restrict__ rtr,
+                                              const double* __restrict__ rti)
+{
+  const double c1 = 0.5;
+  for (uint32_t i = 2 + threadIdx.x; i <= (F >> 2); i += ACF_THREADS) {
+    const uint32_t i1 = 2 * i - 2, i2 = i1 + 1, i3 = F - i1, i4 = i3 + 1;
+    const double wr = rtr[i - 2], wi = rti[i - 2];
+    const double a1 = d[i1], a2 = d[i2], a3 = d[i3], a4 = d[i4];
+    const double h1r = c1 * (a1 + a3);
+    const double h1i = c1 * (a2 - a4);
+    const double h2r = -c2 * (a2 + a4);
+    const double h2i = c2 * (a1 - a3);
+    d[i1] = h1r + wr * h2r - wi * h2i;
+    d[i2] = h1i + wr * h2i + wi * h2r;
+    d[i3] = h1r - wr * h2r + wi * h2i;
+    d[i4] = -h1i + wr * h2i + wi * h2r;
+  }
+}
+
+template <bool IN_LDS>
+__global__ __launch_bounds__(ACF_THREADS)
+void k_ltm_acf(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_acf_job* __restrict__ jobs,
+               uint32_t njobs, uint32_t log2F, const double* __restrict__ tw, double* __restrict__ scratch,
+               double* __restrict__ out, uint32_t head)
+{
+  extern __shared__ double lds[];
+  const uint32_t F = 1u << log2F, npts = F >> 1, log2npts = log2F - 1;
+  double* d = IN_LDS ? lds : (scratch + (uint64_t)blockIdx.x * F);
+  const double* twr_f = tw;            const double* twi_f = tw + (F >> 1);
+  const double* twr_i = tw + F;        const double* twi_i = tw + F + (F >> 1);
+  const double* rtr_f = tw + 2 * F;    const double* rti_f = rtr_f + (F >> 2);
+  const double* rtr_i = rti_f + (F >> 2); const double* rti_i = rtr_i + (F >> 2);
+  const double scale = 4.656612873077392578125e-10;   // 2^-31
+
+  for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) {
+    const sla_hip_acf_job jb = jobs[job];
+    const int32_t* src = res + (uint64_t)jb.channel * stride + jb.blk_off;
+    const uint32_t n = jb.blk_len;
+    // load, zero-padded, straight into bit-reversed complex order
+    for (uint32_t k = threadIdx.x; k < npts; k += ACF_THREADS) {
+      const uint32_t j = __brev(k) >> (32 - log2npts);
+      d[2 * j]     = (2 * k < n)     ? (double)src[2 * k] * scale     : 0.0;
+      d[2 * j + 1] = (2 * k + 1 < n) ? (double)src[2 * k + 1] * scale : 0.0;
+    }
+    __syncthreads();
+    acf_stages(d, log2npts, twr_f, twi_f);
+    acf_real_pass(d, F, -0.5, rtr_f, rti_f);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double h = d[0];
+      const double s0 = h + d[1], s1 = h - d[1];
+      d[0] = s0 * s0;                    // DC and Nyquist power
+      d[1] = s1 * s1;
+    }
+    for (uint32_t i = 1 + threadIdx.x; i < npts; i += ACF_THREADS) {
+      const double re = d[2 * i], im = d[2 * i + 1];
+      d[2 * i] = re * re + im * im;
+      d[2 * i + 1] = 0.0;
+    }
+    __syncthreads();
+    acf_real_pass(d, F, 0.5, rtr_i, rti_i);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double h = d[0], g = d[1];
+      d[0] = 0.5 * (h + g);
+      d[1] = 0.5 * (h - g);
+    }
+    __syncthreads();
+    // in-place bit reversal, then the inverse stages
+    for (uint32_t k = threadIdx.x; k < npts; k += ACF_THREADS) {
+      const uint32_t j = __brev(k) >> (32 - log2npts);
+      if (j > k) {
+        const double a = d[2 * k], b = d[2 * k + 1];
+        d[2 * k] = d[2 * j]; d[2 * k + 1] = d[2 * j + 1];
+        d[2 * j] = a; d[2 * j + 1] = b;
+      }
+    }
+    __syncthreads();
+    acf_stages(d, log2npts, twr_i, twi_i);
+    for (uint32_t t = threadIdx.x; t < head; t += ACF_THREADS) { out[(uint64_t)job * head + t] = d[t]; }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers (C-ABI, see include/sla_hip.h)
 // ---------------------------------------------------------------------------------------------
 static inline int hip_rc(hipError_t e) { return (e == hipSuccess) ? 0 : -(int)e; }
@@ -448,6 +569,32 @@ extern "C" int sla_hip_launch_tail(const int32_t* d_res_in, int32_t* d_res_out, 
     case 16: hipLaunchKernelGGL(k_tail<16>, grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum); break;
     case 32: hipLaunchKernelGGL(k_tail<32>, grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum); break;
     default: return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY;
+  }
+  return hip_rc(hipGetLastError());
+}
+
+extern "C" int sla_hip_launch_ltm_acf(const int32_t* d_residual, uint64_t plane_stride,
+                                      const sla_hip_acf_job* d_jobs, uint32_t num_jobs, uint32_t fft_size,
+                                      const double* d_twiddles, double* d_scratch, uint32_t scratch_slots,
+                                      double* d_acf_head, uint32_t head, sla_hip_stream_t stream)
+{
+  if (d_residual == nullptr || d_jobs == nullptr || d_twiddles == nullptr || d_acf_head == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (fft_size < 1024 || fft_size > 65536 * 2 || (fft_size & (fft_size - 1)) || head == 0 || head > fft_size) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (num_jobs == 0) { return 0; }
+  uint32_t log2F = 0;
+  while ((1u << log2F) < fft_size) { log2F++; }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = sizeof(double) * (size_t)fft_size;
+  if (lds <= SLA_HIP_LDS_BUDGET) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_ltm_acf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { return hip_rc(e); }
+    hipLaunchKernelGGL(k_ltm_acf<true>, dim3(num_jobs), dim3(ACF_THREADS), lds, st, d_residual, plane_stride, d_jobs, num_jobs,
+                       log2F, d_twiddles, (double*)nullptr, d_acf_head, head);
+  } else {
+    if (d_scratch == nullptr || scratch_slots == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+    uint32_t grid = (num_jobs < scratch_slots) ? num_jobs : scratch_slots;
+    hipLaunchKernelGGL(k_ltm_acf<false>, dim3(grid), dim3(ACF_THREADS), 0, st, d_residual, plane_stride, d_jobs, num_jobs,
+                       log2F, d_twiddles, d_scratch, d_acf_head, head);
   }
   return hip_rc(hipGetLastError());
 }

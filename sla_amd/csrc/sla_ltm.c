@@ -95,90 +95,22 @@ void slai_fft_plan_destroy(slai_fft_plan* p)
   free(p);
 }
 
-/* in-place complex FFT over z[0..2*npts) (re,im interleaved), decimation in time */
-static void complex_fft(const slai_fft_plan* p, double* z, uint32_t npts, int dir)
-{
-  const uint32_t n = npts << 1;
-  uint32_t i, j = 0, m, mmax;
-  for (i = 0; i < n; i += 2) {              /* bit-reversal permutation */
-    if (j > i) {
-      double t;
-      t = z[j]; z[j] = z[i]; z[i] = t;
-      t = z[j + 1]; z[j + 1] = z[i + 1]; z[i + 1] = t;
-    }
-    m = npts;
-    while (m >= 2 && j >= m) { j -= m; m >>= 1; }
-    j += m;
-  }
-  for (mmax = 2; mmax < n; mmax <<= 1) {
-    const uint32_t step = mmax << 1, base = mmax / 2 - 1;
-    uint32_t k;
-    for (k = 0; k < mmax / 2; k++) {
-      const double wr = p->tw_re[dir][base + k], wi = p->tw_im[dir][base + k];
-      for (i = 2 * k; i < n; i += step) {
-        const uint32_t q = i + mmax;
-        const double tr = wr * z[q] - wi * z[q + 1];
-        const double ti = wr * z[q + 1] + wi * z[q];
-        z[q] = z[i] - tr;
-        z[q + 1] = z[i + 1] - ti;
-        z[i] += tr;
-        z[i + 1] += ti;
-      }
-    }
-  }
-}
-
-/* real FFT (dir 0) / its un-normalised inverse (dir 1) of d[0..n) */
-static void real_fft(const slai_fft_plan* p, double* d, int dir)
-{
-  const uint32_t n = p->fft_size;
-  const double c1 = 0.5, c2 = (dir == 0) ? -0.5 : 0.5;
-  uint32_t i;
-  if (dir == 0) { complex_fft(p, d, n >> 1, 0); }
-  for (i = 2; i <= (n >> 2); i++) {
-    const uint32_t i1 = 2 * i - 2, i2 = i1 + 1, i3 = n - i1, i4 = i3 + 1;   /* 0-based */
-    const double wr = p->rt_re[dir][i - 2], wi = p->rt_im[dir][i - 2];
-    const double h1r = c1 * (d[i1] + d[i3]);
-    const double h1i = c1 * (d[i2] - d[i4]);
-    const double h2r = -c2 * (d[i2] + d[i4]);
-    const double h2i = c2 * (d[i1] - d[i3]);
-    d[i1] = h1r + wr * h2r - wi * h2i;
-    d[i2] = h1i + wr * h2i + wi * h2r;
-    d[i3] = h1r - wr * h2r + wi * h2i;
-    d[i4] = -h1i + wr * h2i + wi * h2r;
-  }
-  if (dir == 0) {
-    const double h = d[0];
-    d[0] = h + d[1];
-    d[1] = h - d[1];
-  } else {
-    const double h = d[0];
-    d[0] = c1 * (h + d[1]);
-    d[1] = c1 * (h - d[1]);
-    complex_fft(p, d, n >> 1, 1);
-  }
-}
-
-/* Wiener-Khinchin autocorrelation as the reference computes it
- * (src/SLAPredictor.c:827-853) */
 uint32_t slai_fft_plan_size(const slai_fft_plan* p) { return p->fft_size; }
 
-/* `d` is caller scratch of fft_size doubles (the plan itself is read-only and shared by threads) */
-void slai_ltm_autocorr_host(const slai_fft_plan* p, double* d, const int32_t* res, uint32_t n, double* acf_head, uint32_t head)
+/* flat copy for the device kernel (layout documented at k_ltm_acf in sla_kernels.hip):
+ * 3 * fft_size doubles */
+void slai_fft_plan_export(const slai_fft_plan* p, double* out)
 {
-  const uint32_t fft = p->fft_size;
-  uint32_t i;
-  for (i = 0; i < fft; i++) { d[i] = (i < n) ? (double)res[i] * ldexp(1.0, -31) : 0.0; }
-  real_fft(p, d, 0);
-  d[0] *= d[0];
-  d[1] *= d[1];
-  for (i = 1; i < fft / 2; i++) {
-    const double re = d[2 * i], im = d[2 * i + 1];
-    d[2 * i] = re * re + im * im;
-    d[2 * i + 1] = 0.0;
-  }
-  real_fft(p, d, 1);
-  memcpy(acf_head, d, sizeof(double) * head);
+  const uint32_t F = p->fft_size, half = F / 2, quarter = F / 4;
+  memset(out, 0, sizeof(double) * 3 * (size_t)F);
+  memcpy(out,                       p->tw_re[0], sizeof(double) * (half - 1));
+  memcpy(out + half,                p->tw_im[0], sizeof(double) * (half - 1));
+  memcpy(out + F,                   p->tw_re[1], sizeof(double) * (half - 1));
+  memcpy(out + F + half,            p->tw_im[1], sizeof(double) * (half - 1));
+  memcpy(out + 2 * F,               p->rt_re[0], sizeof(double) * (quarter - 1));
+  memcpy(out + 2 * F + quarter,     p->rt_im[0], sizeof(double) * (quarter - 1));
+  memcpy(out + 2 * F + 2 * quarter, p->rt_re[1], sizeof(double) * (quarter - 1));
+  memcpy(out + 2 * F + 3 * quarter, p->rt_im[1], sizeof(double) * (quarter - 1));
 }
 
 /* ---- tiny dense solve (reference src/SLAUtility.c:487-674) ---------------- */

@@ -81,6 +81,12 @@ def main():
         "p4": lambda: diag("music o32 16384", W.music_like(1, 40000, 16, seed=8), 16, 48000, 32, 3, 8, 0, 1, 16384, (8, 16384, 48, 5, 40)),
     }
     allok = True
+    if which.startswith("matrix:"):
+        _, name, nch, bits, lshift = which.split(":")
+        nch, bits, lshift = int(nch), int(bits), int(lshift)
+        pcm = W.gen(name, nch, 8192 + 517, bits, lshift=lshift, seed=nch * 100 + bits)
+        ok = diag(which, pcm, bits, 44100, 4, 1, 4, 0, 1, 16384, (8, 16384, 48, 5, 40))
+        return 0 if ok else 1
     for k, fn in cases.items():
         if which in ("all", k):
             allok &= bool(fn())

@@ -141,11 +141,8 @@ def test_zero_run_helpers(L):
 
 
 @pytest.mark.parametrize("ntaps", [1, 3, 5])
-def test_longterm_host_analysis(L, oracle, ntaps):
-    L.slai_fft_plan_create.restype = C.c_void_p
-    L.slai_fft_plan_create.argtypes = [C.c_uint32]
-    L.slai_fft_plan_destroy.argtypes = [C.c_void_p]
-    L.slai_ltm_autocorr_host.argtypes = [C.c_void_p, f64p, i32p, C.c_uint32, f64p, C.c_uint32]
+def test_longterm_solve(L, oracle, ntaps):
+    """pitch picking + Toeplitz solve from an autocorrelation head (the FFT itself runs on the GPU)"""
     L.slai_ltm_solve.argtypes = [f64p, C.c_uint32, u32p, f64p]
     rng = np.random.default_rng(ntaps)
     cases = [W.gen(nm, 1, 4096, 16, seed=11)[0] >> 18 for nm in W.NAMES]
@@ -153,14 +150,9 @@ def test_longterm_host_analysis(L, oracle, ntaps):
     cases.append((np.tile(base, 50)[:4096] + rng.integers(-50, 50, 4096)).astype(np.int32))
     cases.append((np.tile(base[:2], 2048) * 3).astype(np.int32))
     for fft in (8192, 32768):
-        plan = L.slai_fft_plan_create(fft)
-        work = np.zeros(fft)
         for res in cases:
-            res = np.ascontiguousarray(res, np.int32)
-            head = np.zeros(264)
-            L.slai_ltm_autocorr_host(plan, ptr(work, f64p), ptr(res, i32p), len(res), ptr(head, f64p), 264)
-            ret, pitch, coef, ac = oracle.ltm_analyze(res, fft, ntaps, want_autocorr=True)
-            assert np.array_equal(head.view(np.uint64), ac[:264].view(np.uint64))
+            ret, pitch, coef, ac = oracle.ltm_analyze(np.ascontiguousarray(res, np.int32), fft, ntaps, want_autocorr=True)
+            head = np.ascontiguousarray(ac[:264])
             got_pitch = C.c_uint32(0)
             got = np.zeros(5)
             r2 = L.slai_ltm_solve(ptr(head, f64p), ntaps, C.byref(got_pitch), ptr(got, f64p))
@@ -168,7 +160,63 @@ def test_longterm_host_analysis(L, oracle, ntaps):
             if ret == 0:
                 assert got_pitch.value == pitch
                 assert np.array_equal(got[:ntaps].view(np.uint64), coef.view(np.uint64))
-        L.slai_fft_plan_destroy(plan)
+
+
+def test_fft_twiddle_tables(L, oracle):
+    """the twiddle tables shipped to k_ltm_acf reproduce the reference FFT when driven by a plain
+    numpy butterfly loop (same evaluation order as the kernel)"""
+    L.slai_fft_plan_create.restype = C.c_void_p
+    L.slai_fft_plan_create.argtypes = [C.c_uint32]
+    L.slai_fft_plan_destroy.argtypes = [C.c_void_p]
+    L.slai_fft_plan_export.argtypes = [C.c_void_p, f64p]
+    F = 1024
+    plan = L.slai_fft_plan_create(F)
+    tw = np.zeros(3 * F)
+    L.slai_fft_plan_export(plan, ptr(tw, f64p))
+    L.slai_fft_plan_destroy(plan)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(F)
+
+    def stages(z, twr, twi):
+        npts = F // 2
+        mmax = 2
+        while mmax < 2 * npts:
+            h = mmax // 2
+            for b in range(npts // 2):
+                k, blk = b % h, b // h
+                i = 2 * k + blk * 2 * mmax
+                q = i + mmax
+                wr, wi = twr[h - 1 + k], twi[h - 1 + k]
+                tr = wr * z[q] - wi * z[q + 1]
+                ti = wr * z[q + 1] + wi * z[q]
+                z[q], z[q + 1], z[i], z[i + 1] = z[i] - tr, z[i + 1] - ti, z[i] + tr, z[i + 1] + ti
+            mmax *= 2
+
+    def real_pass(d, c2, rtr, rti):
+        for i in range(2, F // 4 + 1):
+            i1 = 2 * i - 2; i2 = i1 + 1; i3 = F - i1; i4 = i3 + 1
+            wr, wi = rtr[i - 2], rti[i - 2]
+            h1r = 0.5 * (d[i1] + d[i3]); h1i = 0.5 * (d[i2] - d[i4])
+            h2r = -c2 * (d[i2] + d[i4]); h2i = c2 * (d[i1] - d[i3])
+            d[i1] = h1r + wr * h2r - wi * h2i; d[i2] = h1i + wr * h2i + wi * h2r
+            d[i3] = h1r - wr * h2r + wi * h2i; d[i4] = -h1i + wr * h2i + wi * h2r
+
+    npts, lg = F // 2, 9
+    rev = [int(format(k, "0%db" % lg)[::-1], 2) for k in range(npts)]
+    d = np.zeros(F)
+    for k in range(npts):
+        d[2 * rev[k]], d[2 * rev[k] + 1] = x[2 * k], x[2 * k + 1]
+    stages(d, tw[0:F // 2], tw[F // 2:F])
+    real_pass(d, -0.5, tw[2 * F:], tw[2 * F + F // 4:])
+    h = d[0]; d[0], d[1] = h + d[1], h - d[1]
+    assert np.array_equal(d.view(np.uint64), oracle.fft(x, 1).view(np.uint64))
+    real_pass(d, 0.5, tw[2 * F + 2 * (F // 4):], tw[2 * F + 3 * (F // 4):])
+    h = d[0]; d[0], d[1] = 0.5 * (h + d[1]), 0.5 * (h - d[1])
+    e = d.copy()
+    for k in range(npts):
+        e[2 * rev[k]], e[2 * rev[k] + 1] = d[2 * k], d[2 * k + 1]
+    stages(e, tw[F:F + F // 2], tw[F + F // 2:2 * F])
+    assert np.array_equal(e.view(np.uint64), oracle.fft(oracle.fft(x, 1), -1).view(np.uint64))
 
 
 class BlockParams(C.Structure):
