@@ -20,6 +20,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def hip():
+    # torch (device memory for the launcher tests) must bring up its HIP runtime before
+    # libsla_hip.so binds libamdhip64, otherwise torch reports "No HIP GPUs are available"
+    import torch
+    torch.cuda.init()
     import sla_amd
     sla_amd.lib()
     return sla_amd
