@@ -86,10 +86,12 @@ def main():
     enc.bind_residual_planes(d_lat.data_ptr(), d_fin.data_ptr(), stride)
     torch.cuda.synchronize()
 
+    from sla_amd import dist as sdist
+
     def step():
         t = enc.analyze_device(d_pcm.data_ptr(), stride, n)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, d_fin)      # RCCL over xGMI: re-assemble the residual stream
+            sdist.all_gather_planes(d_fin, gathered)          # RCCL over xGMI: re-assemble the residual stream
         return t
 
     for _ in range(args.warmup):
@@ -106,9 +108,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed = sdist.max_over_ranks(elapsed, "cuda")
     kernel_ms /= max(args.steps, 1)
 
     total_samples = float(n) * nch * world * args.steps
