@@ -99,20 +99,27 @@ __device__ __forceinline__ double chain_lag0(const double* __restrict__ xs, uint
 
 // lag >= 1, lag < n.  Order of terms: for i in [0,lag): for l in {0,2lag,..,span-2lag}:
 //   x[l+lag+i]*(x[l+i]+x[l+2lag+i]);  then the leftover products x[span+lag+i]*x[span+i].
+// The (i,l) nest is flattened so that lanes with different lags share one loop; inside one i the
+// right neighbour of this step is the left neighbour of the next, so a step costs two LDS reads.
 __device__ __forceinline__ double chain_lag(const double* __restrict__ xs, uint32_t n, uint32_t lag)
 {
   const uint32_t lag2 = lag << 1;
   const uint32_t groups = ((3 * lag) < n) ? (1 + (n - 3 * lag) / lag2) : 0;
   const uint32_t span = groups * lag2;
   double acc = 0.0;
-  // flattened (i, l) walk so that lanes with different lags stay in one loop
-  uint32_t steps = groups * lag, i = 0, l = 0;
-  for (uint32_t s = 0; s < steps; s++) {
-    double c = xs[l + lag + i];
-    double e = xs[l + i] + xs[l + lag2 + i];
-    acc += c * e;
-    l += lag2;
-    if (l >= span) { l = 0; i++; }
+  if (groups > 0) {
+    const uint32_t steps = groups * lag;
+    uint32_t i = 0, left = groups;            // `left` steps remain in the current i
+    const double* p = xs;                     // &xs[l + i]
+    double a = p[0];
+    for (uint32_t s = 0; s < steps; s++) {
+      const double c = p[lag];
+      const double b = p[lag2];
+      acc += c * (a + b);
+      p += lag2;
+      a = b;
+      if (--left == 0) { left = groups; i++; p = xs + i; a = p[0]; }
+    }
   }
   const uint32_t rest = n - span - lag;
   const double* t = xs + span;
@@ -169,14 +176,19 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
   __syncthreads();
 
   // ---- autocorrelation chains -----------------------------------------------------------------
-  const uint32_t nchains = nc * O1;
-  for (uint32_t chain = threadIdx.x; chain < nchains; chain += blockDim.x) {
-    const uint32_t c = chain / O1, lag = chain - c * O1;
-    const uint32_t start = cd[c].start, n = cd[c].len;
-    const double* xs = x + start;
-    double acc = 0.0;
-    if (lag < n) { acc = (lag == 0) ? chain_lag0(xs, n) : chain_lag(xs, n, lag); }
-    r[chain] = acc;
+  // waves 0..2 walk the lag >= 1 chains, wave 3 the lag-0 (energy) chains: the two loop bodies differ,
+  // so keeping them in different waves avoids executing both serially under divergence
+  if (threadIdx.x < 192) {
+    const uint32_t nchains = nc * order;
+    for (uint32_t q = threadIdx.x; q < nchains; q += 192) {
+      const uint32_t c = q / order, lag = 1 + (q - c * order);
+      const uint32_t n = cd[c].len;
+      r[c * O1 + lag] = (lag < n) ? chain_lag(x + cd[c].start, n, lag) : 0.0;
+    }
+  } else {
+    for (uint32_t c = threadIdx.x - 192; c < nc; c += 64) {
+      r[c * O1] = chain_lag0(x + cd[c].start, cd[c].len);
+    }
   }
   __syncthreads();
 
