@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <float.h>
+#include <stdlib.h>
 
 #include "sla_hip.h"
 
@@ -90,17 +91,29 @@ void k_prepass(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t nch, u
 // sequential FP64 accumulation (the reference's order decides the rounding), so the available
 // parallelism is (candidates x lags x groups), not the samples of one sum.
 // ---------------------------------------------------------------------------------------------
+// Chains are latency-bound (LDS read -> add -> mul -> add, few waves per SIMD because the window owns
+// the LDS), so both loops fetch CHAIN_U steps of operands before they run the CHAIN_U dependent
+// accumulations: the sum order is untouched, only the loads move up.
+#define CHAIN_U 8
+
 __device__ __forceinline__ double chain_lag0(const double* __restrict__ xs, uint32_t n)
 {
   double acc = 0.0;
-  for (uint32_t i = 0; i < n; i++) { double v = xs[i]; acc += v * v; }
+  uint32_t i = 0;
+  for (; i + CHAIN_U <= n; i += CHAIN_U) {
+    double v[CHAIN_U];
+#pragma unroll
+    for (int u = 0; u < CHAIN_U; u++) { v[u] = xs[i + u]; }
+#pragma unroll
+    for (int u = 0; u < CHAIN_U; u++) { acc += v[u] * v[u]; }
+  }
+  for (; i < n; i++) { const double v = xs[i]; acc += v * v; }
   return acc;
 }
 
 // lag >= 1, lag < n.  Order of terms: for i in [0,lag): for l in {0,2lag,..,span-2lag}:
 //   x[l+lag+i]*(x[l+i]+x[l+2lag+i]);  then the leftover products x[span+lag+i]*x[span+i].
-// The (i,l) nest is flattened so that lanes with different lags share one loop; inside one i the
-// right neighbour of this step is the left neighbour of the next, so a step costs two LDS reads.
+// The (i,l) nest is flattened so that lanes with different lags share one loop.
 __device__ __forceinline__ double chain_lag(const double* __restrict__ xs, uint32_t n, uint32_t lag)
 {
   const uint32_t lag2 = lag << 1;
@@ -109,16 +122,23 @@ __device__ __forceinline__ double chain_lag(const double* __restrict__ xs, uint3
   double acc = 0.0;
   if (groups > 0) {
     const uint32_t steps = groups * lag;
-    uint32_t i = 0, left = groups;            // `left` steps remain in the current i
+    uint32_t i = 0, left = groups, s = 0;     // `left` steps remain in the current i
     const double* p = xs;                     // &xs[l + i]
-    double a = p[0];
-    for (uint32_t s = 0; s < steps; s++) {
-      const double c = p[lag];
-      const double b = p[lag2];
-      acc += c * (a + b);
+    for (; s + CHAIN_U <= steps; s += CHAIN_U) {
+      double a[CHAIN_U], c[CHAIN_U], b[CHAIN_U];
+#pragma unroll
+      for (int u = 0; u < CHAIN_U; u++) {
+        a[u] = p[0]; c[u] = p[lag]; b[u] = p[lag2];
+        p += lag2;
+        if (--left == 0) { left = groups; i++; p = xs + i; }
+      }
+#pragma unroll
+      for (int u = 0; u < CHAIN_U; u++) { acc += c[u] * (a[u] + b[u]); }
+    }
+    for (; s < steps; s++) {
+      acc += p[lag] * (p[0] + p[lag2]);
       p += lag2;
-      a = b;
-      if (--left == 0) { left = groups; i++; p = xs + i; a = p[0]; }
+      if (--left == 0) { left = groups; i++; p = xs + i; }
     }
   }
   const uint32_t rest = n - span - lag;
@@ -139,7 +159,7 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
            const sla_hip_lpc_group* __restrict__ groups, const sla_hip_lpc_cand* __restrict__ cands,
            const double* __restrict__ window_pool, double* __restrict__ out,
            int32_t* __restrict__ out_code, int32_t* __restrict__ out_kint, uint32_t* __restrict__ out_rshift,
-           uint32_t x_region)
+           uint32_t x_region, uint32_t dbg_skip)
 {
   extern __shared__ double lds[];
   const sla_hip_lpc_group g = groups[blockIdx.x];
@@ -178,7 +198,9 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
   // ---- autocorrelation chains -----------------------------------------------------------------
   // waves 0..2 walk the lag >= 1 chains, wave 3 the lag-0 (energy) chains: the two loop bodies differ,
   // so keeping them in different waves avoids executing both serially under divergence
-  if (threadIdx.x < 192) {
+  if (dbg_skip & 1) {
+    for (uint32_t q = threadIdx.x; q < nc * O1; q += blockDim.x) { r[q] = 1.0 / (1.0 + q); }
+  } else if (threadIdx.x < 192) {
     const uint32_t nchains = nc * order;
     for (uint32_t q = threadIdx.x; q < nchains; q += 192) {
       const uint32_t c = q / order, lag = 1 + (q - c * order);
@@ -193,7 +215,7 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
   __syncthreads();
 
   // ---- Levinson-Durbin, one thread per candidate ----------------------------------------------
-  for (uint32_t c = threadIdx.x; c < nc; c += blockDim.x) {
+  for (uint32_t c = threadIdx.x; c < nc && !(dbg_skip & 2); c += blockDim.x) {
     const uint32_t n = cd[c].len;
     const double* rc = r + c * O1;
     double* a = av + c * O2;
@@ -318,68 +340,136 @@ void k_lattice(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, ui
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_tail: long-term filter -> sign-log LMS -> folded sum.  The LMS is serial in time (every
-// sample updates all 2*ORDER coefficients from the error it just produced), so one lane walks
-// one (block, channel); parallelism is across blocks x channels.
+// k_tail: long-term filter -> sign-log LMS -> folded sum.  The LMS is serial in time (every sample
+// updates all 2*ORDER coefficients from the error it just produced), so parallelism inside one
+// (block, channel) exists only ACROSS THE TAPS: a group of G = 2*ORDER lanes owns one job, lane t holds
+// one coefficient and one history value (t < ORDER: input history, else prediction history).  Per
+// sample: one 32-bit product per lane, a log2(G)-step DPP sum (wrapping int adds are associative, so
+// the tree equals the reference's serial sum), the error/step computed redundantly by every lane, one
+// multiply-add coefficient update per lane and a one-lane DPP shift of the history.  Samples are
+// fetched G at a time (lane t loads and long-term-filters sample s0+t: coalesced), handed to the
+// group through ds_bpermute, and the G errors are stored back coalesced.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int32_t sgn(int32_t v) { return (v > 0) - (v < 0); }
+__device__ __forceinline__ int32_t sgn(int32_t v)          // clamp to [-1, 1] = sign, one v_med3_i32
+{
+  int32_t r;
+  asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(v));
+  return r;
+}
+
+// all lanes of the permutation are valid, so old = 0 / bound_ctrl lets the add absorb the DPP read
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t x)
+{
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, true);
+}
+
+template <int G>
+__device__ __forceinline__ uint32_t group_sum(uint32_t x)
+{
+  x += dpp_u32<0xB1>(x);                       // quad_perm [1,0,3,2]   lane ^ 1
+  x += dpp_u32<0x4E>(x);                       // quad_perm [2,3,0,1]   lane ^ 2
+  x += dpp_u32<0x141>(x);                      // row_half_mirror       other quad of the 8
+  if (G >= 16) { x += dpp_u32<0x140>(x); }     // row_mirror            other half of the 16
+  if (G >= 32) { x += (uint32_t)__shfl_xor((int)x, 16); }
+  if (G >= 64) { x += (uint32_t)__shfl_xor((int)x, 32); }
+  return x;
+}
+
+// G consecutive samples of one job group.  FIRST: this is the block that starts at sample 0, whose first
+// ORDER samples only prime both histories (src/SLAPredictor.c:1233-1255); u is a compile-time constant
+// after unrolling, so the priming steps cost nothing in the steady-state instantiation.
+template <int ORDER, bool FIRST>
+__device__ __forceinline__ int32_t tail_block(int32_t v_mine, uint32_t grp_base, bool is_fir_head, bool is_iir_head,
+                                              uint32_t t, int32_t& coef, int32_t& h)
+{
+  constexpr int G = 2 * ORDER;
+  int32_t e_mine = 0;
+#pragma unroll
+  for (int u = 0; u < G; u++) {
+    const int32_t v = __shfl(v_mine, (int)(grp_base + u));
+    int32_t e, ph;
+    if (FIRST && u < ORDER) {
+      e = v; ph = v;
+    } else {
+      const uint32_t sum = group_sum<G>((uint32_t)coef * (uint32_t)h) + (1u << 9);
+      const int32_t p = (int32_t)sum >> 10;
+      e = (int32_t)((uint32_t)v - (uint32_t)p);
+      const uint32_t mag = (uint32_t)max(e, (int32_t)(0u - (uint32_t)e));
+      const int32_t lg = 32 - (int32_t)__clz((int)mag);                    // ceil(log2(|e|+1)); __clz(0) = 32
+      const int32_t step = sgn(e) * (lg >> 1);                              // table src/SLAPredictor.c:123-144
+      coef += step * sgn(h);
+      ph = p;
+    }
+    // history: lane t takes lane t-1; the group's first FIR / IIR lane takes the new input / prediction
+    h = (int32_t)__builtin_amdgcn_update_dpp(h, h, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+    h = is_fir_head ? v : (is_iir_head ? ph : h);
+    e_mine = (t == (uint32_t)u) ? e : e_mine;
+  }
+  return e_mine;
+}
 
 template <int ORDER>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(256)
 void k_tail(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, uint64_t stride,
             const sla_hip_tail_job* __restrict__ jobs, uint32_t num_jobs, uint32_t ntaps,
             uint64_t* __restrict__ fold_sum)
 {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= num_jobs) { return; }
-  const sla_hip_tail_job job = jobs[j];
+  constexpr int G = 2 * ORDER;                 // lanes per job
+  constexpr int JPW = 64 / G;                  // jobs per wave
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t t = lane & (G - 1);
+  const uint32_t grp_base = lane - t;
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t j = wave * JPW + (lane / G);
+  const bool have = (j < num_jobs);
+  const sla_hip_tail_job job = jobs[have ? j : 0];
+  const uint32_t n = have ? job.blk_len : 0;
   const int32_t* in = res_in + (uint64_t)job.channel * stride + job.blk_off;
   int32_t* out = res_out + (uint64_t)job.channel * stride + job.blk_off;
-  const uint32_t n = job.blk_len;
   const uint32_t delay = job.pitch + (ntaps >> 1);
   const bool use_ltm = (job.pitch >= 3);
+  const bool short_job = (n < (uint32_t)ORDER);      // fewer samples than taps: everything passes through
+  const bool is_fir_head = (t == 0), is_iir_head = (t == (uint32_t)ORDER);
+  const uint32_t nmax = umax_wave(n);
 
-  int32_t cf[ORDER], ci[ORDER], hx[ORDER], hp[ORDER];   // hx[0] / hp[0] = most recent
-#pragma unroll
-  for (int i = 0; i < ORDER; i++) { cf[i] = 0; ci[i] = 0; hx[i] = 0; hp[i] = 0; }
+  // lane t fetches sample s0+t and applies the long-term stage to it   src/SLAPredictor.c:1063-1099
+  auto fetch = [&](uint32_t s) -> int32_t {
+    int32_t v = 0;
+    if (s < n) {
+      v = in[s];
+      if (use_ltm && s >= delay) {
+        int64_t acc = (int64_t)1 << 30;
+        for (uint32_t k = 0; k < ntaps; k++) { acc += (int64_t)job.ltm_coef[k] * (int64_t)in[s - delay + k]; }
+        v = (int32_t)((uint32_t)v - (uint32_t)(int32_t)(acc >> 31));
+      }
+    }
+    return v;
+  };
+
+  int32_t coef = 0, h = 0;
   uint64_t fsum = 0;
-
-  for (uint32_t s = 0; s < n; s++) {
-    // long-term stage: first `delay` samples pass through        src/SLAPredictor.c:1063-1099
-    int32_t v = in[s];
-    if (use_ltm && s >= delay) {
-      int64_t acc = (int64_t)1 << 30;
-      for (uint32_t t = 0; t < ntaps; t++) { acc += (int64_t)job.ltm_coef[t] * (int64_t)in[s - delay + t]; }
-      v = (int32_t)((uint32_t)v - (uint32_t)(int32_t)(acc >> 31));
+  int32_t v_next = fetch(t);
+  for (uint32_t s0 = 0; s0 < nmax; s0 += G) {
+    const int32_t v_mine = v_next;
+    v_next = fetch(s0 + G + t);                      // next block's samples travel while this one computes
+    int32_t e_mine = (s0 == 0) ? tail_block<ORDER, true>(v_mine, grp_base, is_fir_head, is_iir_head, t, coef, h)
+                               : tail_block<ORDER, false>(v_mine, grp_base, is_fir_head, is_iir_head, t, coef, h);
+    e_mine = short_job ? v_mine : e_mine;
+    const uint32_t s = s0 + t;
+    if (s < n) {
+      out[s] = e_mine;
+      fsum += (e_mine < 0) ? ~((uint32_t)e_mine << 1) : ((uint32_t)e_mine << 1);   // zig-zag fold, src/SLAUtility.h:37
     }
-    // LMS stage: first ORDER samples prime both histories         src/SLAPredictor.c:1233-1255
-    int32_t e = v, pred_hist = v;
-    if (n >= (uint32_t)ORDER && s >= (uint32_t)ORDER) {
-      uint32_t pred = 1u << 9;
-#pragma unroll
-      for (int i = 0; i < ORDER; i++) {
-        pred += (uint32_t)cf[i] * (uint32_t)hx[i];
-        pred += (uint32_t)ci[i] * (uint32_t)hp[i];
-      }
-      int32_t p = (int32_t)pred >> 10;
-      e = (int32_t)((uint32_t)v - (uint32_t)p);
-      uint32_t mag = (e > 0) ? (uint32_t)e : (0u - (uint32_t)e);
-      int32_t lg = mag ? (int32_t)(32 - __builtin_clz(mag)) : 0;        // ceil(log2(|e|+1))
-      int32_t step = sgn(e) * (lg >> 1);                                // ((lg<<4)>>5), table src/SLAPredictor.c:123-144
-#pragma unroll
-      for (int i = 0; i < ORDER; i++) {
-        cf[i] += step * sgn(hx[i]);
-        ci[i] += step * sgn(hp[i]);
-      }
-      pred_hist = p;
-    }
-#pragma unroll
-    for (int i = ORDER - 1; i >= 1; i--) { hx[i] = hx[i - 1]; hp[i] = hp[i - 1]; }
-    hx[0] = v; hp[0] = pred_hist;
-    out[s] = e;
-    fsum += (e < 0) ? ~((uint32_t)e << 1) : ((uint32_t)e << 1);          // zig-zag fold, src/SLAUtility.h:37
   }
-  fold_sum[j] = fsum;
+  // sum of the lanes' partial folded sums
+#pragma unroll
+  for (int off = 1; off < G; off <<= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)fsum, off);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(fsum >> 32), off);
+    fsum += ((uint64_t)hi << 32) | lo;
+  }
+  if (have && t == 0) { fold_sum[j] = fsum; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -545,7 +635,8 @@ extern "C" int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, u
   hipError_t e = hipFuncSetAttribute((const void*)k_lpc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { return hip_rc(e); }
   hipLaunchKernelGGL(k_lpc, dim3(num_groups), dim3(256), lds, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
-                     d_groups, d_cands, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)x_region);
+                     d_groups, d_cands, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)x_region,
+                     (uint32_t)(getenv("SLA_HIP_LPC_SKIP") ? atoi(getenv("SLA_HIP_LPC_SKIP")) : 0));
   return hip_rc(hipGetLastError());
 }
 
@@ -572,8 +663,10 @@ extern "C" int sla_hip_launch_tail(const int32_t* d_res_in, int32_t* d_res_out, 
 {
   if (d_res_in == nullptr || d_res_out == nullptr || d_jobs == nullptr || d_fold_sum == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (longterm_order > 5 || !(longterm_order & 1)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (!(lms_order == 4 || lms_order == 8 || lms_order == 16 || lms_order == 32)) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
   if (num_jobs == 0) { return 0; }
-  dim3 grid((num_jobs + 63) / 64), block(64);
+  const uint32_t jobs_per_block = 4 * (64 / (2 * lms_order));     // 4 waves, 64/(2*order) jobs per wave
+  dim3 grid((num_jobs + jobs_per_block - 1) / (jobs_per_block ? jobs_per_block : 1)), block(256);
   hipStream_t st = (hipStream_t)stream;
   switch (lms_order) {
     case 4:  hipLaunchKernelGGL(k_tail<4>,  grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum); break;
