@@ -120,11 +120,14 @@ int sla_hip_launch_lattice(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
                            const sla_hip_lattice_chunk* d_chunks, uint32_t num_chunks,
                            const int32_t* d_kint, int32_t* d_residual, sla_hip_stream_t stream);
 
-/* First `head` lags of the autocorrelation of each job's residual, computed exactly as the reference's
- * real-FFT route does (zero-padded to fft_size, forward, |.|^2, inverse).  d_twiddles holds the
+/* Autocorrelation of each job's residual, computed exactly as the reference's real-FFT route does
+ * (zero-padded to fft_size, forward, |.|^2, inverse).  head == SLA_HIP_ACF_RECORD: per job a 12-double
+ * record {code (0 silent, 1 ok, 2 no candidate), chosen pitch lag, acf[0..4], acf[chosen-2..chosen+2]}
+ * after the reference's peak scan (src/SLAPredictor.c:866-924); any other head: the first `head` lags.  d_twiddles holds the
  * 3*fft_size doubles produced by the host with the reference's recurrence (layout: sla_kernels.hip).
  * fft_size*8 bytes must fit SLA_HIP_LDS_BUDGET, otherwise d_scratch (scratch_slots x fft_size doubles
  * of device memory) is used as the work area. */
+#define SLA_HIP_ACF_RECORD 12u
 int sla_hip_launch_ltm_acf(const int32_t* d_residual, uint64_t plane_stride,
                            const sla_hip_acf_job* d_jobs, uint32_t num_jobs, uint32_t fft_size,
                            const double* d_twiddles, double* d_scratch, uint32_t scratch_slots,

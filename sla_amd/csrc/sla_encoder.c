@@ -43,6 +43,8 @@ typedef struct {
   int32_t  ltm_q[SLAI_MAX_TAPS];
 } blkch_t;
 
+struct slai_pool;
+
 struct SLAEncoder {
   struct SLAEncoderConfig   cfg;
   struct SLAWaveFormat      wave_format;
@@ -53,6 +55,7 @@ struct SLAEncoder {
   hipEvent_t  ev[12];
   slai_fft_plan* fft;
   uint32_t threads;
+  struct slai_pool* pool;
 
   /* device workspace */
   devbuf_t d_pcm, d_res1, d_res2, d_or, d_nz, d_groups, d_cands, d_lpc_out, d_code, d_kint, d_rshift,
@@ -121,29 +124,99 @@ static int pin_reserve(pinbuf_t* b, size_t bytes)
   return 0;
 }
 
-/* run fn(ctx, i) for i in [0,count) on the encoder's host threads */
-typedef struct { void (*fn)(void*, uint32_t); void* ctx; uint32_t count; volatile uint32_t next; } pfor_t;
-static void* pfor_worker(void* arg)
+/* Persistent host worker pool: run fn(ctx, i) for i in [0,count).  The scalar host stages between
+ * kernel launches (code-length logs + Dijkstra, long-term solve, block packing) are short, so paying
+ * pthread_create per stage would be a visible fraction of them. */
+struct slai_pool {
+  pthread_t tid[64];
+  uint32_t nworkers;                 /* threads besides the caller */
+  pthread_mutex_t mu;
+  pthread_cond_t cv_start, cv_done;
+  uint64_t generation;
+  int shutdown;
+  void (*fn)(void*, uint32_t);
+  void* ctx;
+  uint32_t count, grain;
+  volatile uint32_t next;
+  uint32_t busy;
+};
+
+static void pool_drain(struct slai_pool* p)
 {
-  pfor_t* p = (pfor_t*)arg;
   for (;;) {
-    uint32_t i = __atomic_fetch_add(&p->next, 1u, __ATOMIC_RELAXED);
-    if (i >= p->count) { break; }
-    p->fn(p->ctx, i);
+    uint32_t lo = __atomic_fetch_add(&p->next, p->grain, __ATOMIC_RELAXED), hi, i;
+    if (lo >= p->count) { break; }
+    hi = (p->count - lo < p->grain) ? p->count : lo + p->grain;
+    for (i = lo; i < hi; i++) { p->fn(p->ctx, i); }
   }
+}
+
+static void* pool_worker(void* arg)
+{
+  struct slai_pool* p = (struct slai_pool*)arg;
+  uint64_t seen = 0;
+  pthread_mutex_lock(&p->mu);
+  for (;;) {
+    while (!p->shutdown && p->generation == seen) { pthread_cond_wait(&p->cv_start, &p->mu); }
+    if (p->shutdown) { break; }
+    seen = p->generation;
+    pthread_mutex_unlock(&p->mu);
+    pool_drain(p);
+    pthread_mutex_lock(&p->mu);
+    if (--p->busy == 0) { pthread_cond_signal(&p->cv_done); }
+  }
+  pthread_mutex_unlock(&p->mu);
   return NULL;
 }
-static void parallel_for(uint32_t threads, uint32_t count, void (*fn)(void*, uint32_t), void* ctx)
+
+static struct slai_pool* pool_create(uint32_t threads)
 {
-  pfor_t p;
-  pthread_t tid[64];
-  uint32_t t, started = 0;
-  p.fn = fn; p.ctx = ctx; p.count = count; p.next = 0;
+  struct slai_pool* p = (struct slai_pool*)calloc(1, sizeof(*p));
+  uint32_t t;
+  if (p == NULL) { return NULL; }
+  pthread_mutex_init(&p->mu, NULL);
+  pthread_cond_init(&p->cv_start, NULL);
+  pthread_cond_init(&p->cv_done, NULL);
   if (threads > 64) { threads = 64; }
-  if (threads > count) { threads = count; }
-  for (t = 1; t < threads; t++) { if (pthread_create(&tid[started], NULL, pfor_worker, &p) == 0) { started++; } }
-  pfor_worker(&p);
-  for (t = 0; t < started; t++) { pthread_join(tid[t], NULL); }
+  for (t = 1; t < threads; t++) {
+    if (pthread_create(&p->tid[p->nworkers], NULL, pool_worker, p) == 0) { p->nworkers++; }
+  }
+  return p;
+}
+
+static void pool_destroy(struct slai_pool* p)
+{
+  uint32_t t;
+  if (p == NULL) { return; }
+  pthread_mutex_lock(&p->mu);
+  p->shutdown = 1;
+  pthread_cond_broadcast(&p->cv_start);
+  pthread_mutex_unlock(&p->mu);
+  for (t = 0; t < p->nworkers; t++) { pthread_join(p->tid[t], NULL); }
+  pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_start); pthread_cond_destroy(&p->cv_done);
+  free(p);
+}
+
+static void parallel_for(struct slai_pool* p, uint32_t count, void (*fn)(void*, uint32_t), void* ctx)
+{
+  uint32_t i;
+  if (count == 0) { return; }
+  if (p == NULL || p->nworkers == 0 || count < 4) {
+    for (i = 0; i < count; i++) { fn(ctx, i); }
+    return;
+  }
+  pthread_mutex_lock(&p->mu);
+  p->fn = fn; p->ctx = ctx; p->count = count; p->next = 0;
+  p->grain = count / ((p->nworkers + 1) * 8);
+  if (p->grain == 0) { p->grain = 1; }
+  p->busy = p->nworkers;
+  p->generation++;
+  pthread_cond_broadcast(&p->cv_start);
+  pthread_mutex_unlock(&p->mu);
+  pool_drain(p);
+  pthread_mutex_lock(&p->mu);
+  while (p->busy != 0) { pthread_cond_wait(&p->cv_done, &p->mu); }
+  pthread_mutex_unlock(&p->mu);
 }
 
 /* ------------------------------------------------------------- create / destroy */
@@ -185,6 +258,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   if (e->threads > 32) { e->threads = 32; }
   env = getenv("SLA_HIP_THREADS");
   if (env != NULL && atoi(env) > 0) { e->threads = (uint32_t)atoi(env); }
+  e->pool = pool_create(e->threads);
   e->win_type = (SLAWindowFunctionType)-1;
   return e;
 }
@@ -209,6 +283,7 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   for (i = 0; i < 12; i++) { (void)hipEventDestroy(e->ev[i]); }
   (void)hipStreamDestroy(e->stream);
   slai_fft_plan_destroy(e->fft);
+  pool_destroy(e->pool);
   free(e->win_host); free(e->win_len); free(e->win_off);
   free(e->blk); free(e->bc); free(e->parcor); free(e->code); free(e->kint);
   free(e);
@@ -525,7 +600,7 @@ static int stage_plan(struct SLAEncoder* e)
     for (i = 0; i < nsf; i++) { if (sf[i].shape != 0xFFFFFFFFu) { live[nlive] = i; lsf[nlive] = sf[i]; nlive++; } }
     ctx.e = e; ctx.sf = lsf; ctx.shapes = shapes; ctx.cands = cands; ctx.out = (const double*)e->h_lpc_out.ptr;
     ctx.parts = parts; ctx.nparts = nparts; ctx.status = status;
-    parallel_for(e->threads, nlive, plan_one, &ctx);
+    parallel_for(e->pool, nlive, plan_one, &ctx);
     j = 0;
     for (i = 0; i < nsf && rc == 0; i++) {
       if (sf[i].shape == 0xFFFFFFFFu) {
@@ -553,7 +628,7 @@ static int stage_plan(struct SLAEncoder* e)
 
 typedef struct {
   struct SLAEncoder* e;
-  const double* acf;           /* [ngroups][SLAI_LTM_ACF_HEAD] autocorrelation heads from k_ltm_acf */
+  const double* acf;           /* [ngroups][SLAI_LTM_ACF_HEAD] compact autocorrelation records from k_ltm_acf */
   const uint32_t* job_blk; const uint32_t* job_ch; const uint32_t* job_grp;
 } ltm_ctx_t;
 
@@ -761,7 +836,7 @@ static int stage_blocks(struct SLAEncoder* e)
   {
     ltm_ctx_t lc;
     lc.e = e; lc.acf = (const double*)e->h_acf.ptr; lc.job_blk = job_blk; lc.job_ch = job_ch; lc.job_grp = job_grp;
-    parallel_for(e->threads, njobs, ltm_one, &lc);
+    parallel_for(e->pool, njobs, ltm_one, &lc);
   }
   e->timing[6] = (float)(now_ms() - t0);
 
@@ -947,7 +1022,7 @@ static int pack_impl(struct SLAEncoder* e, const int32_t* const* host_pcm, uint8
   ctx.bufs = (uint8_t**)calloc(e->num_blocks + 1, sizeof(uint8_t*));
   ctx.sizes = (uint32_t*)calloc(e->num_blocks + 1, sizeof(uint32_t));
   if (ctx.bufs == NULL || ctx.sizes == NULL) { free(ctx.bufs); free(ctx.sizes); return SLA_APIRESULT_NG; }
-  parallel_for(e->threads, e->num_blocks, pack_one, &ctx);
+  parallel_for(e->pool, e->num_blocks, pack_one, &ctx);
 
   for (b = 0; b < e->num_blocks; b++) {
     uint32_t bps_blk;

@@ -53,9 +53,9 @@ slai_fft_plan* slai_fft_plan_create(uint32_t fft_size);
 void           slai_fft_plan_destroy(slai_fft_plan* plan);
 uint32_t       slai_fft_plan_size(const slai_fft_plan* plan);
 void           slai_fft_plan_export(const slai_fft_plan* plan, double* out /* 3*fft_size doubles */);
-/* pitch + Q31 taps from the autocorrelation head; returns 0 ok, 4 analysis failed */
-int  slai_ltm_solve(const double* acf, uint32_t ntaps, uint32_t* pitch, double* coef);
-#define SLAI_LTM_ACF_HEAD (SLAI_LTM_MAX_PERIOD + 8)
+/* pitch + taps from the device's compact autocorrelation record; returns 0 ok, 4 analysis failed */
+int  slai_ltm_solve(const double* rec, uint32_t ntaps, uint32_t* pitch, double* coef);
+#define SLAI_LTM_ACF_HEAD SLA_HIP_ACF_RECORD
 
 /* ---- sla_pack.c: bit-serial block writer ---------------------------------- */
 typedef struct slai_block_params {

@@ -528,6 +528,41 @@ __device__ __forceinline__ void acf_real_pass(double* d, uint32_t F, double c2, 
   }
 }
 
+// Pitch candidate from the autocorrelation, a one-pass restatement of the reference's nested scans
+// (src/SLAPredictor.c:866-924): segments run from an upward zero crossing to the next downward one
+// (inclusive, capped at lag 256; a search that reaches 256 inspects lags 256 and 257), each segment
+// contributes its largest strict local maximum, and the earliest of the globally largest wins.
+// Every element is read once and the read address never depends on the scan state.
+__device__ __forceinline__ void acf_pick(const double* d, uint32_t& chosen, uint32_t& ncand)
+{
+  double top = 0.0, val = 0.0, prev = d[0], cur = d[1];
+  uint32_t start = 0, arg = 0;
+  bool in_seg = false, done = false;
+  chosen = 0; ncand = 0;
+  for (uint32_t j = 1; j <= 257 && !done; j++) {
+    const double next = d[j + 1];
+    if (!in_seg) {
+      if (j < 256) {
+        if (prev < 0.0 && cur > 0.0) { in_seg = true; start = j; arg = 0; val = 0.0; }
+      } else {
+        in_seg = true; start = 256; arg = 0; val = 0.0;
+      }
+    }
+    if (in_seg) {
+      if (cur > prev && cur > next && cur > val) { arg = j; val = cur; }
+      bool is_end;
+      if (start == 256) { is_end = (j == 257); }
+      else { is_end = (j >= start + 1) && ((j < 256) ? (cur > 0.0 && next < 0.0) : true); }
+      if (is_end) {
+        if (arg != 0) { ncand++; if (val > top) { top = val; chosen = arg; } }
+        in_seg = false;
+        if (j + 1 >= 256) { done = true; }
+      }
+    }
+    prev = cur; cur = next;
+  }
+}
+
 template <bool IN_LDS>
 __global__ __launch_bounds__(ACF_THREADS)
 void k_ltm_acf(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_acf_job* __restrict__ jobs,
@@ -588,7 +623,24 @@ void k_ltm_acf(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_a
     }
     __syncthreads();
     acf_stages(d, log2npts, twr_i, twi_i);
-    for (uint32_t t = threadIdx.x; t < head; t += ACF_THREADS) { out[(uint64_t)job * head + t] = d[t]; }
+    if (head == SLA_HIP_ACF_RECORD) {
+      // compact record: {code, chosen lag, acf[0..4], acf[chosen-2..chosen+2]}; the Toeplitz solve (x87
+      // long double in the reference) is left to the host
+      if (threadIdx.x == 0) {
+        double* o = out + (uint64_t)job * SLA_HIP_ACF_RECORD;
+        uint32_t chosen = 0, ncand = 0;
+        double code = 0.0;                                   // 0: silent block
+        if (fabs(d[0]) > (double)FLT_MIN) {
+          acf_pick(d, chosen, ncand);
+          code = (ncand == 0) ? 2.0 : 1.0;                   // 2: no pitch candidate
+        }
+        o[0] = code; o[1] = (double)chosen;
+        for (uint32_t k = 0; k < 5; k++) { o[2 + k] = d[k]; }
+        for (uint32_t k = 0; k < 5; k++) { o[7 + k] = (chosen + k >= 2) ? d[chosen + k - 2] : 0.0; }
+      }
+    } else {
+      for (uint32_t t = threadIdx.x; t < head; t += ACF_THREADS) { out[(uint64_t)job * head + t] = d[t]; }
+    }
     __syncthreads();
   }
 }

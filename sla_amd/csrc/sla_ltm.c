@@ -9,8 +9,8 @@
  * the same recurrence in host double arithmetic (slai_fft_plan); the
  * butterflies then only multiply/add doubles in a fixed order.
  *
- * The peak picking and the tiny Toeplitz solve (x87 long double residual,
- * src/SLAUtility.c:627-657) stay on the host: a few hundred flops per block.
+ * Only the tiny Toeplitz solve (x87 long double residual, src/SLAUtility.c:627-657)
+ * stays on the host: a few hundred flops per block; the peak scan runs in k_ltm_acf.
  */
 #include "sla_internal.h"
 
@@ -196,52 +196,34 @@ static int toeplitz_solve(const double R[NT][NT], double* b, uint32_t dim, uint3
   return 0;
 }
 
-/* pitch = first local maximum between zero crossings that reaches the global maximum of those
- * maxima; taps = Wiener solution around it (reference src/SLAPredictor.c:855-979).
- * `acf` holds at least SLAI_LTM_ACF_HEAD lags. */
-int slai_ltm_solve(const double* acf, uint32_t ntaps, uint32_t* pitch, double* coef)
+/* Long-term taps from the device's compact record {code, chosen lag, acf[0..4], acf[chosen-2..chosen+2]}
+ * (k_ltm_acf did the FFT autocorrelation and the peak scan): range check, Wiener solution around the
+ * chosen lag, stability fallback (reference src/SLAPredictor.c:855-863, 913-979).
+ * Returns 0 ok, 4 analysis failed (SLAPREDICTOR_APIRESULT_FAILED_TO_CALCULATION). */
+int slai_ltm_solve(const double* rec, uint32_t ntaps, uint32_t* pitch, double* coef)
 {
-  uint32_t cand[SLAI_LTM_MAX_PERIOD], ncand = 0, i, chosen;
-  double top = 0.0;
-  if (fabs(acf[0]) <= FLT_MIN) {
+  const double* low = rec + 2;            /* acf[0..4]                 */
+  const double* mid = rec + 7;            /* acf[chosen-2..chosen+2]   */
+  const uint32_t chosen = (uint32_t)rec[1];
+  double R[NT][NT], vec[NT], mag = 0.0;
+  uint32_t j, k;
+  if (rec[0] == 0.0) {
     *pitch = 0;
-    for (i = 0; i < ntaps; i++) { coef[i] = 0.0; }
+    for (j = 0; j < ntaps; j++) { coef[j] = 0.0; }
     return 0;
   }
-  i = 1;
-  while (i < SLAI_LTM_MAX_PERIOD && ncand < SLAI_LTM_MAX_PERIOD) {
-    uint32_t up, down, j, arg = 0;
-    double val = 0.0;
-    for (up = i; up < SLAI_LTM_MAX_PERIOD; up++) { if (acf[up - 1] < 0.0 && acf[up] > 0.0) { break; } }
-    for (down = up + 1; down < SLAI_LTM_MAX_PERIOD; down++) { if (acf[down] > 0.0 && acf[down + 1] < 0.0) { break; } }
-    for (j = up; j <= down; j++) {
-      if (acf[j] > acf[j - 1] && acf[j] > acf[j + 1] && acf[j] > val) { arg = j; val = acf[j]; }
-    }
-    if (arg != 0) {
-      cand[ncand++] = arg;
-      if (val > top) { top = val; }
-    }
-    i = down + 1;
-  }
-  if (ncand == 0) { return 4; }
-  for (i = 0; i < ncand; i++) { if (acf[cand[i]] >= 1.0f * top) { break; } }
-  if (i == ncand) { return 4; }
-  chosen = cand[i];
+  if (rec[0] != 1.0) { return 4; }
   if (chosen < ntaps / 2 + 1) { return 4; }
-  {
-    double R[NT][NT], vec[NT], mag = 0.0;
-    uint32_t j, k;
-    memset(R, 0, sizeof(R));
-    for (j = 0; j < ntaps; j++) { for (k = 0; k < ntaps; k++) { R[j][k] = acf[(j >= k) ? (j - k) : (k - j)]; } }
-    for (j = 0; j < ntaps; j++) { vec[j] = acf[j + chosen - ntaps / 2]; }
-    if (toeplitz_solve((const double (*)[NT])R, vec, ntaps, 2) != 0) { return 4; }
-    for (j = 0; j < ntaps; j++) { mag += fabs(vec[j]); }
-    if (mag >= 1.0) {
-      for (j = 0; j < ntaps; j++) { vec[j] = 0.0; }
-      vec[ntaps / 2] = acf[chosen] / acf[0];
-    }
-    *pitch = chosen;
-    for (j = 0; j < ntaps; j++) { coef[j] = vec[j]; }
+  memset(R, 0, sizeof(R));
+  for (j = 0; j < ntaps; j++) { for (k = 0; k < ntaps; k++) { R[j][k] = low[(j >= k) ? (j - k) : (k - j)]; } }
+  for (j = 0; j < ntaps; j++) { vec[j] = mid[2 + j - ntaps / 2]; }
+  if (toeplitz_solve((const double (*)[NT])R, vec, ntaps, 2) != 0) { return 4; }
+  for (j = 0; j < ntaps; j++) { mag += fabs(vec[j]); }
+  if (mag >= 1.0) {
+    for (j = 0; j < ntaps; j++) { vec[j] = 0.0; }
+    vec[ntaps / 2] = mid[2] / low[0];
   }
+  *pitch = chosen;
+  for (j = 0; j < ntaps; j++) { coef[j] = vec[j]; }
   return 0;
 }

@@ -142,24 +142,38 @@ def test_zero_run_helpers(L):
 
 @pytest.mark.parametrize("ntaps", [1, 3, 5])
 def test_longterm_solve(L, oracle, ntaps):
-    """pitch picking + Toeplitz solve from an autocorrelation head (the FFT itself runs on the GPU)"""
+    """Toeplitz solve + stability fallback from the compact record the FFT kernel hands back
+    (the FFT and the peak scan run on the GPU and are covered by the -m gpu tests)"""
     L.slai_ltm_solve.argtypes = [f64p, C.c_uint32, u32p, f64p]
     rng = np.random.default_rng(ntaps)
     cases = [W.gen(nm, 1, 4096, 16, seed=11)[0] >> 18 for nm in W.NAMES]
     base = rng.integers(-2000, 2000, 97)
     cases.append((np.tile(base, 50)[:4096] + rng.integers(-50, 50, 4096)).astype(np.int32))
     cases.append((np.tile(base[:2], 2048) * 3).astype(np.int32))
+    checked = 0
     for fft in (8192, 32768):
         for res in cases:
             ret, pitch, coef, ac = oracle.ltm_analyze(np.ascontiguousarray(res, np.int32), fft, ntaps, want_autocorr=True)
-            head = np.ascontiguousarray(ac[:264])
+            if ret != 0:
+                continue
+            rec = np.zeros(12)
+            if abs(ac[0]) <= np.finfo(np.float32).tiny:
+                rec[0] = 0.0
+            else:
+                rec[0], rec[1] = 1.0, float(pitch)
+                rec[2:7] = ac[:5]
+                rec[7:12] = [ac[pitch + k - 2] if pitch + k >= 2 else 0.0 for k in range(5)]
             got_pitch = C.c_uint32(0)
             got = np.zeros(5)
-            r2 = L.slai_ltm_solve(ptr(head, f64p), ntaps, C.byref(got_pitch), ptr(got, f64p))
-            assert r2 == ret
-            if ret == 0:
-                assert got_pitch.value == pitch
-                assert np.array_equal(got[:ntaps].view(np.uint64), coef.view(np.uint64))
+            assert L.slai_ltm_solve(ptr(rec, f64p), ntaps, C.byref(got_pitch), ptr(got, f64p)) == 0
+            assert got_pitch.value == pitch
+            assert np.array_equal(got[:ntaps].view(np.uint64), coef.view(np.uint64))
+            checked += 1
+    assert checked >= 4
+    rec = np.zeros(12); rec[0] = 2.0
+    assert L.slai_ltm_solve(ptr(rec, f64p), ntaps, C.byref(C.c_uint32(0)), ptr(np.zeros(5), f64p)) == 4
+    rec[0], rec[1] = 1.0, float(ntaps // 2)            # chosen lag too close to the origin
+    assert L.slai_ltm_solve(ptr(rec, f64p), ntaps, C.byref(C.c_uint32(0)), ptr(np.zeros(5), f64p)) == 4
 
 
 def test_fft_twiddle_tables(L, oracle):
