@@ -138,6 +138,15 @@ def main():
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                            "traffic": None, "kernel_ms": round(float(kern[dom]), 4),
                            "algorithmic_bytes_per_launch": algo_bytes}
+        # HBM traffic per launch of that kernel from the committed rocprofv3 --pmc passes (same config only)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.config.lower())))
+            key = KERNEL_NAMES[dom].split(" ")[0]
+            if args.seconds is None:
+                out["roofline"]["traffic"] = pmc["bytes_per_launch"][key]["total"]
+                out["roofline"]["traffic_source"] = pmc["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         out["stage_ms"] = {"k_prepass": round(float(kernel_ms[0]), 4), "k_lpc_search": round(float(kernel_ms[1]), 4),
                            "k_lpc_blocks": round(float(kernel_ms[2]), 4), "k_lattice": round(float(kernel_ms[3]), 4),
                            "k_tail": round(float(kernel_ms[4]), 4), "k_ltm_acf": round(float(kernel_ms[8]), 4), "host_plan": round(float(kernel_ms[5]), 4),

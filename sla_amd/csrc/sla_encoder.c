@@ -51,18 +51,20 @@ struct SLAEncoder {
   struct SLAEncodeParameter encode_param;
   uint32_t status_flag;
   int      device;
-  hipStream_t stream;
-  hipEvent_t  ev[12];
+  hipStream_t stream, stream2, stream3;
+  hipEvent_t  ev[2 + 8 * 12];       /* prepass pair + MAX_CHUNKS x EV_PER_CHUNK */
+  uint32_t chunks;
   slai_fft_plan* fft;
   uint32_t threads;
   struct slai_pool* pool;
 
   /* device workspace */
   devbuf_t d_pcm, d_res1, d_res2, d_or, d_nz, d_groups, d_cands, d_lpc_out, d_code, d_kint, d_rshift,
-           d_winpool, d_chunks, d_jobs, d_fold, d_acf_jobs, d_acf, d_acf_scratch, d_twiddle;
+           d_winpool, d_chunks, d_jobs, d_fold, d_acf_jobs, d_acf, d_acf_scratch, d_twiddle, d_bgroups, d_bcands, d_blk_out;
   int twiddle_ready;
   /* pinned host staging */
-  pinbuf_t h_nz, h_groups, h_cands, h_lpc_out, h_code, h_kint, h_rshift, h_chunks, h_jobs, h_fold, h_res, h_pcm, h_acf_jobs, h_acf;
+  pinbuf_t h_nz, h_groups, h_cands, h_lpc_out, h_code, h_kint, h_rshift, h_chunks, h_jobs, h_fold, h_res, h_pcm, h_acf_jobs, h_acf,
+           h_bgroups, h_bcands, h_blk_out;
   uint32_t* h_or;
 
   /* window pool: tables for every block length seen so far */
@@ -244,8 +246,13 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   if (hipGetDeviceProperties(&prop, e->device) == hipSuccess) {
     snprintf(g_device_name, sizeof(g_device_name), "%s (%s)", prop.name, prop.gcnArchName);
   }
-  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { free(e); return NULL; }
-  for (i = 0; i < 12; i++) { if (hipEventCreate(&e->ev[i]) != hipSuccess) { free(e); return NULL; } }
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess
+      || hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess
+      || hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess) { free(e); return NULL; }
+  for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { if (hipEventCreate(&e->ev[i]) != hipSuccess) { free(e); return NULL; } }
+  e->chunks = 2;
+  env = getenv("SLA_HIP_CHUNKS");
+  if (env != NULL && atoi(env) > 0) { e->chunks = (uint32_t)atoi(env); }
   if (hipHostMalloc((void**)&e->h_or, 64, hipHostMallocDefault) != hipSuccess) { free(e); return NULL; }
   {
     uint32_t fft = 1;
@@ -265,23 +272,24 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
 
 void SLAEncoder_Destroy(struct SLAEncoder* e)
 {
-  devbuf_t* d[19];
-  pinbuf_t* h[14];
+  devbuf_t* d[22];
+  pinbuf_t* h[17];
   int i;
   if (e == NULL) { return; }
-  (void)hipStreamSynchronize(e->stream);
+  (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3);
   d[0] = &e->d_pcm; d[1] = &e->d_res1; d[2] = &e->d_res2; d[3] = &e->d_or; d[4] = &e->d_nz; d[5] = &e->d_groups;
   d[6] = &e->d_cands; d[7] = &e->d_lpc_out; d[8] = &e->d_code; d[9] = &e->d_kint; d[10] = &e->d_rshift;
   d[11] = &e->d_winpool; d[12] = &e->d_chunks; d[13] = &e->d_jobs; d[14] = &e->d_fold;
   d[15] = &e->d_acf_jobs; d[16] = &e->d_acf; d[17] = &e->d_acf_scratch; d[18] = &e->d_twiddle;
-  for (i = 0; i < 19; i++) { if (d[i]->ptr != NULL) { (void)hipFree(d[i]->ptr); } }
+  d[19] = &e->d_bgroups; d[20] = &e->d_bcands; d[21] = &e->d_blk_out;
+  for (i = 0; i < 22; i++) { if (d[i]->ptr != NULL) { (void)hipFree(d[i]->ptr); } }
   h[0] = &e->h_nz; h[1] = &e->h_groups; h[2] = &e->h_cands; h[3] = &e->h_lpc_out; h[4] = &e->h_code; h[5] = &e->h_kint;
   h[6] = &e->h_rshift; h[7] = &e->h_chunks; h[8] = &e->h_jobs; h[9] = &e->h_fold; h[10] = &e->h_res; h[11] = &e->h_pcm;
-  h[12] = &e->h_acf_jobs; h[13] = &e->h_acf;
-  for (i = 0; i < 14; i++) { if (h[i]->ptr != NULL) { (void)hipHostFree(h[i]->ptr); } }
+  h[12] = &e->h_acf_jobs; h[13] = &e->h_acf; h[14] = &e->h_bgroups; h[15] = &e->h_bcands; h[16] = &e->h_blk_out;
+  for (i = 0; i < 17; i++) { if (h[i]->ptr != NULL) { (void)hipHostFree(h[i]->ptr); } }
   if (e->h_or != NULL) { (void)hipHostFree(e->h_or); }
-  for (i = 0; i < 12; i++) { (void)hipEventDestroy(e->ev[i]); }
-  (void)hipStreamDestroy(e->stream);
+  for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { (void)hipEventDestroy(e->ev[i]); }
+  (void)hipStreamDestroy(e->stream); (void)hipStreamDestroy(e->stream2); (void)hipStreamDestroy(e->stream3);
   slai_fft_plan_destroy(e->fft);
   pool_destroy(e->pool);
   free(e->win_host); free(e->win_len); free(e->win_off);
@@ -360,30 +368,68 @@ static int blocks_push(struct SLAEncoder* e, uint32_t start, uint32_t nsmpl, uin
   return 0;
 }
 
-/* ------------------------------------------------------------ stage 1: planning */
+/* ---------------------------------------------------------------- analysis pipeline
+ *
+ * The file is cut into up to MAX_CHUNKS runs of super-frames that travel through three stages
+ *   search : k_lpc over every partition candidate           (stream 1)  -> host: log2 costs + Dijkstra
+ *   blocks : k_lpc(windowed)+quantiser, k_lattice, k_ltm_acf (stream 2)  -> host: RAW test + Toeplitz solve
+ *   tail   : k_tail                                          (stream 3)  -> Rice initial parameters
+ * one chunk behind each other, so the host's scalar work on chunk c overlaps kernels of chunks c+1.. and
+ * kernels of different stages co-run on the device (k_lpc is LDS-occupancy bound, k_tail/k_lattice use no LDS).
+ * All buffers are sized for the whole file before the first launch: nothing is reallocated in flight. */
 
-typedef struct { uint32_t start, window, min_blk, shape, slot_base; } sframe_t;
+#define MAX_CHUNKS 8
+enum { EV_SEARCH_S, EV_SEARCH_E, EV_SEARCH_DONE, EV_LPCB_S, EV_LPCB_E, EV_LAT_E, EV_ACF_S, EV_ACF_E, EV_BLOCK_DONE,
+       EV_TAIL_S, EV_TAIL_E, EV_TAIL_DONE, EV_PER_CHUNK };
+
+typedef struct { uint32_t start, window, min_blk, shape, slot_base, grp_lo, grp_hi; } sframe_t;
 typedef struct { uint32_t window, min_blk, nodes, ncand, cand_first; uint32_t pair[SLAI_MAX_NODES * SLAI_MAX_NODES]; } shape_t;
 
 typedef struct {
+  uint32_t sf_lo, sf_hi;          /* super-frames of this chunk                                  */
+  uint32_t grp_lo, grp_hi;        /* search work-groups                                          */
+  uint32_t slot_lo, slot_hi;      /* search output slots                                         */
+  uint32_t blk_lo, blk_hi;        /* blocks the plan produced                                    */
+  uint32_t bg_lo, bg_hi;          /* (non-silent block, channel) groups = k_lpc groups = acf jobs */
+  uint32_t lc_lo, lc_hi;          /* lattice chunks                                              */
+  uint32_t job_lo, job_hi;        /* tail jobs                                                   */
+} chunk_t;
+
+typedef struct {
+  sframe_t* sf; uint32_t nsf;
+  shape_t* shapes; uint32_t nshapes;
+  uint32_t ncands, nsgroups, nslots, max_window, max_cpg;
+  uint32_t blocks_bound, lchunks_bound;
+  uint32_t nbg, nlc, njobs;                       /* running counters of the block stage */
+  uint32_t *job_blk, *job_ch, *job_grp, *grp_of_slot;
+  uint32_t *parts, *nparts; int* status;          /* per super-frame plan results        */
+  chunk_t ck[MAX_CHUNKS]; uint32_t nchunks;
+  hipEvent_t* ev;                                 /* [nchunks][EV_PER_CHUNK]             */
+} actx_t;
+
+typedef struct {
   struct SLAEncoder* e;
-  const sframe_t* sf; const shape_t* shapes; const sla_hip_lpc_cand* cands; const double* out;
-  uint32_t* parts;       /* [nsf][SLAI_MAX_NODES] */
-  uint32_t* nparts;      /* [nsf] */
-  int*      status;
+  const actx_t* a;
+  uint32_t sf_lo;
+  const sla_hip_lpc_cand* cands; const double* out;
 } plan_ctx_t;
 
 /* host part of the partition search for one super-frame: edge costs from the device's
  * (r0, PARCOR) per candidate, then the shortest path (reference src/SLAPredictor.c:1615-1692) */
-static void plan_one(void* vctx, uint32_t idx)
+static void plan_one(void* vctx, uint32_t rel)
 {
   plan_ctx_t* c = (plan_ctx_t*)vctx;
   const struct SLAEncoder* e = c->e;
-  const sframe_t* sf = &c->sf[idx];
-  const shape_t* sh = &c->shapes[sf->shape];
+  const actx_t* a = c->a;
+  const uint32_t idx = c->sf_lo + rel;
+  const sframe_t* sf = &a->sf[idx];
   const uint32_t C = e->wave_format.num_channels, order = e->encode_param.parcor_order, O2 = order + 2;
   double adj[SLAI_MAX_NODES * SLAI_MAX_NODES];
   uint32_t path[SLAI_MAX_NODES], i, j, ch, count, node;
+  const shape_t* sh;
+  a->status[idx] = 0; a->nparts[idx] = 0;
+  if (sf->shape == 0xFFFFFFFFu) { return; }
+  sh = &a->shapes[sf->shape];
   for (i = 0; i < sh->nodes; i++) {
     for (j = 0; j < sh->nodes; j++) {
       const uint32_t k = sh->pair[i * sh->nodes + j];
@@ -400,39 +446,70 @@ static void plan_one(void* vctx, uint32_t idx)
       adj[i * sh->nodes + j] = est;
     }
   }
-  if (slai_shortest_path(adj, sh->nodes, path) != 0) { c->status[idx] = SLA_APIRESULT_FAILED_TO_CALCULATE_COEF; return; }
+  if (slai_shortest_path(adj, sh->nodes, path) != 0) { a->status[idx] = SLA_APIRESULT_FAILED_TO_CALCULATE_COEF; return; }
   count = 0;
   for (node = sh->nodes - 1; node != 0; node = path[node]) {
-    if (path[node] >= node) { c->status[idx] = SLA_APIRESULT_FAILED_TO_CALCULATE_COEF; return; }
+    if (path[node] >= node) { a->status[idx] = SLA_APIRESULT_FAILED_TO_CALCULATE_COEF; return; }
     count++;
   }
   node = sh->nodes - 1;
   for (i = 0; i < count; i++) {
     uint32_t off = path[node] * SLAI_SEARCH_DELTA, len = (node - path[node]) * SLAI_SEARCH_DELTA;
     if (len > sf->window - off) { len = sf->window - off; }
-    c->parts[(size_t)idx * SLAI_MAX_NODES + (count - i - 1)] = len;
+    a->parts[(size_t)idx * SLAI_MAX_NODES + (count - i - 1)] = len;
     node = path[node];
   }
-  c->nparts[idx] = count;
-  c->status[idx] = 0;
+  a->nparts[idx] = count;
 }
 
-static int stage_plan(struct SLAEncoder* e)
+typedef struct {
+  struct SLAEncoder* e;
+  const double* acf;           /* [groups][SLAI_LTM_ACF_HEAD] compact autocorrelation records from k_ltm_acf */
+  const uint32_t* job_blk; const uint32_t* job_ch; const uint32_t* job_grp;
+  uint32_t job_lo;
+} ltm_ctx_t;
+
+/* pitch + taps of one (block, channel) from the device's autocorrelation record */
+static void ltm_one(void* vctx, uint32_t rel)
+{
+  ltm_ctx_t* c = (ltm_ctx_t*)vctx;
+  struct SLAEncoder* e = c->e;
+  const uint32_t j = c->job_lo + rel;
+  const uint32_t C = e->wave_format.num_channels, ntaps = e->encode_param.longterm_order;
+  blkch_t* bc = &e->bc[(size_t)c->job_blk[j] * C + c->job_ch[j]];
+  double coef[SLAI_MAX_TAPS] = {0, 0, 0, 0, 0};
+  uint32_t t;
+  const int ret = slai_ltm_solve(c->acf + (size_t)c->job_grp[j] * SLAI_LTM_ACF_HEAD, ntaps, &bc->pitch, coef);
+  if (ret != 0 || bc->pitch >= SLAI_LTM_MAX_PERIOD) { bc->pitch = 0; }      /* src/SLAEncoder.c:629-632 */
+  for (t = 0; t < ntaps; t++) {
+    /* Round(coef * 2^15) << 16, x86 conversion semantics       src/SLAEncoder.c:635-640 */
+    const double v = coef[t] * 32768.0;
+    const double rv = (v >= 0.0) ? floor(v + 0.5) : -floor(-v + 0.5);
+    const int32_t q = (!(rv > -2147483649.0 && rv < 2147483648.0)) ? INT32_MIN : (int32_t)rv;
+    bc->ltm_q[t] = (int32_t)((uint32_t)q << 16);
+  }
+}
+
+static void actx_free(actx_t* a)
+{
+  free(a->sf); free(a->shapes); free(a->job_blk); free(a->job_ch); free(a->job_grp); free(a->grp_of_slot);
+  free(a->parts); free(a->nparts); free(a->status);
+}
+
+/* prepass + whole-file tables: offset_lshift, super-frames, candidate shapes, search groups */
+static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
 {
   const uint32_t C = e->wave_format.num_channels, bps = e->wave_format.bit_per_sample;
-  const uint32_t order = e->encode_param.parcor_order, O1 = order + 1, O2 = order + 2;
+  const uint32_t order = e->encode_param.parcor_order, O1 = order + 1;
   const uint32_t ms = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
   const uint32_t n = e->num_samples, maxb = e->encode_param.max_num_block_samples;
   const uint64_t nwords = ((uint64_t)n + 63) / 64;
-  sframe_t* sf = NULL; uint32_t nsf = 0, sf_cap = 0;
-  shape_t* shapes = NULL; uint32_t nshapes = 0;
+  extern uint32_t sla_hip_lattice_chunk_samples(uint32_t order);
+  const uint32_t chunk_samples = sla_hip_lattice_chunk_samples(order);
   sla_hip_lpc_cand* cands; sla_hip_lpc_group* groups;
-  uint32_t ncands = 0, ngroups = 0, nslots = 0, max_cpg = 1, pos, i, j;
+  uint32_t sf_cap = 0, shapes_cap = 8, pos, i;
   const uint64_t* nz;
-  double t0;
-  int rc = 0;
 
-  /* ---- prepass --------------------------------------------------------------- */
   RCCHK(dev_reserve(&e->d_or, 64));
   RCCHK(dev_reserve(&e->d_nz, (size_t)(nwords + 2) * 8));
   RCCHK(pin_reserve(&e->h_nz, (size_t)(nwords + 2) * 8));
@@ -453,430 +530,545 @@ static int stage_plan(struct SLAEncoder* e)
       const uint32_t ntz = (uint32_t)__builtin_ctz(mask);
       if (bps < 32 - ntz) { return SLA_APIRESULT_INVALID_ARGUMENT; }   /* samples wider than declared */
       e->lshift = bps - (32 - ntz);
+      if (e->lshift >= bps) { return SLA_APIRESULT_INVALID_ARGUMENT; }
     }
-    if (e->lshift >= bps && mask != 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   }
 
-  /* ---- super-frame table (sequential hop over silence runs)   src/SLAEncoder.c:846-869, 392-408 */
-  t0 = now_ms();
-  e->num_blocks = 0;
-  shapes = (shape_t*)malloc(sizeof(shape_t) * 8);
-  if (shapes == NULL) { return SLA_APIRESULT_NG; }
+  /* super-frame table (sequential hop over silence runs)        src/SLAEncoder.c:846-869, 392-408 */
+  a->shapes = (shape_t*)malloc(sizeof(shape_t) * shapes_cap);
+  if (a->shapes == NULL) { return SLA_APIRESULT_NG; }
   for (pos = 0; pos < n;) {
     const uint32_t remain = n - pos;
     const uint32_t window = (maxb < remain) ? maxb : remain;
     const uint32_t min_blk = (SLAI_MIN_BLOCK < remain) ? SLAI_MIN_BLOCK : remain;
     const uint32_t run = slai_zero_run(nz, pos, window);
+    sframe_t* f;
     uint32_t s;
-    if (nsf == sf_cap) {
+    if (a->nsf == sf_cap) {
       sf_cap = sf_cap ? sf_cap * 2 : 1024;
-      sf = (sframe_t*)realloc(sf, sizeof(sframe_t) * sf_cap);
-      if (sf == NULL) { free(shapes); return SLA_APIRESULT_NG; }
+      a->sf = (sframe_t*)realloc(a->sf, sizeof(sframe_t) * sf_cap);
+      if (a->sf == NULL) { return SLA_APIRESULT_NG; }
     }
-    sf[nsf].start = pos; sf[nsf].window = window; sf[nsf].min_blk = min_blk; sf[nsf].slot_base = 0;
+    f = &a->sf[a->nsf++];
+    f->start = pos; f->window = window; f->min_blk = min_blk; f->slot_base = 0; f->grp_lo = f->grp_hi = 0;
     if (run >= min_blk) {
-      sf[nsf].shape = 0xFFFFFFFFu;      /* one SILENT block of `run` samples, no search */
-      sf[nsf].window = run;
+      f->shape = 0xFFFFFFFFu;           /* one SILENT block of `run` samples, no search */
+      f->window = run;
       pos += run;
+      a->blocks_bound += 1;
     } else {
-      for (s = 0; s < nshapes; s++) { if (shapes[s].window == window && shapes[s].min_blk == min_blk) { break; } }
-      if (s == nshapes) {
-        if (nshapes >= 8) { shapes = (shape_t*)realloc(shapes, sizeof(shape_t) * (nshapes + 1)); if (shapes == NULL) { free(sf); return SLA_APIRESULT_NG; } }
-        shapes[s].window = window; shapes[s].min_blk = min_blk;
-        shapes[s].nodes = (window + SLAI_SEARCH_DELTA - 1) / SLAI_SEARCH_DELTA + 1;
-        shapes[s].ncand = 0; shapes[s].cand_first = 0;
-        nshapes++;
+      for (s = 0; s < a->nshapes; s++) { if (a->shapes[s].window == window && a->shapes[s].min_blk == min_blk) { break; } }
+      if (s == a->nshapes) {
+        if (a->nshapes == shapes_cap) {
+          shapes_cap *= 2;
+          a->shapes = (shape_t*)realloc(a->shapes, sizeof(shape_t) * shapes_cap);
+          if (a->shapes == NULL) { return SLA_APIRESULT_NG; }
+        }
+        a->shapes[s].window = window; a->shapes[s].min_blk = min_blk;
+        a->shapes[s].nodes = (window + SLAI_SEARCH_DELTA - 1) / SLAI_SEARCH_DELTA + 1;
+        a->shapes[s].ncand = 0; a->shapes[s].cand_first = 0;
+        a->nshapes++;
       }
-      sf[nsf].shape = s;
+      f->shape = s;
       pos += window;
+      a->blocks_bound += window / min_blk + 1;
+      a->lchunks_bound += C * (window / chunk_samples + window / min_blk + 2);
     }
-    nsf++;
   }
 
   /* candidate table per shape: every (i,j) whose clipped length is allowed   src/SLAPredictor.c:1615-1630 */
-  for (i = 0; i < nshapes; i++) { ncands += shapes[i].nodes * shapes[i].nodes; }
-  RCCHK(pin_reserve(&e->h_cands, sizeof(sla_hip_lpc_cand) * (ncands + 1)));
+  {
+    uint32_t total = 1;
+    for (i = 0; i < a->nshapes; i++) { total += a->shapes[i].nodes * a->shapes[i].nodes; }
+    RCCHK(pin_reserve(&e->h_cands, sizeof(sla_hip_lpc_cand) * total));
+  }
   cands = (sla_hip_lpc_cand*)e->h_cands.ptr;
-  ncands = 0;
-  for (i = 0; i < nshapes; i++) {
-    shape_t* sh = &shapes[i];
-    uint32_t a, b;
-    sh->cand_first = ncands;
-    for (a = 0; a < sh->nodes; a++) {
-      for (b = 0; b < sh->nodes; b++) {
-        uint32_t off = a * SLAI_SEARCH_DELTA, len = (b > a) ? (b - a) * SLAI_SEARCH_DELTA : 0;
-        sh->pair[a * sh->nodes + b] = 0xFFFFFFFFu;
-        if (b <= a) { continue; }
+  for (i = 0; i < a->nshapes; i++) {
+    shape_t* sh = &a->shapes[i];
+    uint32_t p, q, woff;
+    sh->cand_first = a->ncands;
+    for (p = 0; p < sh->nodes; p++) {
+      for (q = 0; q < sh->nodes; q++) {
+        uint32_t off = p * SLAI_SEARCH_DELTA, len = (q > p) ? (q - p) * SLAI_SEARCH_DELTA : 0;
+        sh->pair[p * sh->nodes + q] = 0xFFFFFFFFu;
+        if (q <= p) { continue; }
         if (len > sh->window - off) { len = sh->window - off; }
         if (len < sh->min_blk || len > sh->window) { continue; }
-        sh->pair[a * sh->nodes + b] = sh->ncand;
-        cands[ncands].start = off; cands[ncands].len = len;
-        ncands++; sh->ncand++;
+        sh->pair[p * sh->nodes + q] = sh->ncand;
+        cands[a->ncands].start = off; cands[a->ncands].len = len;
+        a->ncands++; sh->ncand++;
+        RCCHK(window_offset(e, len, &woff));      /* every block length the plan can choose gets its table now */
       }
     }
   }
 
-  /* groups: (super-frame, channel) split so that window + r[] fits the LDS budget */
+  /* search groups: (super-frame, channel), candidates sliced so that window + r[] fits the LDS budget */
   {
-    uint32_t total_groups = 0;
-    for (i = 0; i < nsf; i++) {
-      if (sf[i].shape == 0xFFFFFFFFu) { continue; }
-      {
-        const shape_t* sh = &shapes[sf[i].shape];
-        size_t room = (SLA_HIP_LDS_BUDGET / 8 > sh->window) ? (SLA_HIP_LDS_BUDGET / 8 - sh->window) : 0;
-        uint32_t cpg = (uint32_t)(room / O1);
-        if (cpg == 0) { free(sf); free(shapes); return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
-        if (cpg > sh->ncand) { cpg = sh->ncand; }
-        total_groups += C * ((sh->ncand + cpg - 1) / cpg);
-      }
+    uint32_t total_groups = 1;
+    for (i = 0; i < a->nsf; i++) {
+      const shape_t* sh;
+      size_t room; uint32_t cpg;
+      if (a->sf[i].shape == 0xFFFFFFFFu) { continue; }
+      sh = &a->shapes[a->sf[i].shape];
+      room = (SLA_HIP_LDS_BUDGET / 8 > sh->window) ? (SLA_HIP_LDS_BUDGET / 8 - sh->window) : 0;
+      cpg = (uint32_t)(room / O1);
+      if (cpg == 0) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
+      if (cpg > sh->ncand) { cpg = sh->ncand; }
+      total_groups += C * ((sh->ncand + cpg - 1) / cpg);
     }
-    RCCHK(pin_reserve(&e->h_groups, sizeof(sla_hip_lpc_group) * (total_groups + 1)));
+    RCCHK(pin_reserve(&e->h_groups, sizeof(sla_hip_lpc_group) * total_groups));
   }
   groups = (sla_hip_lpc_group*)e->h_groups.ptr;
-  {
-    uint32_t max_window = 1;
-    for (i = 0; i < nsf; i++) {
-      const shape_t* sh;
-      uint32_t cpg, ch, first;
-      size_t room;
-      if (sf[i].shape == 0xFFFFFFFFu) { continue; }
-      sh = &shapes[sf[i].shape];
-      room = SLA_HIP_LDS_BUDGET / 8 - sh->window;
-      cpg = (uint32_t)(room / O1);
-      if (cpg > sh->ncand) { cpg = sh->ncand; }
-      sf[i].slot_base = nslots;
-      for (ch = 0; ch < C; ch++) {
-        for (first = 0; first < sh->ncand; first += cpg) {
-          sla_hip_lpc_group* g = &groups[ngroups++];
-          g->pcm_off = sf[i].start; g->num_samples = sh->window; g->channel = ch;
-          g->win_off = SLA_HIP_NO_WINDOW; g->int_shift = 32 - bps;
-          g->cand_first = sh->cand_first + first;
-          g->cand_count = (sh->ncand - first < cpg) ? (sh->ncand - first) : cpg;
-          g->slot_first = nslots + ch * sh->ncand + first; g->pad_ = 0;
-          if (g->cand_count > max_cpg) { max_cpg = g->cand_count; }
-        }
-      }
-      nslots += C * sh->ncand;
-      if (sh->window > max_window) { max_window = sh->window; }
-    }
-
-    /* ---- search kernel ---------------------------------------------------------- */
-    if (ngroups > 0) {
-      RCCHK(dev_reserve(&e->d_groups, sizeof(sla_hip_lpc_group) * ngroups));
-      RCCHK(dev_reserve(&e->d_cands, sizeof(sla_hip_lpc_cand) * ncands));
-      RCCHK(dev_reserve(&e->d_lpc_out, sizeof(double) * (size_t)nslots * O2));
-      RCCHK(pin_reserve(&e->h_lpc_out, sizeof(double) * (size_t)nslots * O2));
-      HIPCHK(hipMemcpyAsync(e->d_groups.ptr, groups, sizeof(sla_hip_lpc_group) * ngroups, hipMemcpyHostToDevice, e->stream));
-      HIPCHK(hipMemcpyAsync(e->d_cands.ptr, cands, sizeof(sla_hip_lpc_cand) * ncands, hipMemcpyHostToDevice, e->stream));
-      HIPCHK(hipEventRecord(e->ev[2], e->stream));
-      rc = sla_hip_launch_lpc(e->pcm_dev, e->stride, ms, order, (const sla_hip_lpc_group*)e->d_groups.ptr, ngroups,
-                              max_window, max_cpg, (const sla_hip_lpc_cand*)e->d_cands.ptr, NULL,
-                              (double*)e->d_lpc_out.ptr, NULL, NULL, NULL, e->stream);
-      if (rc != 0) { free(sf); free(shapes); return rc; }
-      HIPCHK(hipEventRecord(e->ev[3], e->stream));
-      HIPCHK(hipMemcpyAsync(e->h_lpc_out.ptr, e->d_lpc_out.ptr, sizeof(double) * (size_t)nslots * O2, hipMemcpyDeviceToHost, e->stream));
-      HIPCHK(hipStreamSynchronize(e->stream));
-    } else {
-      HIPCHK(hipEventRecord(e->ev[2], e->stream));
-      HIPCHK(hipEventRecord(e->ev[3], e->stream));
-    }
-  }
-  e->timing[5] = (float)(now_ms() - t0);
-
-  /* ---- host: code lengths + shortest path per super-frame, then the block table ------- */
-  t0 = now_ms();
-  {
-    plan_ctx_t ctx;
-    uint32_t* parts = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(nsf + 1) * SLAI_MAX_NODES);
-    uint32_t* nparts = (uint32_t*)calloc(nsf + 1, sizeof(uint32_t));
-    int* status = (int*)calloc(nsf + 1, sizeof(int));
-    uint32_t* live = (uint32_t*)malloc(sizeof(uint32_t) * (nsf + 1));
-    sframe_t* lsf = (sframe_t*)malloc(sizeof(sframe_t) * (nsf + 1));
-    uint32_t nlive = 0;
-    if (parts == NULL || nparts == NULL || status == NULL || live == NULL || lsf == NULL) {
-      free(parts); free(nparts); free(status); free(live); free(lsf); free(sf); free(shapes);
-      return SLA_APIRESULT_NG;
-    }
-    for (i = 0; i < nsf; i++) { if (sf[i].shape != 0xFFFFFFFFu) { live[nlive] = i; lsf[nlive] = sf[i]; nlive++; } }
-    ctx.e = e; ctx.sf = lsf; ctx.shapes = shapes; ctx.cands = cands; ctx.out = (const double*)e->h_lpc_out.ptr;
-    ctx.parts = parts; ctx.nparts = nparts; ctx.status = status;
-    parallel_for(e->pool, nlive, plan_one, &ctx);
-    j = 0;
-    for (i = 0; i < nsf && rc == 0; i++) {
-      if (sf[i].shape == 0xFFFFFFFFu) {
-        rc = blocks_push(e, sf[i].start, sf[i].window, SLAI_BLK_SILENT);
-      } else {
-        uint32_t p, at = sf[i].start;
-        if (status[j] != 0) { rc = status[j]; break; }
-        for (p = 0; p < nparts[j] && rc == 0; p++) {
-          const uint32_t len = parts[(size_t)j * SLAI_MAX_NODES + p];
-          const uint32_t type = slai_range_is_zero(nz, at, len) ? SLAI_BLK_SILENT : SLAI_BLK_COMPRESS;
-          rc = blocks_push(e, at, len, type);
-          at += len;
-        }
-        j++;
-      }
-    }
-    free(parts); free(nparts); free(status); free(live); free(lsf);
-  }
-  free(sf); free(shapes);
-  e->timing[5] += (float)(now_ms() - t0);
-  return rc;
-}
-
-/* ------------------------------------------------- stage 2: chosen blocks on the device */
-
-typedef struct {
-  struct SLAEncoder* e;
-  const double* acf;           /* [ngroups][SLAI_LTM_ACF_HEAD] compact autocorrelation records from k_ltm_acf */
-  const uint32_t* job_blk; const uint32_t* job_ch; const uint32_t* job_grp;
-} ltm_ctx_t;
-
-/* pitch + taps of one (block, channel) from the device's autocorrelation head */
-static void ltm_one(void* vctx, uint32_t j)
-{
-  ltm_ctx_t* c = (ltm_ctx_t*)vctx;
-  struct SLAEncoder* e = c->e;
-  const uint32_t C = e->wave_format.num_channels, ntaps = e->encode_param.longterm_order;
-  blkch_t* bc = &e->bc[(size_t)c->job_blk[j] * C + c->job_ch[j]];
-  double coef[SLAI_MAX_TAPS] = {0, 0, 0, 0, 0};
-  uint32_t t;
-  const int ret = slai_ltm_solve(c->acf + (size_t)c->job_grp[j] * SLAI_LTM_ACF_HEAD, ntaps, &bc->pitch, coef);
-  if (ret != 0 || bc->pitch >= SLAI_LTM_MAX_PERIOD) { bc->pitch = 0; }      /* src/SLAEncoder.c:629-632 */
-  for (t = 0; t < ntaps; t++) {
-    /* Round(coef * 2^15) << 16, x86 conversion semantics       src/SLAEncoder.c:635-640 */
-    const double v = coef[t] * 32768.0;
-    const double rv = (v >= 0.0) ? floor(v + 0.5) : -floor(-v + 0.5);
-    const int32_t q = (!(rv > -2147483649.0 && rv < 2147483648.0)) ? INT32_MIN : (int32_t)rv;
-    bc->ltm_q[t] = (int32_t)((uint32_t)q << 16);
-  }
-}
-
-static int stage_blocks(struct SLAEncoder* e)
-{
-  const uint32_t C = e->wave_format.num_channels, bps = e->wave_format.bit_per_sample;
-  const uint32_t order = e->encode_param.parcor_order, O1 = order + 1, O2 = order + 2;
-  const uint32_t ms = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
-  const uint32_t ntaps = e->encode_param.longterm_order, lms = e->encode_param.lms_order_per_filter;
-  const uint32_t nb = e->num_blocks, shift = 32 - bps + e->lshift;
-  extern uint32_t sla_hip_lattice_chunk_samples(uint32_t order);
-  const uint32_t chunk_samples = sla_hip_lattice_chunk_samples(order);
-  const size_t nslots = (size_t)nb * C;
-  sla_hip_lpc_group* groups; sla_hip_lpc_cand* cands; sla_hip_lattice_chunk* chunks; sla_hip_tail_job* jobs;
-  sla_hip_acf_job* acf_jobs;
-  uint32_t ngroups = 0, nchunks = 0, njobs = 0, max_window = 1, b, ch;
-  uint32_t *job_blk, *job_ch, *job_grp, *grp_of_slot;
-  const uint32_t fft_size = slai_fft_plan_size(e->fft);
-  double t0;
-  int rc;
-
-  /* host result arrays */
-  if (e->bc_cap < nslots + 1) {
-    e->bc_cap = nslots + 1 + nslots / 4;
-    e->bc = (blkch_t*)realloc(e->bc, sizeof(blkch_t) * e->bc_cap);
-  }
-  if (e->coef_cap < (nslots + 1) * O1) {
-    e->coef_cap = (nslots + 1 + nslots / 4) * O1;
-    e->parcor = (double*)realloc(e->parcor, sizeof(double) * e->coef_cap);
-    e->code = (int32_t*)realloc(e->code, sizeof(int32_t) * e->coef_cap);
-    e->kint = (int32_t*)realloc(e->kint, sizeof(int32_t) * e->coef_cap);
-  }
-  if (e->bc == NULL || e->parcor == NULL || e->code == NULL || e->kint == NULL) { return SLA_APIRESULT_NG; }
-  memset(e->bc, 0, sizeof(blkch_t) * (nslots + 1));
-
-  /* descriptors */
-  {
-    size_t total_chunks = 0;
-    for (b = 0; b < nb; b++) {
-      if (e->blk[b].type != SLAI_BLK_SILENT) { total_chunks += (size_t)C * ((e->blk[b].nsmpl + chunk_samples - 1) / chunk_samples); }
-    }
-    RCCHK(pin_reserve(&e->h_groups, sizeof(sla_hip_lpc_group) * (nslots + 1)));
-    RCCHK(pin_reserve(&e->h_cands, sizeof(sla_hip_lpc_cand) * (nslots + 1)));
-    RCCHK(pin_reserve(&e->h_chunks, sizeof(sla_hip_lattice_chunk) * (total_chunks + 1)));
-    RCCHK(pin_reserve(&e->h_jobs, sizeof(sla_hip_tail_job) * (nslots + 1)));
-    RCCHK(pin_reserve(&e->h_acf_jobs, sizeof(sla_hip_acf_job) * (nslots + 1)));
-  }
-  acf_jobs = (sla_hip_acf_job*)e->h_acf_jobs.ptr;
-  groups = (sla_hip_lpc_group*)e->h_groups.ptr; cands = (sla_hip_lpc_cand*)e->h_cands.ptr;
-  chunks = (sla_hip_lattice_chunk*)e->h_chunks.ptr; jobs = (sla_hip_tail_job*)e->h_jobs.ptr;
-  for (b = 0; b < nb; b++) {
-    const blk_t* k = &e->blk[b];
-    uint32_t woff = 0, at;
-    if (k->type == SLAI_BLK_SILENT) { continue; }
-    if (k->nsmpl > MAX_ANALYSIS_WINDOW) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
-    RCCHK(window_offset(e, k->nsmpl, &woff));
+  a->max_window = 1; a->max_cpg = 1;
+  for (i = 0; i < a->nsf; i++) {
+    sframe_t* f = &a->sf[i];
+    const shape_t* sh;
+    uint32_t cpg, ch, first;
+    f->grp_lo = f->grp_hi = a->nsgroups;
+    if (f->shape == 0xFFFFFFFFu) { continue; }
+    sh = &a->shapes[f->shape];
+    cpg = (uint32_t)((SLA_HIP_LDS_BUDGET / 8 - sh->window) / O1);
+    if (cpg > sh->ncand) { cpg = sh->ncand; }
+    f->slot_base = a->nslots;
     for (ch = 0; ch < C; ch++) {
-      sla_hip_lpc_group* g = &groups[ngroups];
-      g->pcm_off = k->start; g->num_samples = k->nsmpl; g->channel = ch; g->win_off = woff; g->int_shift = shift;
-      g->cand_first = ngroups; g->cand_count = 1; g->slot_first = b * C + ch; g->pad_ = 0;
-      cands[ngroups].start = 0; cands[ngroups].len = k->nsmpl;
-      acf_jobs[ngroups].blk_off = k->start; acf_jobs[ngroups].blk_len = k->nsmpl; acf_jobs[ngroups].channel = ch;
-      ngroups++;
-      for (at = 0; at < k->nsmpl; at += chunk_samples) {
-        sla_hip_lattice_chunk* c = &chunks[nchunks++];
-        c->blk_off = k->start; c->blk_len = k->nsmpl; c->chunk_start = at;
-        c->count = (k->nsmpl - at < chunk_samples) ? (k->nsmpl - at) : chunk_samples;
-        c->channel = ch; c->slot = b * C + ch; c->int_shift = shift;
+      for (first = 0; first < sh->ncand; first += cpg) {
+        sla_hip_lpc_group* g = &groups[a->nsgroups++];
+        g->pcm_off = f->start; g->num_samples = sh->window; g->channel = ch;
+        g->win_off = SLA_HIP_NO_WINDOW; g->int_shift = 32 - bps;
+        g->cand_first = sh->cand_first + first;
+        g->cand_count = (sh->ncand - first < cpg) ? (sh->ncand - first) : cpg;
+        g->slot_first = a->nslots + ch * sh->ncand + first; g->pad_ = 0;
+        if (g->cand_count > a->max_cpg) { a->max_cpg = g->cand_count; }
       }
     }
-    if (k->nsmpl > max_window) { max_window = k->nsmpl; }
+    f->grp_hi = a->nsgroups;
+    a->nslots += C * sh->ncand;
+    if (sh->window > a->max_window) { a->max_window = sh->window; }
   }
+  return 0;
+}
 
+/* size every device / pinned buffer of the block and tail stages for the whole file */
+static int pipeline_reserve(struct SLAEncoder* e, const actx_t* a)
+{
+  const uint32_t C = e->wave_format.num_channels, order = e->encode_param.parcor_order, O1 = order + 1, O2 = order + 2;
+  const size_t nslots = (size_t)a->blocks_bound * C + 1;
+  const uint32_t fft_size = slai_fft_plan_size(e->fft);
+  /* search */
+  RCCHK(dev_reserve(&e->d_groups, sizeof(sla_hip_lpc_group) * (a->nsgroups + 1)));
+  RCCHK(dev_reserve(&e->d_cands, sizeof(sla_hip_lpc_cand) * (a->ncands + 1)));
+  RCCHK(dev_reserve(&e->d_lpc_out, sizeof(double) * ((size_t)a->nslots + 1) * O2));
+  RCCHK(pin_reserve(&e->h_lpc_out, sizeof(double) * ((size_t)a->nslots + 1) * O2));
+  /* blocks */
+  RCCHK(pin_reserve(&e->h_bgroups, sizeof(sla_hip_lpc_group) * nslots));
+  RCCHK(pin_reserve(&e->h_bcands, sizeof(sla_hip_lpc_cand) * nslots));
+  RCCHK(pin_reserve(&e->h_chunks, sizeof(sla_hip_lattice_chunk) * ((size_t)a->lchunks_bound + 1)));
+  RCCHK(pin_reserve(&e->h_acf_jobs, sizeof(sla_hip_acf_job) * nslots));
+  RCCHK(pin_reserve(&e->h_jobs, sizeof(sla_hip_tail_job) * nslots));
+  RCCHK(pin_reserve(&e->h_blk_out, sizeof(double) * nslots * O2));
+  RCCHK(pin_reserve(&e->h_code, sizeof(int32_t) * nslots * O1));
+  RCCHK(pin_reserve(&e->h_kint, sizeof(int32_t) * nslots * O1));
+  RCCHK(pin_reserve(&e->h_rshift, sizeof(uint32_t) * nslots));
+  RCCHK(pin_reserve(&e->h_acf, sizeof(double) * nslots * SLAI_LTM_ACF_HEAD));
+  RCCHK(pin_reserve(&e->h_fold, sizeof(uint64_t) * nslots));
+  RCCHK(dev_reserve(&e->d_bgroups, sizeof(sla_hip_lpc_group) * nslots));
+  RCCHK(dev_reserve(&e->d_bcands, sizeof(sla_hip_lpc_cand) * nslots));
+  RCCHK(dev_reserve(&e->d_chunks, sizeof(sla_hip_lattice_chunk) * ((size_t)a->lchunks_bound + 1)));
+  RCCHK(dev_reserve(&e->d_acf_jobs, sizeof(sla_hip_acf_job) * nslots));
+  RCCHK(dev_reserve(&e->d_jobs, sizeof(sla_hip_tail_job) * nslots));
+  RCCHK(dev_reserve(&e->d_blk_out, sizeof(double) * nslots * O2));
+  RCCHK(dev_reserve(&e->d_code, sizeof(int32_t) * nslots * O1));
+  RCCHK(dev_reserve(&e->d_kint, sizeof(int32_t) * nslots * O1));
+  RCCHK(dev_reserve(&e->d_rshift, sizeof(uint32_t) * nslots));
+  RCCHK(dev_reserve(&e->d_acf, sizeof(double) * nslots * SLAI_LTM_ACF_HEAD));
+  RCCHK(dev_reserve(&e->d_fold, sizeof(uint64_t) * nslots));
+  if (sizeof(double) * (size_t)fft_size > SLA_HIP_LDS_BUDGET) {
+    RCCHK(dev_reserve(&e->d_acf_scratch, sizeof(double) * (size_t)fft_size * 512));
+  }
   if (e->user_res1 != NULL && e->user_stride != e->stride) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (e->user_res1 == NULL) {
     RCCHK(dev_reserve(&e->d_res1, sizeof(int32_t) * (size_t)C * e->stride));
     RCCHK(dev_reserve(&e->d_res2, sizeof(int32_t) * (size_t)C * e->stride));
   }
-  RCCHK(dev_reserve(&e->d_lpc_out, sizeof(double) * (nslots + 1) * O2));
-  RCCHK(dev_reserve(&e->d_code, sizeof(int32_t) * (nslots + 1) * O1));
-  RCCHK(dev_reserve(&e->d_kint, sizeof(int32_t) * (nslots + 1) * O1));
-  RCCHK(dev_reserve(&e->d_rshift, sizeof(uint32_t) * (nslots + 1)));
-  RCCHK(pin_reserve(&e->h_lpc_out, sizeof(double) * (nslots + 1) * O2));
-  RCCHK(pin_reserve(&e->h_code, sizeof(int32_t) * (nslots + 1) * O1));
-  RCCHK(pin_reserve(&e->h_kint, sizeof(int32_t) * (nslots + 1) * O1));
-  RCCHK(pin_reserve(&e->h_rshift, sizeof(uint32_t) * (nslots + 1)));
-  HIPCHK(hipEventRecord(e->ev[4], e->stream));
-  HIPCHK(hipEventRecord(e->ev[5], e->stream));
-  HIPCHK(hipEventRecord(e->ev[6], e->stream));
-  HIPCHK(hipEventRecord(e->ev[9], e->stream));
-  HIPCHK(hipEventRecord(e->ev[10], e->stream));
-  if (ngroups > 0) {
-    if (e->win_dirty) {
-      RCCHK(dev_reserve(&e->d_winpool, sizeof(double) * e->win_count));
-      HIPCHK(hipMemcpyAsync(e->d_winpool.ptr, e->win_host, sizeof(double) * e->win_count, hipMemcpyHostToDevice, e->stream));
-      e->win_dirty = 0;
-    }
-    RCCHK(dev_reserve(&e->d_groups, sizeof(sla_hip_lpc_group) * ngroups));
-    RCCHK(dev_reserve(&e->d_cands, sizeof(sla_hip_lpc_cand) * ngroups));
-    RCCHK(dev_reserve(&e->d_chunks, sizeof(sla_hip_lattice_chunk) * nchunks));
-    HIPCHK(hipMemcpyAsync(e->d_groups.ptr, groups, sizeof(sla_hip_lpc_group) * ngroups, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->d_cands.ptr, cands, sizeof(sla_hip_lpc_cand) * ngroups, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->d_chunks.ptr, chunks, sizeof(sla_hip_lattice_chunk) * nchunks, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemsetAsync(e->d_code.ptr, 0, sizeof(int32_t) * (nslots + 1) * O1, e->stream));
-    HIPCHK(hipMemsetAsync(e->d_kint.ptr, 0, sizeof(int32_t) * (nslots + 1) * O1, e->stream));
-    HIPCHK(hipMemsetAsync(e->d_rshift.ptr, 0, sizeof(uint32_t) * (nslots + 1), e->stream));
-    HIPCHK(hipMemsetAsync(e->d_lpc_out.ptr, 0, sizeof(double) * (nslots + 1) * O2, e->stream));
-    HIPCHK(hipEventRecord(e->ev[4], e->stream));
-    RCCHK(sla_hip_launch_lpc(e->pcm_dev, e->stride, ms, order, (const sla_hip_lpc_group*)e->d_groups.ptr, ngroups,
-                             max_window, 1, (const sla_hip_lpc_cand*)e->d_cands.ptr, (const double*)e->d_winpool.ptr,
-                             (double*)e->d_lpc_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
-                             (uint32_t*)e->d_rshift.ptr, e->stream));
-    HIPCHK(hipEventRecord(e->ev[5], e->stream));
-    RCCHK(sla_hip_launch_lattice(e->pcm_dev, e->stride, ms, order, (const sla_hip_lattice_chunk*)e->d_chunks.ptr, nchunks,
-                                 (const int32_t*)e->d_kint.ptr, RES1(e), e->stream));
-    HIPCHK(hipEventRecord(e->ev[6], e->stream));
-    HIPCHK(hipMemcpyAsync(e->h_lpc_out.ptr, e->d_lpc_out.ptr, sizeof(double) * nslots * O2, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(e->h_code.ptr, e->d_code.ptr, sizeof(int32_t) * nslots * O1, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(e->h_kint.ptr, e->d_kint.ptr, sizeof(int32_t) * nslots * O1, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(e->h_rshift.ptr, e->d_rshift.ptr, sizeof(uint32_t) * nslots, hipMemcpyDeviceToHost, e->stream));
-    /* long-term analysis: FFT autocorrelation heads of every lattice residual */
-    if (!e->twiddle_ready) {
-      double* tw = (double*)malloc(sizeof(double) * 3 * (size_t)fft_size);
-      if (tw == NULL) { return SLA_APIRESULT_NG; }
-      slai_fft_plan_export(e->fft, tw);
-      RCCHK(dev_reserve(&e->d_twiddle, sizeof(double) * 3 * (size_t)fft_size));
-      HIPCHK(hipMemcpy(e->d_twiddle.ptr, tw, sizeof(double) * 3 * (size_t)fft_size, hipMemcpyHostToDevice));
-      free(tw);
-      e->twiddle_ready = 1;
-    }
-    {
-      uint32_t slots = 0;
-      if (sizeof(double) * (size_t)fft_size > SLA_HIP_LDS_BUDGET) {
-        slots = (ngroups < 512) ? ngroups : 512;
-        RCCHK(dev_reserve(&e->d_acf_scratch, sizeof(double) * (size_t)fft_size * slots));
-      }
-      RCCHK(dev_reserve(&e->d_acf_jobs, sizeof(sla_hip_acf_job) * ngroups));
-      RCCHK(dev_reserve(&e->d_acf, sizeof(double) * (size_t)ngroups * SLAI_LTM_ACF_HEAD));
-      RCCHK(pin_reserve(&e->h_acf, sizeof(double) * (size_t)ngroups * SLAI_LTM_ACF_HEAD));
-      HIPCHK(hipMemcpyAsync(e->d_acf_jobs.ptr, acf_jobs, sizeof(sla_hip_acf_job) * ngroups, hipMemcpyHostToDevice, e->stream));
-      HIPCHK(hipEventRecord(e->ev[9], e->stream));
-      RCCHK(sla_hip_launch_ltm_acf(RES1(e), e->stride, (const sla_hip_acf_job*)e->d_acf_jobs.ptr, ngroups, fft_size,
-                                   (const double*)e->d_twiddle.ptr, (double*)e->d_acf_scratch.ptr, slots,
-                                   (double*)e->d_acf.ptr, SLAI_LTM_ACF_HEAD, e->stream));
-      HIPCHK(hipEventRecord(e->ev[10], e->stream));
-      HIPCHK(hipMemcpyAsync(e->h_acf.ptr, e->d_acf.ptr, sizeof(double) * (size_t)ngroups * SLAI_LTM_ACF_HEAD, hipMemcpyDeviceToHost, e->stream));
-    }
-    HIPCHK(hipStreamSynchronize(e->stream));
+  /* host result arrays */
+  if (e->bc_cap < nslots) {
+    e->bc_cap = nslots;
+    e->bc = (blkch_t*)realloc(e->bc, sizeof(blkch_t) * e->bc_cap);
   }
+  if (e->coef_cap < nslots * O1) {
+    e->coef_cap = nslots * O1;
+    e->parcor = (double*)realloc(e->parcor, sizeof(double) * e->coef_cap);
+    e->code = (int32_t*)realloc(e->code, sizeof(int32_t) * e->coef_cap);
+    e->kint = (int32_t*)realloc(e->kint, sizeof(int32_t) * e->coef_cap);
+  }
+  if (e->bc == NULL || e->parcor == NULL || e->code == NULL || e->kint == NULL) { return SLA_APIRESULT_NG; }
+  memset(e->bc, 0, sizeof(blkch_t) * nslots);
+  /* tables that never change while kernels are in flight */
+  if (e->win_dirty) {
+    RCCHK(dev_reserve(&e->d_winpool, sizeof(double) * (e->win_count + 1)));
+    HIPCHK(hipMemcpyAsync(e->d_winpool.ptr, e->win_host, sizeof(double) * e->win_count, hipMemcpyHostToDevice, e->stream));
+    e->win_dirty = 0;
+  }
+  if (!e->twiddle_ready) {
+    double* tw = (double*)malloc(sizeof(double) * 3 * (size_t)fft_size);
+    if (tw == NULL) { return SLA_APIRESULT_NG; }
+    slai_fft_plan_export(e->fft, tw);
+    RCCHK(dev_reserve(&e->d_twiddle, sizeof(double) * 3 * (size_t)fft_size));
+    HIPCHK(hipMemcpy(e->d_twiddle.ptr, tw, sizeof(double) * 3 * (size_t)fft_size, hipMemcpyHostToDevice));
+    free(tw);
+    e->twiddle_ready = 1;
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return 0;
+}
 
-  /* ---- host: RAW decision per block (any channel's estimate >= 0.95)   src/SLAEncoder.c:553-565 */
-  t0 = now_ms();
-  job_blk = (uint32_t*)malloc(sizeof(uint32_t) * (nslots + 1));
-  job_ch = (uint32_t*)malloc(sizeof(uint32_t) * (nslots + 1));
-  job_grp = (uint32_t*)malloc(sizeof(uint32_t) * (nslots + 1));
-  grp_of_slot = (uint32_t*)malloc(sizeof(uint32_t) * (nslots + 1));
-  if (job_blk == NULL || job_ch == NULL || job_grp == NULL || grp_of_slot == NULL) {
-    free(job_blk); free(job_ch); free(job_grp); free(grp_of_slot); return SLA_APIRESULT_NG;
+/* stage 1 of chunk c: enqueue the partition-search kernel and the copy of its results */
+static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
+{
+  const chunk_t* k = &a->ck[c];
+  const uint32_t order = e->encode_param.parcor_order, O2 = order + 2;
+  const uint32_t ms = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
+  hipEvent_t* ev = a->ev + (size_t)c * EV_PER_CHUNK;
+  const uint32_t ng = k->grp_hi - k->grp_lo;
+  HIPCHK(hipEventRecord(ev[EV_SEARCH_S], e->stream));
+  if (ng > 0) {
+    const sla_hip_lpc_group* hg = (const sla_hip_lpc_group*)e->h_groups.ptr + k->grp_lo;
+    sla_hip_lpc_group* dg = (sla_hip_lpc_group*)e->d_groups.ptr + k->grp_lo;
+    HIPCHK(hipMemcpyAsync(dg, hg, sizeof(sla_hip_lpc_group) * ng, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipEventRecord(ev[EV_SEARCH_S], e->stream));
+    RCCHK(sla_hip_launch_lpc(e->pcm_dev, e->stride, ms, order, dg, ng, a->max_window, a->max_cpg,
+                             (const sla_hip_lpc_cand*)e->d_cands.ptr, NULL, (double*)e->d_lpc_out.ptr, NULL, NULL, NULL, e->stream));
+    HIPCHK(hipEventRecord(ev[EV_SEARCH_E], e->stream));
+    HIPCHK(hipMemcpyAsync((double*)e->h_lpc_out.ptr + (size_t)k->slot_lo * O2, (double*)e->d_lpc_out.ptr + (size_t)k->slot_lo * O2,
+                          sizeof(double) * (size_t)(k->slot_hi - k->slot_lo) * O2, hipMemcpyDeviceToHost, e->stream));
+  } else {
+    HIPCHK(hipEventRecord(ev[EV_SEARCH_E], e->stream));
   }
-  {
-    uint32_t g;
-    for (g = 0; g < ngroups; g++) { grp_of_slot[groups[g].slot_first] = g; }
+  HIPCHK(hipEventRecord(ev[EV_SEARCH_DONE], e->stream));
+  return 0;
+}
+
+/* host: plan of chunk c -> block table entries [blk_lo, blk_hi) */
+static int plan_chunk(struct SLAEncoder* e, actx_t* a, uint32_t c)
+{
+  chunk_t* k = &a->ck[c];
+  const uint64_t* nz = (const uint64_t*)e->h_nz.ptr;
+  plan_ctx_t ctx;
+  uint32_t i;
+  ctx.e = e; ctx.a = a; ctx.sf_lo = k->sf_lo;
+  ctx.cands = (const sla_hip_lpc_cand*)e->h_cands.ptr; ctx.out = (const double*)e->h_lpc_out.ptr;
+  parallel_for(e->pool, k->sf_hi - k->sf_lo, plan_one, &ctx);
+  k->blk_lo = e->num_blocks;
+  for (i = k->sf_lo; i < k->sf_hi; i++) {
+    const sframe_t* f = &a->sf[i];
+    if (f->shape == 0xFFFFFFFFu) {
+      RCCHK(blocks_push(e, f->start, f->window, SLAI_BLK_SILENT));
+    } else {
+      uint32_t p, at = f->start;
+      if (a->status[i] != 0) { return a->status[i]; }
+      for (p = 0; p < a->nparts[i]; p++) {
+        const uint32_t len = a->parts[(size_t)i * SLAI_MAX_NODES + p];
+        RCCHK(blocks_push(e, at, len, slai_range_is_zero(nz, at, len) ? SLAI_BLK_SILENT : SLAI_BLK_COMPRESS));
+        at += len;
+      }
+    }
   }
-  for (b = 0; b < nb; b++) {
-    blk_t* k = &e->blk[b];
-    if (k->type == SLAI_BLK_SILENT) { continue; }
+  k->blk_hi = e->num_blocks;
+  if (k->blk_hi > a->blocks_bound) { return SLA_APIRESULT_NG; }
+  return 0;
+}
+
+/* stage 2 of chunk c: windowed LPC + quantiser, lattice, long-term FFT for blocks [blk_lo, blk_hi) */
+static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
+{
+  chunk_t* k = &a->ck[c];
+  const uint32_t C = e->wave_format.num_channels, bps = e->wave_format.bit_per_sample;
+  const uint32_t order = e->encode_param.parcor_order, O1 = order + 1, O2 = order + 2;
+  const uint32_t ms = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
+  const uint32_t shift = 32 - bps + e->lshift;
+  extern uint32_t sla_hip_lattice_chunk_samples(uint32_t order);
+  const uint32_t chunk_samples = sla_hip_lattice_chunk_samples(order);
+  const uint32_t fft_size = slai_fft_plan_size(e->fft);
+  sla_hip_lpc_group* groups = (sla_hip_lpc_group*)e->h_bgroups.ptr;
+  sla_hip_lpc_cand* cands = (sla_hip_lpc_cand*)e->h_bcands.ptr;
+  sla_hip_lattice_chunk* lch = (sla_hip_lattice_chunk*)e->h_chunks.ptr;
+  sla_hip_acf_job* acf_jobs = (sla_hip_acf_job*)e->h_acf_jobs.ptr;
+  hipEvent_t* ev = a->ev + (size_t)c * EV_PER_CHUNK;
+  uint32_t b, ch, max_window = 1, ng, nl;
+  const size_t slot_lo = (size_t)k->blk_lo * C, nsl = (size_t)(k->blk_hi - k->blk_lo) * C;
+
+  k->bg_lo = a->nbg; k->lc_lo = a->nlc;
+  for (b = k->blk_lo; b < k->blk_hi; b++) {
+    const blk_t* blk = &e->blk[b];
+    uint32_t woff = 0, at;
+    if (blk->type == SLAI_BLK_SILENT) { continue; }
+    if (blk->nsmpl > MAX_ANALYSIS_WINDOW) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
+    RCCHK(window_offset(e, blk->nsmpl, &woff));
+    if (e->win_dirty) { return SLA_APIRESULT_NG; }      /* every length was tabulated in pipeline_prepare */
+    for (ch = 0; ch < C; ch++) {
+      const uint32_t g = a->nbg++;
+      sla_hip_lpc_group* gr = &groups[g];
+      gr->pcm_off = blk->start; gr->num_samples = blk->nsmpl; gr->channel = ch; gr->win_off = woff; gr->int_shift = shift;
+      gr->cand_first = g; gr->cand_count = 1; gr->slot_first = b * C + ch; gr->pad_ = 0;
+      cands[g].start = 0; cands[g].len = blk->nsmpl;
+      acf_jobs[g].blk_off = blk->start; acf_jobs[g].blk_len = blk->nsmpl; acf_jobs[g].channel = ch;
+      a->grp_of_slot[(size_t)b * C + ch] = g;
+      for (at = 0; at < blk->nsmpl; at += chunk_samples) {
+        sla_hip_lattice_chunk* lc;
+        if (a->nlc >= a->lchunks_bound) { return SLA_APIRESULT_NG; }
+        lc = &lch[a->nlc++];
+        lc->blk_off = blk->start; lc->blk_len = blk->nsmpl; lc->chunk_start = at;
+        lc->count = (blk->nsmpl - at < chunk_samples) ? (blk->nsmpl - at) : chunk_samples;
+        lc->channel = ch; lc->slot = b * C + ch; lc->int_shift = shift;
+      }
+    }
+    if (blk->nsmpl > max_window) { max_window = blk->nsmpl; }
+  }
+  k->bg_hi = a->nbg; k->lc_hi = a->nlc;
+  ng = k->bg_hi - k->bg_lo; nl = k->lc_hi - k->lc_lo;
+
+  HIPCHK(hipEventRecord(ev[EV_LPCB_S], e->stream2));
+  if (ng > 0) {
+    sla_hip_lpc_group* dg = (sla_hip_lpc_group*)e->d_bgroups.ptr + k->bg_lo;
+    sla_hip_lattice_chunk* dl = (sla_hip_lattice_chunk*)e->d_chunks.ptr + k->lc_lo;
+    sla_hip_acf_job* da = (sla_hip_acf_job*)e->d_acf_jobs.ptr + k->bg_lo;
+    uint32_t slots = 0;
+    HIPCHK(hipMemcpyAsync(dg, groups + k->bg_lo, sizeof(sla_hip_lpc_group) * ng, hipMemcpyHostToDevice, e->stream2));
+    HIPCHK(hipMemcpyAsync((sla_hip_lpc_cand*)e->d_bcands.ptr + k->bg_lo, cands + k->bg_lo, sizeof(sla_hip_lpc_cand) * ng, hipMemcpyHostToDevice, e->stream2));
+    HIPCHK(hipMemcpyAsync(dl, lch + k->lc_lo, sizeof(sla_hip_lattice_chunk) * nl, hipMemcpyHostToDevice, e->stream2));
+    HIPCHK(hipMemcpyAsync(da, acf_jobs + k->bg_lo, sizeof(sla_hip_acf_job) * ng, hipMemcpyHostToDevice, e->stream2));
+    HIPCHK(hipMemsetAsync((int32_t*)e->d_code.ptr + slot_lo * O1, 0, sizeof(int32_t) * nsl * O1, e->stream2));
+    HIPCHK(hipMemsetAsync((int32_t*)e->d_kint.ptr + slot_lo * O1, 0, sizeof(int32_t) * nsl * O1, e->stream2));
+    HIPCHK(hipMemsetAsync((uint32_t*)e->d_rshift.ptr + slot_lo, 0, sizeof(uint32_t) * nsl, e->stream2));
+    HIPCHK(hipMemsetAsync((double*)e->d_blk_out.ptr + slot_lo * O2, 0, sizeof(double) * nsl * O2, e->stream2));
+    HIPCHK(hipEventRecord(ev[EV_LPCB_S], e->stream2));
+    RCCHK(sla_hip_launch_lpc(e->pcm_dev, e->stride, ms, order, dg, ng, max_window, 1,
+                             (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
+                             (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
+                             (uint32_t*)e->d_rshift.ptr, e->stream2));
+    HIPCHK(hipEventRecord(ev[EV_LPCB_E], e->stream2));
+    RCCHK(sla_hip_launch_lattice(e->pcm_dev, e->stride, ms, order, dl, nl, (const int32_t*)e->d_kint.ptr, RES1(e), e->stream2));
+    HIPCHK(hipEventRecord(ev[EV_LAT_E], e->stream2));
+    if (sizeof(double) * (size_t)fft_size > SLA_HIP_LDS_BUDGET) { slots = (ng < 512) ? ng : 512; }
+    HIPCHK(hipEventRecord(ev[EV_ACF_S], e->stream2));
+    RCCHK(sla_hip_launch_ltm_acf(RES1(e), e->stride, da, ng, fft_size, (const double*)e->d_twiddle.ptr,
+                                 (double*)e->d_acf_scratch.ptr, slots,
+                                 (double*)e->d_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD, SLAI_LTM_ACF_HEAD, e->stream2));
+    HIPCHK(hipEventRecord(ev[EV_ACF_E], e->stream2));
+    HIPCHK(hipMemcpyAsync((double*)e->h_blk_out.ptr + slot_lo * O2, (double*)e->d_blk_out.ptr + slot_lo * O2, sizeof(double) * nsl * O2, hipMemcpyDeviceToHost, e->stream2));
+    HIPCHK(hipMemcpyAsync((int32_t*)e->h_code.ptr + slot_lo * O1, (int32_t*)e->d_code.ptr + slot_lo * O1, sizeof(int32_t) * nsl * O1, hipMemcpyDeviceToHost, e->stream2));
+    HIPCHK(hipMemcpyAsync((int32_t*)e->h_kint.ptr + slot_lo * O1, (int32_t*)e->d_kint.ptr + slot_lo * O1, sizeof(int32_t) * nsl * O1, hipMemcpyDeviceToHost, e->stream2));
+    HIPCHK(hipMemcpyAsync((uint32_t*)e->h_rshift.ptr + slot_lo, (uint32_t*)e->d_rshift.ptr + slot_lo, sizeof(uint32_t) * nsl, hipMemcpyDeviceToHost, e->stream2));
+    HIPCHK(hipMemcpyAsync((double*)e->h_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD, (double*)e->d_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD,
+                          sizeof(double) * (size_t)ng * SLAI_LTM_ACF_HEAD, hipMemcpyDeviceToHost, e->stream2));
+  } else {
+    HIPCHK(hipEventRecord(ev[EV_LPCB_E], e->stream2));
+    HIPCHK(hipEventRecord(ev[EV_LAT_E], e->stream2));
+    HIPCHK(hipEventRecord(ev[EV_ACF_S], e->stream2));
+    HIPCHK(hipEventRecord(ev[EV_ACF_E], e->stream2));
+  }
+  HIPCHK(hipEventRecord(ev[EV_BLOCK_DONE], e->stream2));
+  return 0;
+}
+
+/* host + stage 3 of chunk c: RAW decision, long-term solve, then k_tail */
+static int tail_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
+{
+  chunk_t* k = &a->ck[c];
+  const uint32_t C = e->wave_format.num_channels, bps = e->wave_format.bit_per_sample;
+  const uint32_t order = e->encode_param.parcor_order, O1 = order + 1, O2 = order + 2;
+  const uint32_t ntaps = e->encode_param.longterm_order, lms = e->encode_param.lms_order_per_filter;
+  sla_hip_tail_job* jobs = (sla_hip_tail_job*)e->h_jobs.ptr;
+  hipEvent_t* ev = a->ev + (size_t)c * EV_PER_CHUNK;
+  uint32_t b, ch, j, t, nj;
+
+  k->job_lo = a->njobs;
+  /* RAW decision per block: any channel's estimate >= 0.95        src/SLAEncoder.c:553-565 */
+  for (b = k->blk_lo; b < k->blk_hi; b++) {
+    blk_t* blk = &e->blk[b];
+    if (blk->type == SLAI_BLK_SILENT) { continue; }
     for (ch = 0; ch < C; ch++) {
       const size_t slot = (size_t)b * C + ch;
-      const double* o = (const double*)e->h_lpc_out.ptr + slot * O2;
+      const double* o = (const double*)e->h_blk_out.ptr + slot * O2;
       double est;
       memcpy(e->parcor + slot * O1, o + 1, sizeof(double) * O1);
       memcpy(e->code + slot * O1, (const int32_t*)e->h_code.ptr + slot * O1, sizeof(int32_t) * O1);
       memcpy(e->kint + slot * O1, (const int32_t*)e->h_kint.ptr + slot * O1, sizeof(int32_t) * O1);
       e->bc[slot].rshift = ((const uint32_t*)e->h_rshift.ptr)[slot];
-      est = slai_code_length(o[0], k->nsmpl, bps, o + 1, order);
+      est = slai_code_length(o[0], blk->nsmpl, bps, o + 1, order);
       est = (8 * est) / bps;
-      if (est >= SLAI_RAW_THRESHOLD) { k->type = SLAI_BLK_RAW; break; }
+      if (est >= SLAI_RAW_THRESHOLD) { blk->type = SLAI_BLK_RAW; break; }
     }
-    if (k->type == SLAI_BLK_COMPRESS) {
-      for (ch = 0; ch < C; ch++) { job_blk[njobs] = b; job_ch[njobs] = ch; job_grp[njobs] = grp_of_slot[(size_t)b * C + ch]; njobs++; }
+    if (blk->type == SLAI_BLK_COMPRESS) {
+      for (ch = 0; ch < C; ch++) {
+        a->job_blk[a->njobs] = b; a->job_ch[a->njobs] = ch; a->job_grp[a->njobs] = a->grp_of_slot[(size_t)b * C + ch];
+        a->njobs++;
+      }
     }
   }
-
-  /* ---- host: long-term analysis (pitch + taps) per compressed (block, channel) ---------- */
+  k->job_hi = a->njobs;
+  nj = k->job_hi - k->job_lo;
   {
     ltm_ctx_t lc;
-    lc.e = e; lc.acf = (const double*)e->h_acf.ptr; lc.job_blk = job_blk; lc.job_ch = job_ch; lc.job_grp = job_grp;
-    parallel_for(e->pool, njobs, ltm_one, &lc);
+    lc.e = e; lc.acf = (const double*)e->h_acf.ptr; lc.job_blk = a->job_blk; lc.job_ch = a->job_ch; lc.job_grp = a->job_grp;
+    lc.job_lo = k->job_lo;
+    parallel_for(e->pool, nj, ltm_one, &lc);
   }
-  e->timing[6] = (float)(now_ms() - t0);
-
-  /* ---- tail kernel: long-term filter + LMS + folded sum --------------------------------- */
-  HIPCHK(hipEventRecord(e->ev[7], e->stream));
-  HIPCHK(hipEventRecord(e->ev[8], e->stream));
-  if (njobs > 0) {
-    uint32_t j, t;
-    const uint64_t* fold;
-    for (j = 0; j < njobs; j++) {
-      const blk_t* k = &e->blk[job_blk[j]];
-      const blkch_t* bc = &e->bc[(size_t)job_blk[j] * C + job_ch[j]];
-      jobs[j].blk_off = k->start; jobs[j].blk_len = k->nsmpl; jobs[j].channel = job_ch[j]; jobs[j].pitch = bc->pitch;
+  HIPCHK(hipEventRecord(ev[EV_TAIL_S], e->stream3));
+  if (nj > 0) {
+    sla_hip_tail_job* dj = (sla_hip_tail_job*)e->d_jobs.ptr + k->job_lo;
+    for (j = k->job_lo; j < k->job_hi; j++) {
+      const blk_t* blk = &e->blk[a->job_blk[j]];
+      const blkch_t* bc = &e->bc[(size_t)a->job_blk[j] * C + a->job_ch[j]];
+      jobs[j].blk_off = blk->start; jobs[j].blk_len = blk->nsmpl; jobs[j].channel = a->job_ch[j]; jobs[j].pitch = bc->pitch;
       for (t = 0; t < SLAI_MAX_TAPS; t++) { jobs[j].ltm_coef[t] = bc->ltm_q[t]; }
       jobs[j].pad_[0] = jobs[j].pad_[1] = 0;
     }
-    RCCHK(dev_reserve(&e->d_jobs, sizeof(sla_hip_tail_job) * njobs));
-    RCCHK(dev_reserve(&e->d_fold, sizeof(uint64_t) * njobs));
-    RCCHK(pin_reserve(&e->h_fold, sizeof(uint64_t) * njobs));
-    HIPCHK(hipMemcpyAsync(e->d_jobs.ptr, jobs, sizeof(sla_hip_tail_job) * njobs, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipEventRecord(e->ev[7], e->stream));
-    rc = sla_hip_launch_tail(RES1(e), RES2(e), e->stride,
-                             (const sla_hip_tail_job*)e->d_jobs.ptr, njobs, ntaps, lms, (uint64_t*)e->d_fold.ptr, e->stream);
-    if (rc != 0) { free(job_blk); free(job_ch); free(job_grp); free(grp_of_slot); return rc; }
-    HIPCHK(hipEventRecord(e->ev[8], e->stream));
-    HIPCHK(hipMemcpyAsync(e->h_fold.ptr, e->d_fold.ptr, sizeof(uint64_t) * njobs, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    fold = (const uint64_t*)e->h_fold.ptr;
-    for (j = 0; j < njobs; j++) {
-      /* mean of the folded residual, at least 1                 src/SLACoder.c:371-384 */
-      const uint64_t mean = fold[j] / e->blk[job_blk[j]].nsmpl;
-      const uint32_t init = (uint32_t)(mean > 1 ? mean : 1);
-      /* the coder keeps the parameter as a 32-bit 24.8 fixed-point word (src/SLACoder.c:14,19):
-       * store the value that survives that round trip, which is also what is transmitted */
-      const uint32_t kept = (uint32_t)((((uint64_t)(uint32_t)(init << 8)) + 128u) >> 8);
-      e->bc[(size_t)job_blk[j] * C + job_ch[j]].rice_init = kept ? kept : 1u;
+    HIPCHK(hipMemcpyAsync(dj, jobs + k->job_lo, sizeof(sla_hip_tail_job) * nj, hipMemcpyHostToDevice, e->stream3));
+    HIPCHK(hipEventRecord(ev[EV_TAIL_S], e->stream3));
+    RCCHK(sla_hip_launch_tail(RES1(e), RES2(e), e->stride, dj, nj, ntaps, lms, (uint64_t*)e->d_fold.ptr + k->job_lo, e->stream3));
+    HIPCHK(hipEventRecord(ev[EV_TAIL_E], e->stream3));
+    HIPCHK(hipMemcpyAsync((uint64_t*)e->h_fold.ptr + k->job_lo, (uint64_t*)e->d_fold.ptr + k->job_lo, sizeof(uint64_t) * nj, hipMemcpyDeviceToHost, e->stream3));
+  } else {
+    HIPCHK(hipEventRecord(ev[EV_TAIL_E], e->stream3));
+  }
+  HIPCHK(hipEventRecord(ev[EV_TAIL_DONE], e->stream3));
+  return 0;
+}
+
+/* Rice initial parameters from the folded sums, once every tail kernel has landed */
+static void finish_rice(struct SLAEncoder* e, const actx_t* a)
+{
+  const uint32_t C = e->wave_format.num_channels;
+  const uint64_t* fold = (const uint64_t*)e->h_fold.ptr;
+  uint32_t j;
+  for (j = 0; j < a->njobs; j++) {
+    /* mean of the folded residual, at least 1                 src/SLACoder.c:371-384 */
+    const uint64_t mean = fold[j] / e->blk[a->job_blk[j]].nsmpl;
+    const uint32_t init = (uint32_t)(mean > 1 ? mean : 1);
+    /* the coder keeps the parameter as a 32-bit 24.8 fixed-point word (src/SLACoder.c:14,19):
+     * store the value that survives that round trip, which is also what is transmitted */
+    const uint32_t kept = (uint32_t)((((uint64_t)(uint32_t)(init << 8)) + 128u) >> 8);
+    e->bc[(size_t)a->job_blk[j] * C + a->job_ch[j]].rice_init = kept ? kept : 1u;
+  }
+}
+
+static float ev_ms(hipEvent_t s, hipEvent_t t) { float ms = 0.f; return (hipEventElapsedTime(&ms, s, t) == hipSuccess) ? ms : 0.f; }
+
+/* run the pipeline.  preset_blocks != 0: the block table is already in e->blk (EncodeBlock), no search. */
+static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
+{
+  const uint32_t C = e->wave_format.num_channels;
+  actx_t a;
+  uint32_t c, i, want_chunks;
+  double t_host = 0.0, t0;
+  int rc = 0;
+  memset(&a, 0, sizeof(a));
+  a.ev = e->ev + 2;
+
+  if (!preset_blocks) {
+    e->num_blocks = 0;
+    if ((rc = pipeline_prepare(e, &a)) != 0) { actx_free(&a); return rc; }
+  } else {
+    extern uint32_t sla_hip_lattice_chunk_samples(uint32_t order);
+    const uint32_t cs = sla_hip_lattice_chunk_samples(e->encode_param.parcor_order);
+    uint32_t woff;
+    a.blocks_bound = e->num_blocks;
+    for (i = 0; i < e->num_blocks; i++) {
+      a.lchunks_bound += C * (e->blk[i].nsmpl / cs + 2);
+      if (e->blk[i].type != SLAI_BLK_SILENT && (rc = window_offset(e, e->blk[i].nsmpl, &woff)) != 0) { actx_free(&a); return rc; }
+    }
+    RCCHK(pin_reserve(&e->h_cands, 64)); RCCHK(pin_reserve(&e->h_groups, 64));
+  }
+  {
+    const size_t nslots = (size_t)a.blocks_bound * C + 1;
+    a.job_blk = (uint32_t*)malloc(sizeof(uint32_t) * nslots);
+    a.job_ch = (uint32_t*)malloc(sizeof(uint32_t) * nslots);
+    a.job_grp = (uint32_t*)malloc(sizeof(uint32_t) * nslots);
+    a.grp_of_slot = (uint32_t*)malloc(sizeof(uint32_t) * nslots);
+    a.parts = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)a.nsf + 1) * SLAI_MAX_NODES);
+    a.nparts = (uint32_t*)calloc((size_t)a.nsf + 1, sizeof(uint32_t));
+    a.status = (int*)calloc((size_t)a.nsf + 1, sizeof(int));
+    if (!a.job_blk || !a.job_ch || !a.job_grp || !a.grp_of_slot || !a.parts || !a.nparts || !a.status) { actx_free(&a); return SLA_APIRESULT_NG; }
+  }
+  if ((rc = pipeline_reserve(e, &a)) != 0) { actx_free(&a); return rc; }
+
+  /* chunking: equal runs of super-frames */
+  want_chunks = e->chunks;
+  if (preset_blocks || a.nsf < 64) { want_chunks = 1; }
+  if (want_chunks > a.nsf / 32 + 1) { want_chunks = a.nsf / 32 + 1; }
+  if (want_chunks > MAX_CHUNKS) { want_chunks = MAX_CHUNKS; }
+  if (want_chunks < 1) { want_chunks = 1; }
+  a.nchunks = want_chunks;
+  for (c = 0; c < a.nchunks; c++) {
+    chunk_t* k = &a.ck[c];
+    k->sf_lo = (uint32_t)((uint64_t)a.nsf * c / a.nchunks);
+    k->sf_hi = (uint32_t)((uint64_t)a.nsf * (c + 1) / a.nchunks);
+    if (!preset_blocks && k->sf_hi > k->sf_lo) {
+      uint32_t last_live = 0xFFFFFFFFu, first_live = 0xFFFFFFFFu;
+      k->grp_lo = a.sf[k->sf_lo].grp_lo; k->grp_hi = a.sf[k->sf_hi - 1].grp_hi;
+      for (i = k->sf_lo; i < k->sf_hi; i++) { if (a.sf[i].shape != 0xFFFFFFFFu) { if (first_live == 0xFFFFFFFFu) { first_live = i; } last_live = i; } }
+      if (first_live != 0xFFFFFFFFu) {
+        k->slot_lo = a.sf[first_live].slot_base;
+        k->slot_hi = a.sf[last_live].slot_base + C * a.shapes[a.sf[last_live].shape].ncand;
+      }
     }
   }
-  free(job_blk); free(job_ch); free(job_grp); free(grp_of_slot);
-  return 0;
+
+  if (!preset_blocks) {
+    if (a.ncands > 0) {
+      HIPCHK(hipMemcpyAsync(e->d_cands.ptr, e->h_cands.ptr, sizeof(sla_hip_lpc_cand) * a.ncands, hipMemcpyHostToDevice, e->stream));
+    }
+    for (c = 0; c < a.nchunks && rc == 0; c++) { rc = search_launch(e, &a, c); }
+  } else {
+    a.ck[0].blk_lo = 0; a.ck[0].blk_hi = e->num_blocks;
+  }
+  /* software pipeline over chunks: plan(c) | blocks(c) ; solve+tail(c-1) */
+  for (c = 0; c < a.nchunks && rc == 0; c++) {
+    hipEvent_t* ev = a.ev + (size_t)c * EV_PER_CHUNK;
+    if (!preset_blocks) {
+      if (hipEventSynchronize(ev[EV_SEARCH_DONE]) != hipSuccess) { rc = SLA_APIRESULT_NG; break; }
+      t0 = now_ms();
+      rc = plan_chunk(e, &a, c);
+      t_host += now_ms() - t0;
+      if (rc != 0) { break; }
+    }
+    if ((rc = blocks_launch(e, &a, c)) != 0) { break; }
+    if (c >= 1) {
+      hipEvent_t* pv = a.ev + (size_t)(c - 1) * EV_PER_CHUNK;
+      if (hipEventSynchronize(pv[EV_BLOCK_DONE]) != hipSuccess) { rc = SLA_APIRESULT_NG; break; }
+      t0 = now_ms();
+      rc = tail_launch(e, &a, c - 1);
+      e->timing[6] += (float)(now_ms() - t0);
+    }
+  }
+  if (rc == 0) {
+    hipEvent_t* pv = a.ev + (size_t)(a.nchunks - 1) * EV_PER_CHUNK;
+    if (hipEventSynchronize(pv[EV_BLOCK_DONE]) != hipSuccess) { rc = SLA_APIRESULT_NG; }
+    else {
+      t0 = now_ms();
+      rc = tail_launch(e, &a, a.nchunks - 1);
+      e->timing[6] += (float)(now_ms() - t0);
+    }
+  }
+  if (hipStreamSynchronize(e->stream) != hipSuccess || hipStreamSynchronize(e->stream2) != hipSuccess
+      || hipStreamSynchronize(e->stream3) != hipSuccess) { if (rc == 0) { rc = SLA_APIRESULT_NG; } }
+  if (rc == 0) {
+    finish_rice(e, &a);
+    e->timing[0] = preset_blocks ? 0.f : ev_ms(e->ev[0], e->ev[1]);
+    e->timing[5] = (float)t_host;
+    for (c = 0; c < a.nchunks; c++) {
+      hipEvent_t* ev = a.ev + (size_t)c * EV_PER_CHUNK;
+      if (!preset_blocks) { e->timing[1] += ev_ms(ev[EV_SEARCH_S], ev[EV_SEARCH_E]); }
+      e->timing[2] += ev_ms(ev[EV_LPCB_S], ev[EV_LPCB_E]);
+      e->timing[3] += ev_ms(ev[EV_LPCB_E], ev[EV_LAT_E]);
+      e->timing[8] += ev_ms(ev[EV_ACF_S], ev[EV_ACF_E]);
+      e->timing[4] += ev_ms(ev[EV_TAIL_S], ev[EV_TAIL_E]);
+    }
+    e->timing[9] = (float)a.nchunks;
+  }
+  actx_free(&a);
+  return rc;
 }
 
 static int check_ready(const struct SLAEncoder* e)
@@ -895,18 +1087,6 @@ static int check_ready(const struct SLAEncoder* e)
   return 0;
 }
 
-static void collect_timing(struct SLAEncoder* e, double t_start)
-{
-  float ms = 0.f;
-  e->timing[0] = (hipEventElapsedTime(&ms, e->ev[0], e->ev[1]) == hipSuccess) ? ms : -1.f;
-  e->timing[1] = (hipEventElapsedTime(&ms, e->ev[2], e->ev[3]) == hipSuccess) ? ms : -1.f;
-  e->timing[2] = (hipEventElapsedTime(&ms, e->ev[4], e->ev[5]) == hipSuccess) ? ms : -1.f;
-  e->timing[3] = (hipEventElapsedTime(&ms, e->ev[5], e->ev[6]) == hipSuccess) ? ms : -1.f;
-  e->timing[4] = (hipEventElapsedTime(&ms, e->ev[7], e->ev[8]) == hipSuccess) ? ms : -1.f;
-  e->timing[8] = (hipEventElapsedTime(&ms, e->ev[9], e->ev[10]) == hipSuccess) ? ms : -1.f;
-  e->timing[7] = (float)(now_ms() - t_start);
-}
-
 int sla_hip_analyze_device(struct SLAEncoder* e, const int32_t* d_pcm, uint64_t plane_stride,
                            uint32_t num_samples, sla_hip_stream_t stream, float* timing_ms)
 {
@@ -919,11 +1099,10 @@ int sla_hip_analyze_device(struct SLAEncoder* e, const int32_t* d_pcm, uint64_t 
   e->analysed = 0;
   e->pcm_dev = d_pcm; e->stride = plane_stride; e->num_samples = num_samples;
   memset(e->timing, 0, sizeof(e->timing));
-  rc = stage_plan(e);
-  if (rc == 0) { rc = stage_blocks(e); }
-  if (rc != 0) { (void)hipStreamSynchronize(e->stream); return rc; }
+  rc = run_pipeline(e, 0);
+  if (rc != 0) { return rc; }
   e->wave_format.offset_lshift = (uint8_t)e->lshift;
-  collect_timing(e, t_start);
+  e->timing[7] = (float)(now_ms() - t_start);
   if (timing_ms != NULL) { memcpy(timing_ms, e->timing, sizeof(e->timing)); }
   e->analysed = 1;
   return 0;
@@ -1116,8 +1295,7 @@ SLAApiResult SLAEncoder_EncodeBlock(struct SLAEncoder* e, const int32_t* const* 
   if (blocks_push(e, 0, num_samples, slai_range_is_zero((const uint64_t*)e->h_nz.ptr, 0, num_samples) ? SLAI_BLK_SILENT : SLAI_BLK_COMPRESS) != 0) {
     return SLA_APIRESULT_NG;
   }
-  { int i; for (i = 0; i < 4; i++) { (void)hipEventRecord(e->ev[i], e->stream); } }
-  rc = stage_blocks(e);
+  rc = run_pipeline(e, 1);
   if (rc != 0) { return (rc > 0) ? (SLAApiResult)rc : SLA_APIRESULT_NG; }
   e->analysed = 1;
   /* pack into a scratch image (header + block) and hand back the block bytes only */

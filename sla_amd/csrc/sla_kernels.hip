@@ -196,8 +196,8 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
   __syncthreads();
 
   // ---- autocorrelation chains -----------------------------------------------------------------
-  // waves 0..2 walk the lag >= 1 chains, wave 3 the lag-0 (energy) chains: the two loop bodies differ,
-  // so keeping them in different waves avoids executing both serially under divergence
+  // waves 0..2 walk the lag >= 1 chains, wave 3 the lag-0 (energy) chains.  (Measured on C2: running the
+  // two loop bodies back to back in the idle lanes of one wave is 1.1-1.4x slower than this split.)
   if (dbg_skip & 1) {
     for (uint32_t q = threadIdx.x; q < nc * O1; q += blockDim.x) { r[q] = 1.0 / (1.0 + q); }
   } else if (threadIdx.x < 192) {
@@ -205,11 +205,11 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
     for (uint32_t q = threadIdx.x; q < nchains; q += 192) {
       const uint32_t c = q / order, lag = 1 + (q - c * order);
       const uint32_t n = cd[c].len;
-      r[c * O1 + lag] = (lag < n) ? chain_lag(x + cd[c].start, n, lag) : 0.0;
+      r[c * O1 + lag] = (dbg_skip & 8) ? 0.0 : ((lag < n) ? chain_lag(x + cd[c].start, n, lag) : 0.0);
     }
   } else {
     for (uint32_t c = threadIdx.x - 192; c < nc; c += 64) {
-      r[c * O1] = chain_lag0(x + cd[c].start, cd[c].len);
+      r[c * O1] = (dbg_skip & 4) ? 1.0 : chain_lag0(x + cd[c].start, cd[c].len);
     }
   }
   __syncthreads();
