@@ -96,6 +96,28 @@ typedef struct sla_hip_tail_job {
   uint32_t pad_[2];
 } sla_hip_tail_job;
 
+/* One (block, channel) of the Rice code-length pass. */
+typedef struct sla_hip_rice_job {
+  uint64_t blk_off;
+  uint32_t blk_len;
+  uint32_t channel;
+  uint32_t rice_init;      /* initial parameter (mean of the folded residual, >= 1)            */
+  uint32_t golomb_m;       /* != 0: block is in fixed-parameter Golomb mode with this modulus */
+} sla_hip_rice_job;
+
+/* One block of the output image. */
+typedef struct sla_hip_pack_block {
+  uint64_t blk_off;        /* first sample inside a channel plane                              */
+  uint64_t out_off;        /* byte offset of the block inside the .sla image                  */
+  uint32_t num_samples;
+  uint32_t type;           /* 0 compressed, 1 silent, 2 raw                                    */
+  uint32_t header_off;     /* offset of the pre-packed header bytes in the header pool         */
+  uint32_t header_bytes;
+  uint32_t out_bytes;      /* total encoded size of the block                                  */
+  uint32_t raw_bits;       /* RAW blocks: bits per sample of channel 0 (bps - offset_lshift)   */
+  uint32_t golomb_m[8];    /* per channel: 0 = adaptive recursive Rice, else Golomb modulus    */
+} sla_hip_pack_block;
+
 /* ---- (1) kernel launchers ----------------------------------------------- */
 
 /* OR of every input word + one bit per sample "any channel non-zero after
@@ -139,6 +161,20 @@ int sla_hip_launch_tail(const int32_t* d_res_in, int32_t* d_res_out, uint64_t pl
                         const sla_hip_tail_job* d_jobs, uint32_t num_jobs, uint32_t longterm_order,
                         uint32_t lms_order, uint64_t* d_fold_sum, sla_hip_stream_t stream);
 
+/* Rice code lengths: per job the log2 of both adaptive moduli for every sample (d_kk, same plane layout
+ * as the residual, uint16: k0 | k1 << 8) and the channel's total body bits (d_chan_bits[job]).
+ * replaces the parameter walk of SLACoder_PutDataArray (src/SLACoder.c:224-270, 429-467). */
+int sla_hip_launch_rice_len(const int32_t* d_residual, uint64_t plane_stride, const sla_hip_rice_job* d_jobs,
+                            uint32_t num_jobs, uint16_t* d_kk, uint64_t* d_chan_bits, sla_hip_stream_t stream);
+
+/* Block assembly into a zero-initialised .sla image (32-bit words, 4-byte aligned at file offset 0):
+ * pre-packed header bytes, channel-interleaved Rice/Golomb/gamma or RAW bodies, then CRC16 + size patch.
+ * replaces src/SLAEncoder.c:740-798 and src/SLACoder.c:45-82,120-138,429-467. */
+int sla_hip_launch_rice_write(const int32_t* d_residual, const int32_t* d_pcm, uint64_t plane_stride,
+                              const uint16_t* d_kk, const sla_hip_pack_block* d_blocks, uint32_t num_blocks,
+                              const uint8_t* d_headers, uint32_t num_channels, uint32_t raw_shift,
+                              uint32_t mid_side, uint32_t* d_image, sla_hip_stream_t stream);
+
 /* ---- (2) whole-file driver ---------------------------------------------- */
 
 /* Per-block results of the last analyze call, copied into caller arrays
@@ -169,6 +205,10 @@ int sla_hip_analyze_device(struct SLAEncoder* encoder, const int32_t* d_pcm, uin
  * residual, block headers, Rice body, CRC16 (reference src/SLAEncoder.c:682-798,
  * src/SLACoder.c:429-467).  Needs a preceding sla_hip_analyze_device. */
 int sla_hip_pack(struct SLAEncoder* encoder, uint8_t* data, uint32_t data_size, uint32_t* output_size);
+
+/* Same bytes as sla_hip_pack, but the Rice coding, block assembly and CRC16 run on the device and one
+ * D2H copy brings the finished image back.  Used by SLAEncoder_EncodeWhole. */
+int sla_hip_pack_device(struct SLAEncoder* encoder, uint8_t* data, uint32_t data_size, uint32_t* output_size);
 
 /* Device pointers of the last analysis (for RCCL gathers / tests). */
 const int32_t* sla_hip_final_residual(const struct SLAEncoder* encoder, uint64_t* plane_stride);

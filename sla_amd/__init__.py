@@ -104,6 +104,7 @@ def lib():
         L.sla_hip_analyze_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
                                              C.POINTER(C.c_float)]
         L.sla_hip_pack.argtypes = [C.c_void_p, u8p, C.c_uint32, u32p]
+        L.sla_hip_pack_device.argtypes = [C.c_void_p, u8p, C.c_uint32, u32p]
         L.sla_hip_get_trace.argtypes = [C.c_void_p, C.POINTER(HipTrace)]
         L.sla_hip_final_residual.restype = C.c_void_p
         L.sla_hip_final_residual.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
@@ -121,7 +122,7 @@ EXPORTED_SYMBOLS = [
     "SLAEncoder_EncodeHeader", "SLAEncoder_EncodeBlock", "SLAEncoder_EncodeWhole",
     # include/sla_hip.h
     "sla_hip_launch_prepass", "sla_hip_launch_lpc", "sla_hip_launch_lattice", "sla_hip_launch_tail",
-    "sla_hip_launch_ltm_acf",
+    "sla_hip_launch_ltm_acf", "sla_hip_launch_rice_len", "sla_hip_launch_rice_write", "sla_hip_pack_device",
     "sla_hip_analyze_device", "sla_hip_pack", "sla_hip_final_residual", "sla_hip_lattice_residual",
     "sla_hip_get_trace", "sla_hip_device_name", "sla_hip_bind_residual_planes",
 ]
@@ -251,10 +252,12 @@ class Encoder:
         self._check(self._lib.sla_hip_bind_residual_planes(self._h, C.c_void_p(lattice_ptr), C.c_void_p(final_ptr),
                                                            plane_stride), "sla_hip_bind_residual_planes")
 
-    def pack(self, capacity):
+    def pack(self, capacity, on_device=False):
+        """bit-pack the analysed file: host threads (sla_hip_pack) or device kernels (sla_hip_pack_device)"""
         out = np.zeros(capacity, np.uint8)
         size = C.c_uint32(0)
-        self._check(self._lib.sla_hip_pack(self._h, out.ctypes.data_as(u8p), capacity, C.byref(size)), "sla_hip_pack")
+        fn = self._lib.sla_hip_pack_device if on_device else self._lib.sla_hip_pack
+        self._check(fn(self._h, out.ctypes.data_as(u8p), capacity, C.byref(size)), "sla_hip_pack")
         return out[:size.value].tobytes()
 
     def trace(self, want_residuals=True):

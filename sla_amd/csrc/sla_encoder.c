@@ -60,11 +60,11 @@ struct SLAEncoder {
 
   /* device workspace */
   devbuf_t d_pcm, d_res1, d_res2, d_or, d_nz, d_groups, d_cands, d_lpc_out, d_code, d_kint, d_rshift,
-           d_winpool, d_chunks, d_jobs, d_fold, d_acf_jobs, d_acf, d_acf_scratch, d_twiddle, d_bgroups, d_bcands, d_blk_out;
+           d_winpool, d_chunks, d_jobs, d_fold, d_acf_jobs, d_acf, d_acf_scratch, d_twiddle, d_bgroups, d_bcands, d_blk_out, d_kk, d_pk_jobs, d_pk_blocks, d_pk_hdr, d_image;
   int twiddle_ready;
   /* pinned host staging */
   pinbuf_t h_nz, h_groups, h_cands, h_lpc_out, h_code, h_kint, h_rshift, h_chunks, h_jobs, h_fold, h_res, h_pcm, h_acf_jobs, h_acf,
-           h_bgroups, h_bcands, h_blk_out;
+           h_bgroups, h_bcands, h_blk_out, h_pk_jobs, h_pk_blocks, h_pk_hdr;
   uint32_t* h_or;
 
   /* window pool: tables for every block length seen so far */
@@ -272,8 +272,8 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
 
 void SLAEncoder_Destroy(struct SLAEncoder* e)
 {
-  devbuf_t* d[22];
-  pinbuf_t* h[17];
+  devbuf_t* d[27];
+  pinbuf_t* h[20];
   int i;
   if (e == NULL) { return; }
   (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3);
@@ -282,11 +282,13 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   d[11] = &e->d_winpool; d[12] = &e->d_chunks; d[13] = &e->d_jobs; d[14] = &e->d_fold;
   d[15] = &e->d_acf_jobs; d[16] = &e->d_acf; d[17] = &e->d_acf_scratch; d[18] = &e->d_twiddle;
   d[19] = &e->d_bgroups; d[20] = &e->d_bcands; d[21] = &e->d_blk_out;
-  for (i = 0; i < 22; i++) { if (d[i]->ptr != NULL) { (void)hipFree(d[i]->ptr); } }
+  d[22] = &e->d_kk; d[23] = &e->d_pk_jobs; d[24] = &e->d_pk_blocks; d[25] = &e->d_pk_hdr; d[26] = &e->d_image;
+  for (i = 0; i < 27; i++) { if (d[i]->ptr != NULL) { (void)hipFree(d[i]->ptr); } }
   h[0] = &e->h_nz; h[1] = &e->h_groups; h[2] = &e->h_cands; h[3] = &e->h_lpc_out; h[4] = &e->h_code; h[5] = &e->h_kint;
   h[6] = &e->h_rshift; h[7] = &e->h_chunks; h[8] = &e->h_jobs; h[9] = &e->h_fold; h[10] = &e->h_res; h[11] = &e->h_pcm;
   h[12] = &e->h_acf_jobs; h[13] = &e->h_acf; h[14] = &e->h_bgroups; h[15] = &e->h_bcands; h[16] = &e->h_blk_out;
-  for (i = 0; i < 17; i++) { if (h[i]->ptr != NULL) { (void)hipHostFree(h[i]->ptr); } }
+  h[17] = &e->h_pk_jobs; h[18] = &e->h_pk_blocks; h[19] = &e->h_pk_hdr;
+  for (i = 0; i < 20; i++) { if (h[i]->ptr != NULL) { (void)hipHostFree(h[i]->ptr); } }
   if (e->h_or != NULL) { (void)hipHostFree(e->h_or); }
   for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { (void)hipEventDestroy(e->ev[i]); }
   (void)hipStreamDestroy(e->stream); (void)hipStreamDestroy(e->stream2); (void)hipStreamDestroy(e->stream3);
@@ -1231,6 +1233,129 @@ int sla_hip_pack(struct SLAEncoder* e, uint8_t* data, uint32_t data_size, uint32
   return pack_impl(e, NULL, data, data_size, output_size);
 }
 
+/* ------------------------------------------------------------------ device pack
+ * Rice/Golomb/gamma coding, block assembly and CRC16 on the device.  The host only
+ * packs the few header bytes of every block (it owns the per-block parameters), turns the per-channel
+ * bit counts into block sizes/offsets, and writes the 43-byte file header. */
+int sla_hip_pack_device(struct SLAEncoder* e, uint8_t* data, uint32_t data_size, uint32_t* output_size)
+{
+  uint32_t C, O1, nb, b, ch, njobs = 0, maxblk = 0, maxbps = 0;
+  sla_hip_rice_job* jobs; sla_hip_pack_block* pb; uint8_t* hdr; uint32_t* job_of;
+  size_t hdr_used = 0, hdr_cap;
+  uint64_t cur = SLA_HEADER_SIZE;
+  struct SLAHeaderInfo hinfo;
+  int rc = 0;
+  if (e == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (!e->analysed) { return SLA_APIRESULT_PARAMETER_NOT_SET; }
+  if (data == NULL || output_size == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (data_size < SLA_HEADER_SIZE) { return SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE; }
+  C = e->wave_format.num_channels; O1 = e->encode_param.parcor_order + 1; nb = e->num_blocks;
+  hdr_cap = (size_t)nb * (16 + C * (8 + 2 * O1 + 16)) + 64;
+  RCCHK(pin_reserve(&e->h_pk_jobs, sizeof(sla_hip_rice_job) * ((size_t)nb * C + 1)));
+  RCCHK(pin_reserve(&e->h_pk_blocks, sizeof(sla_hip_pack_block) * ((size_t)nb + 1)));
+  RCCHK(pin_reserve(&e->h_pk_hdr, hdr_cap));
+  RCCHK(pin_reserve(&e->h_fold, sizeof(uint64_t) * ((size_t)nb * C + 1)));
+  jobs = (sla_hip_rice_job*)e->h_pk_jobs.ptr; pb = (sla_hip_pack_block*)e->h_pk_blocks.ptr; hdr = (uint8_t*)e->h_pk_hdr.ptr;
+  job_of = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)nb + 1));
+  if (job_of == NULL) { return SLA_APIRESULT_NG; }
+
+  /* per block: header bytes, coding mode, Rice jobs */
+  for (b = 0; b < nb; b++) {
+    const blk_t* k = &e->blk[b];
+    slai_block_params bp;
+    uint32_t rshift[SLAI_MAX_CHANNELS], pitch[SLAI_MAX_CHANNELS], rice[SLAI_MAX_CHANNELS];
+    int32_t ltm[SLAI_MAX_CHANNELS * SLAI_MAX_TAPS];
+    memset(&bp, 0, sizeof(bp));
+    bp.num_samples = k->nsmpl; bp.type = k->type; bp.num_channels = C; bp.order = O1 - 1;
+    bp.ntaps = e->encode_param.longterm_order; bp.bps = e->wave_format.bit_per_sample; bp.lshift = e->lshift;
+    bp.mid_side = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
+    for (ch = 0; ch < C; ch++) {
+      const blkch_t* bc = &e->bc[(size_t)b * C + ch];
+      rshift[ch] = bc->rshift; pitch[ch] = bc->pitch; rice[ch] = bc->rice_init;
+      memcpy(&ltm[ch * SLAI_MAX_TAPS], bc->ltm_q, sizeof(int32_t) * SLAI_MAX_TAPS);
+    }
+    bp.code = e->code + (size_t)b * C * O1; bp.rshift = rshift; bp.pitch = pitch; bp.ltm_q = ltm; bp.rice_init = rice;
+    memset(&pb[b], 0, sizeof(pb[b]));
+    pb[b].blk_off = k->start; pb[b].num_samples = k->nsmpl; pb[b].type = k->type;
+    pb[b].header_off = (uint32_t)hdr_used;
+    pb[b].header_bytes = slai_pack_header(&bp, hdr + hdr_used, (uint32_t)(hdr_cap - hdr_used));
+    if (pb[b].header_bytes == 0) { free(job_of); return SLA_APIRESULT_NG; }
+    hdr_used += pb[b].header_bytes;
+    pb[b].raw_bits = bp.bps - e->lshift;
+    job_of[b] = njobs;
+    if (k->type == SLAI_BLK_COMPRESS) {
+      slai_coding_mode(rice, C, pb[b].golomb_m);
+      for (ch = 0; ch < C; ch++) {
+        sla_hip_rice_job* j = &jobs[njobs++];
+        j->blk_off = k->start; j->blk_len = k->nsmpl; j->channel = ch; j->rice_init = rice[ch]; j->golomb_m = pb[b].golomb_m[ch];
+      }
+    }
+  }
+
+  /* code lengths on the device */
+  if (njobs > 0) {
+    RCCHK(dev_reserve(&e->d_kk, sizeof(uint16_t) * (size_t)C * e->stride));
+    RCCHK(dev_reserve(&e->d_pk_jobs, sizeof(sla_hip_rice_job) * njobs));
+    RCCHK(dev_reserve(&e->d_fold, sizeof(uint64_t) * njobs));
+    HIPCHK(hipMemcpyAsync(e->d_pk_jobs.ptr, jobs, sizeof(sla_hip_rice_job) * njobs, hipMemcpyHostToDevice, e->stream));
+    rc = sla_hip_launch_rice_len(RES2(e), e->stride, (const sla_hip_rice_job*)e->d_pk_jobs.ptr, njobs,
+                                 (uint16_t*)e->d_kk.ptr, (uint64_t*)e->d_fold.ptr, e->stream);
+    if (rc != 0) { free(job_of); return rc; }
+    HIPCHK(hipMemcpyAsync(e->h_fold.ptr, e->d_fold.ptr, sizeof(uint64_t) * njobs, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+
+  /* block sizes -> offsets */
+  for (b = 0; b < nb; b++) {
+    const blk_t* k = &e->blk[b];
+    uint64_t body_bits = 0, bytes;
+    uint32_t bps_blk;
+    if (k->type == SLAI_BLK_COMPRESS) {
+      for (ch = 0; ch < C; ch++) { body_bits += ((const uint64_t*)e->h_fold.ptr)[job_of[b] + ch]; }
+    } else if (k->type == SLAI_BLK_RAW) {
+      uint64_t per_sample = (uint64_t)C * pb[b].raw_bits
+        + ((e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS) ? 1u : 0u);
+      body_bits = per_sample * k->nsmpl;
+    }
+    bytes = pb[b].header_bytes + (body_bits + 7) / 8;
+    if (bytes > 0xFFFFFFF0ull || cur >= data_size || bytes > (uint64_t)data_size - cur) { free(job_of); return SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE; }
+    pb[b].out_off = cur; pb[b].out_bytes = (uint32_t)bytes;
+    e->blk[b].bytes = (uint32_t)bytes;
+    cur += bytes;
+    if (bytes > maxblk) { maxblk = (uint32_t)bytes; }
+    bps_blk = (8 * (uint32_t)bytes * e->wave_format.sampling_rate) / k->nsmpl;        /* src/SLAEncoder.c:895 */
+    if (bps_blk > maxbps) { maxbps = bps_blk; }
+  }
+  free(job_of);
+
+  /* assemble the image on the device, bring it back with one copy */
+  {
+    const size_t img_bytes = ((size_t)cur + 8 + 3) & ~(size_t)3;
+    RCCHK(dev_reserve(&e->d_image, img_bytes));
+    RCCHK(dev_reserve(&e->d_pk_blocks, sizeof(sla_hip_pack_block) * (nb + 1)));
+    RCCHK(dev_reserve(&e->d_pk_hdr, hdr_used + 16));
+    if (e->d_kk.ptr == NULL) { RCCHK(dev_reserve(&e->d_kk, sizeof(uint16_t) * (size_t)C * e->stride)); }
+    HIPCHK(hipMemsetAsync(e->d_image.ptr, 0, img_bytes, e->stream));
+    if (nb > 0) {
+      HIPCHK(hipMemcpyAsync(e->d_pk_blocks.ptr, pb, sizeof(sla_hip_pack_block) * nb, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipMemcpyAsync(e->d_pk_hdr.ptr, hdr, hdr_used, hipMemcpyHostToDevice, e->stream));
+      RCCHK(sla_hip_launch_rice_write(RES2(e), e->pcm_dev, e->stride, (const uint16_t*)e->d_kk.ptr,
+                                      (const sla_hip_pack_block*)e->d_pk_blocks.ptr, nb, (const uint8_t*)e->d_pk_hdr.ptr, C,
+                                      32 - e->wave_format.bit_per_sample + e->lshift,
+                                      e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS,
+                                      (uint32_t*)e->d_image.ptr, e->stream));
+    }
+    HIPCHK(hipMemcpyAsync(data, e->d_image.ptr, (size_t)cur, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  hinfo.wave_format = e->wave_format; hinfo.wave_format.offset_lshift = (uint8_t)e->lshift;
+  hinfo.encode_param = e->encode_param; hinfo.num_samples = e->num_samples; hinfo.num_blocks = nb;
+  hinfo.max_block_size = maxblk; hinfo.max_bit_per_second = maxbps;
+  rc = slai_write_header(&hinfo, data, data_size);
+  *output_size = (uint32_t)cur;
+  return rc;
+}
+
 /* -------------------------------------------------------------- public encode API */
 
 static int upload_pcm(struct SLAEncoder* e, const int32_t* const* input, uint32_t n)
@@ -1257,7 +1382,7 @@ SLAApiResult SLAEncoder_EncodeWhole(struct SLAEncoder* e, const int32_t* const* 
   if (data_size < SLA_HEADER_SIZE) { return SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE; }
   if ((rc = upload_pcm(e, input, num_samples)) != 0) { return (rc > 0) ? (SLAApiResult)rc : SLA_APIRESULT_NG; }
   rc = sla_hip_analyze_device(e, e->pcm_dev, e->stride, num_samples, NULL, NULL);
-  if (rc == 0) { rc = pack_impl(e, input, data, data_size, output_size); }
+  if (rc == 0) { rc = sla_hip_pack_device(e, data, data_size, output_size); }
   return (rc >= 0) ? (SLAApiResult)rc : SLA_APIRESULT_NG;
 }
 

@@ -71,6 +71,8 @@ typedef struct slai_block_params {
 } slai_block_params;
 /* returns bytes written, or 0 when `cap` is too small */
 uint32_t slai_pack_block(const slai_block_params* bp, uint8_t* out, uint32_t cap);
+uint32_t slai_pack_header(const slai_block_params* bp, uint8_t* out, uint32_t cap);
+void     slai_coding_mode(const uint32_t* rice_init, uint32_t num_channels, uint32_t* golomb_m);
 uint32_t slai_crc16(const uint8_t* data, size_t n);
 int      slai_write_header(const struct SLAHeaderInfo* h, uint8_t* data, uint32_t data_size);
 

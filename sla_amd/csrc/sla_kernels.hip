@@ -755,3 +755,255 @@ extern "C" int sla_hip_launch_ltm_acf(const int32_t* d_residual, uint64_t plane_
   }
   return hip_rc(hipGetLastError());
 }
+
+// ---------------------------------------------------------------------------------------------
+// Bit-pack on the device: recursive-Rice / Golomb / gamma coding of the final
+// residual (reference src/SLACoder.c:45-82, 120-138, 224-270, 429-467), block assembly and CRC16
+// (src/SLAEncoder.c:682-798, src/SLAUtility.c:322-339).
+//
+//   k_rice_len   one lane per (block, channel): walks the residual with the two adaptive parameters
+//                (8.8 fixed-point EMA, serial in time) and stores log2 of both Rice moduli per sample
+//                plus the channel's total bit count.  Blocks in fixed-Golomb mode need no state.
+//   k_rice_write one workgroup per block: header bytes, then tiles of 256 interleaved (sample, channel)
+//                elements -- code length from (value, k0, k1), workgroup prefix sum -> bit offset, and
+//                the <= 3 non-zero pieces of the codeword OR-ed into the zero-initialised image
+//                (MSB-first, 32-bit atomics on byte-swapped words).  Unary zero runs cost nothing.
+//   k_block_crc  one lane per block: CRC16-IBM over the block, size + CRC patched into the header.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fold_u32(int32_t s) { const uint32_t u = (uint32_t)s << 1; return (s < 0) ? ~u : u; }
+__device__ __forceinline__ uint32_t ceil_log2_u32(uint32_t x) { return (x > 1) ? (32u - (uint32_t)__builtin_clz(x - 1u)) : 0u; }
+
+// log2 of the Rice modulus of an adaptive parameter: 2^ceil(log2(round(p/2))), at least 1   src/SLACoder.c:30-31
+__device__ __forceinline__ uint32_t rice_k(uint64_t p)
+{
+  uint32_t v = (uint32_t)(((p >> 1) + 128u) >> 8);
+  v = v ? v : 1u;
+  return ceil_log2_u32(v);
+}
+// 119/128 old + 9/128 code, the code term in 32-bit wrapping arithmetic                         src/SLACoder.c:26-28
+__device__ __forceinline__ uint64_t rice_adapt(uint64_t p, uint32_t code)
+{
+  return (119u * p + (uint64_t)(uint32_t)(9u * (uint32_t)(code << 8)) + 64u) >> 7;
+}
+__device__ __forceinline__ uint32_t gamma_len(uint32_t g) { return (g == 0) ? 1u : (2u * ceil_log2_u32(g + 2u) - 1u); }
+
+// length in bits of the recursive-Rice codeword of `v` under moduli 2^k0, 2^k1 (two parameters)
+__device__ __forceinline__ uint32_t rrice_len(uint32_t v, uint32_t k0, uint32_t k1)
+{
+  if (v < (1u << k0)) { return 1u + k0; }
+  v -= (1u << k0);
+  const uint32_t q = 1u + (v >> k1);
+  return (q < 16u) ? (q + 1u + k1) : (17u + gamma_len(q - 16u) + k1);
+}
+// length of the Golomb codeword of v with modulus m                                             src/SLACoder.c:45-82
+__device__ __forceinline__ uint32_t golomb_len(uint32_t v, uint32_t m)
+{
+  const uint32_t q = v / m, r = v - q * m;
+  if ((m & (m - 1u)) == 0) { return q + 1u + ceil_log2_u32(m); }
+  const uint32_t b = ceil_log2_u32(m), cut = (1u << b) - m;
+  return q + 1u + ((r < cut) ? (b - 1u) : b);
+}
+
+__global__ __launch_bounds__(64)
+void k_rice_len(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_rice_job* __restrict__ jobs,
+                uint32_t num_jobs, uint16_t* __restrict__ kk, uint64_t* __restrict__ chan_bits)
+{
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= num_jobs) { return; }
+  const sla_hip_rice_job job = jobs[j];
+  const int32_t* in = res + (uint64_t)job.channel * stride + job.blk_off;
+  uint16_t* ko = kk + (uint64_t)job.channel * stride + job.blk_off;
+  const uint32_t n = job.blk_len;
+  uint64_t bits = 0;
+  if (job.golomb_m != 0) {                                   // fixed-parameter mode: stateless
+    for (uint32_t s = 0; s < n; s++) { bits += golomb_len(fold_u32(in[s]), job.golomb_m); }
+    chan_bits[j] = bits;
+    return;
+  }
+  uint64_t p0 = (uint64_t)(uint32_t)(job.rice_init << 8), p1 = p0;
+  uint32_t s = 0;
+  for (; s + 8 <= n; s += 8) {
+    int32_t v8[8];
+    uint16_t k8[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { v8[u] = in[s + u]; }       // loads first: the walk below is a serial chain
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      uint32_t v = fold_u32(v8[u]);
+      const uint32_t k0 = rice_k(p0), k1 = rice_k(p1);
+      k8[u] = (uint16_t)(k0 | (k1 << 8));
+      bits += rrice_len(v, k0, k1);
+      p0 = rice_adapt(p0, v);
+      if (v >= (1u << k0)) { p1 = rice_adapt(p1, v - (1u << k0)); }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) { ko[s + u] = k8[u]; }
+  }
+  for (; s < n; s++) {
+    uint32_t v = fold_u32(in[s]);
+    const uint32_t k0 = rice_k(p0), k1 = rice_k(p1);
+    ko[s] = (uint16_t)(k0 | (k1 << 8));
+    bits += rrice_len(v, k0, k1);
+    p0 = rice_adapt(p0, v);
+    if (v >= (1u << k0)) { p1 = rice_adapt(p1, v - (1u << k0)); }
+  }
+  chan_bits[j] = bits;
+}
+
+// OR `len` (1..32) bits of `val` into the image, the first bit landing at absolute bit `pos` (MSB-first)
+__device__ __forceinline__ void put_piece(uint32_t* __restrict__ img, uint64_t pos, uint32_t val, uint32_t len)
+{
+  const uint64_t w = pos >> 5;
+  const uint32_t sh = (uint32_t)(pos & 31);
+  const uint64_t v64 = ((uint64_t)val << (64 - len)) >> sh;          // bit 63 = first bit of word w
+  const uint32_t hi = (uint32_t)(v64 >> 32), lo = (uint32_t)v64;
+  if (hi) { atomicOr(&img[w], __builtin_bswap32(hi)); }
+  if (lo) { atomicOr(&img[w + 1], __builtin_bswap32(lo)); }
+}
+
+__global__ __launch_bounds__(256)
+void k_rice_write(const int32_t* __restrict__ res, const int32_t* __restrict__ pcm, uint64_t stride,
+                  const uint16_t* __restrict__ kk, const sla_hip_pack_block* __restrict__ blocks,
+                  const uint8_t* __restrict__ headers, uint32_t num_channels, uint32_t raw_shift, uint32_t mid_side,
+                  uint32_t* __restrict__ img)
+{
+  __shared__ uint32_t s_wave[4];
+  __shared__ uint64_t s_base;
+  const sla_hip_pack_block b = blocks[blockIdx.x];
+  const uint32_t C = num_channels, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // header bytes (sync, size/crc placeholders, sample count, type, per-channel fields), packed by the host
+  for (uint32_t t = threadIdx.x; t < b.header_bytes; t += blockDim.x) {
+    const uint64_t at = b.out_off + t;
+    atomicOr(&img[at >> 2], (uint32_t)headers[b.header_off + t] << (8 * (at & 3)));
+  }
+  if (b.type == 1) { return; }                                         // SILENT: header only
+  if (threadIdx.x == 0) { s_base = (b.out_off + b.header_bytes) * 8ull; }
+  __syncthreads();
+  const uint32_t total = b.num_samples * C;
+  for (uint32_t e0 = 0; e0 < total; e0 += 256) {
+    const uint32_t e = e0 + threadIdx.x;
+    uint32_t len = 0, v = 0, k0 = 0, k1 = 0, m = 0;
+    if (e < total) {
+      const uint32_t s = e / C, c = e - s * C;
+      if (b.type == 2) {                                               // RAW: fixed width per channel
+        int32_t x;
+        if (!mid_side) { x = pcm[(uint64_t)c * stride + b.blk_off + s] >> raw_shift; }
+        else {
+          const int32_t l = pcm[b.blk_off + s] >> raw_shift, r = pcm[stride + b.blk_off + s] >> raw_shift;
+          x = (c == 0) ? ((int32_t)((uint32_t)l + (uint32_t)r) >> 1) : (int32_t)((uint32_t)l - (uint32_t)r);
+        }
+        v = fold_u32(x);
+        len = b.raw_bits + ((c == 1 && mid_side) ? 1u : 0u);
+      } else {
+        v = fold_u32(res[(uint64_t)c * stride + b.blk_off + s]);
+        m = b.golomb_m[c];
+        if (m != 0) { len = golomb_len(v, m); }
+        else {
+          const uint32_t k = kk[(uint64_t)c * stride + b.blk_off + s];
+          k0 = k & 0xFF; k1 = k >> 8;
+          len = rrice_len(v, k0, k1);
+        }
+      }
+    }
+    // exclusive prefix sum of `len` over the 256 elements of the tile
+    uint32_t inc = len;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if (lane >= (uint32_t)off) { inc += o; } }
+    if (lane == 63) { s_wave[wv] = inc; }
+    __syncthreads();
+    uint32_t wave_base = 0, tile_total = 0;
+    for (uint32_t w = 0; w < 4; w++) { const uint32_t t = s_wave[w]; wave_base += (w < wv) ? t : 0u; tile_total += t; }
+    const uint64_t pos = s_base + wave_base + (inc - len);
+    if (e < total) {
+      if (b.type == 2) {
+        if (len > 0) { put_piece(img, pos, (len >= 32) ? v : (v & ((1u << len) - 1u)), len); }
+      } else if (m != 0) {                                             // Golomb: zeros(q) 1 payload
+        const uint32_t q = v / m, r = v - q * m;
+        uint32_t nb, pay;
+        if ((m & (m - 1u)) == 0) { nb = ceil_log2_u32(m); pay = r; }
+        else { const uint32_t bb = ceil_log2_u32(m), cut = (1u << bb) - m; if (r < cut) { nb = bb - 1; pay = r; } else { nb = bb; pay = r + cut; } }
+        put_piece(img, pos + q, (1u << nb) | pay, nb + 1);
+      } else if (v < (1u << k0)) {                                     // stage 0: 1 rest
+        put_piece(img, pos, (1u << k0) | v, k0 + 1);
+      } else {
+        const uint32_t vv = v - (1u << k0), q = 1u + (vv >> k1), rest = vv & ((1u << k1) - 1u);
+        if (q < 16u) {
+          put_piece(img, pos + q, (1u << k1) | rest, k1 + 1);
+        } else {                                                       // zeros(16) 1 gamma(q-16) rest
+          const uint32_t g = q - 16u;
+          put_piece(img, pos + 16, 1u, 1);
+          uint64_t at = pos + 17;
+          if (g == 0) { put_piece(img, at, 1u, 1); at += 1; }
+          else { const uint32_t nd = ceil_log2_u32(g + 2u); put_piece(img, at + nd - 1, g + 1u, nd); at += 2 * nd - 1; }
+          if (k1 > 0) { put_piece(img, at, rest, k1); }
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { s_base += tile_total; }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(64)
+void k_block_crc(const sla_hip_pack_block* __restrict__ blocks, uint32_t num_blocks, uint32_t* __restrict__ img)
+{
+  __shared__ uint16_t table[256];
+  for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; k++) { c = (c & 1u) ? ((c >> 1) ^ 0xA001u) : (c >> 1); }
+    table[i] = (uint16_t)c;
+  }
+  __syncthreads();
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= num_blocks) { return; }
+  const sla_hip_pack_block b = blocks[j];
+  const uint8_t* bytes = (const uint8_t*)img;
+  uint32_t crc = 0;
+  uint64_t at = b.out_off + 8;
+  const uint64_t end = b.out_off + b.out_bytes;
+  for (; at + 16 <= end; at += 16) {                   // byte loads first, then the serial table walk
+    uint8_t v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) { v[u] = bytes[at + u]; }
+#pragma unroll
+    for (int u = 0; u < 16; u++) { crc = (crc >> 8) ^ table[(crc ^ v[u]) & 0xFFu]; }
+  }
+  for (; at < end; at++) { crc = (crc >> 8) ^ table[(crc ^ bytes[at]) & 0xFFu]; }
+  // size field = bytes after sync + size (32 bit, big endian), then the CRC (16 bit)
+  const uint32_t sz = b.out_bytes - 6;
+  const uint8_t patch[6] = { (uint8_t)(sz >> 24), (uint8_t)(sz >> 16), (uint8_t)(sz >> 8), (uint8_t)sz,
+                             (uint8_t)(crc >> 8), (uint8_t)crc };
+  for (uint32_t t = 0; t < 6; t++) {
+    const uint64_t at = b.out_off + 2 + t;
+    atomicOr(&img[at >> 2], (uint32_t)patch[t] << (8 * (at & 3)));
+  }
+}
+
+extern "C" int sla_hip_launch_rice_len(const int32_t* d_residual, uint64_t plane_stride, const sla_hip_rice_job* d_jobs,
+                                       uint32_t num_jobs, uint16_t* d_kk, uint64_t* d_chan_bits, sla_hip_stream_t stream)
+{
+  if (d_residual == nullptr || d_jobs == nullptr || d_kk == nullptr || d_chan_bits == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (num_jobs == 0) { return 0; }
+  hipLaunchKernelGGL(k_rice_len, dim3((num_jobs + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_residual, plane_stride,
+                     d_jobs, num_jobs, d_kk, d_chan_bits);
+  return hip_rc(hipGetLastError());
+}
+
+extern "C" int sla_hip_launch_rice_write(const int32_t* d_residual, const int32_t* d_pcm, uint64_t plane_stride,
+                                         const uint16_t* d_kk, const sla_hip_pack_block* d_blocks, uint32_t num_blocks,
+                                         const uint8_t* d_headers, uint32_t num_channels, uint32_t raw_shift,
+                                         uint32_t mid_side, uint32_t* d_image, sla_hip_stream_t stream)
+{
+  if (d_residual == nullptr || d_pcm == nullptr || d_kk == nullptr || d_blocks == nullptr || d_headers == nullptr || d_image == nullptr) {
+    return SLA_APIRESULT_INVALID_ARGUMENT;
+  }
+  if (num_channels == 0 || num_channels > 8 || raw_shift > 31) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (num_blocks == 0) { return 0; }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_rice_write, dim3(num_blocks), dim3(256), 0, st, d_residual, d_pcm, plane_stride, d_kk, d_blocks,
+                     d_headers, num_channels, raw_shift, mid_side, d_image);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { return hip_rc(e); }
+  hipLaunchKernelGGL(k_block_crc, dim3((num_blocks + 63) / 64), dim3(64), 0, st, d_blocks, num_blocks, d_image);
+  return hip_rc(hipGetLastError());
+}

@@ -123,34 +123,65 @@ static inline void put_recursive_rice(bits_t* b, rparam_t* prm, uint32_t v)
 }
 
 /* ---- one block --------------------------------------------------------------- */
-uint32_t slai_pack_block(const slai_block_params* bp, uint8_t* out, uint32_t cap)
+/* sync, size/crc placeholders, sample count, type, per-channel coefficient fields; byte aligned */
+static void put_block_header(bits_t* b, const slai_block_params* bp)
 {
-  const uint32_t C = bp->num_channels, n = bp->num_samples, O1 = bp->order + 1;
-  uint32_t ch, ord, s, size;
+  const uint32_t C = bp->num_channels, O1 = bp->order + 1;
+  uint32_t ch, ord;
+  bits_put(b, SLAI_SYNC_CODE, 16);
+  bits_put(b, 0, 32);                        /* size, patched later */
+  bits_put(b, 0, 16);                        /* crc,  patched later */
+  bits_put(b, bp->num_samples, 16);
+  bits_put(b, bp->type, 2);
+  if (bp->type == SLAI_BLK_COMPRESS) {
+    for (ch = 0; ch < C; ch++) {
+      bits_put(b, bp->rshift[ch], 4);
+      for (ord = 1; ord < O1; ord++) { bits_put(b, fold(bp->code[ch * O1 + ord]), (ord < 4) ? 16 : 8); }
+      if (bp->pitch[ch] >= SLAI_LTM_MIN_PITCH) {
+        bits_put(b, 1, 1);
+        bits_put(b, bp->pitch[ch], SLAI_LTM_PERIOD_BITS);
+        for (ord = 0; ord < bp->ntaps; ord++) { bits_put(b, fold(bp->ltm_q[ch * SLAI_MAX_TAPS + ord] >> 16), 16); }
+      } else {
+        bits_put(b, 0, 1);
+      }
+      bits_put(b, rp_value((rparam_t)(uint32_t)(bp->rice_init[ch] << 8)), bp->bps);
+    }
+  }
+  bits_align(b);
+}
+
+/* header bytes only (the device packer appends the body); returns bytes written or 0 */
+uint32_t slai_pack_header(const slai_block_params* bp, uint8_t* out, uint32_t cap)
+{
   bits_t b;
   if (cap < 16) { return 0; }
   b.p = out; b.end = out + cap; b.acc = 0; b.fill = 0; b.overflow = 0;
+  put_block_header(&b, bp);
+  return b.overflow ? 0 : (uint32_t)(b.p - out);
+}
 
-  bits_put(&b, SLAI_SYNC_CODE, 16);
-  bits_put(&b, 0, 32);                       /* size, patched below */
-  bits_put(&b, 0, 16);                       /* crc,  patched below */
-  bits_put(&b, n, 16);
-  bits_put(&b, bp->type, 2);
-  if (bp->type == SLAI_BLK_COMPRESS) {
-    for (ch = 0; ch < C; ch++) {
-      bits_put(&b, bp->rshift[ch], 4);
-      for (ord = 1; ord < O1; ord++) { bits_put(&b, fold(bp->code[ch * O1 + ord]), (ord < 4) ? 16 : 8); }
-      if (bp->pitch[ch] >= SLAI_LTM_MIN_PITCH) {
-        bits_put(&b, 1, 1);
-        bits_put(&b, bp->pitch[ch], SLAI_LTM_PERIOD_BITS);
-        for (ord = 0; ord < bp->ntaps; ord++) { bits_put(&b, fold(bp->ltm_q[ch * SLAI_MAX_TAPS + ord] >> 16), 16); }
-      } else {
-        bits_put(&b, 0, 1);
-      }
-      bits_put(&b, rp_value((rparam_t)(uint32_t)(bp->rice_init[ch] << 8)), bp->bps);
-    }
+/* Golomb modulus per channel when the block is coded with fixed parameters, 0 for adaptive mode
+ * (mean of the channels' initial parameters <= 8, reference src/SLACoder.c:443-466) */
+void slai_coding_mode(const uint32_t* rice_init, uint32_t num_channels, uint32_t* golomb_m)
+{
+  uint64_t mean = 0;
+  uint32_t ch;
+  for (ch = 0; ch < num_channels; ch++) {
+    golomb_m[ch] = rp_value((rparam_t)(uint32_t)(rice_init[ch] << 8));
+    mean += golomb_m[ch];
   }
-  bits_align(&b);
+  mean /= num_channels;
+  if (mean > SLAI_RICE_LOW_THRESHOLD) { for (ch = 0; ch < num_channels; ch++) { golomb_m[ch] = 0; } }
+}
+
+uint32_t slai_pack_block(const slai_block_params* bp, uint8_t* out, uint32_t cap)
+{
+  const uint32_t C = bp->num_channels, n = bp->num_samples;
+  uint32_t ch, s, size;
+  bits_t b;
+  if (cap < 16) { return 0; }
+  b.p = out; b.end = out + cap; b.acc = 0; b.fill = 0; b.overflow = 0;
+  put_block_header(&b, bp);
 
   if (bp->type == SLAI_BLK_RAW) {
     uint32_t width[SLAI_MAX_CHANNELS];

@@ -403,3 +403,46 @@ def test_c4_batch_of_clips(oracle, hip):
         got = enc.encode_whole(pcm)
         assert got == oracle.encode_whole(p, pcm)[1]
     enc.close()
+
+
+@pytest.mark.parametrize("kind,nch,bits,ms", [("music", 1, 16, 0), ("music", 2, 24, 1), ("white", 2, 16, 1),
+                                               ("gaps", 2, 16, 1), ("quiet", 1, 16, 0), ("spiky", 2, 16, 0)])
+def test_host_and_device_pack_agree(oracle, hip, kind, nch, bits, ms):
+    """the same analysis packed by the host threads (sla_hip_pack) and by the device kernels
+    (sla_hip_pack_device: k_rice_len / k_rice_write / k_block_crc) gives identical bytes == oracle;
+    covers adaptive recursive Rice, fixed Golomb (quiet), gamma escapes (spiky), RAW and SILENT blocks"""
+    import torch
+    n = 40000
+    if kind == "music":
+        pcm = W.music_like(nch, n, bits, seed=21)
+    elif kind == "white":
+        pcm = W.gen("white", nch, n, bits, seed=3)
+    elif kind == "gaps":
+        pcm = S.synth_pcm(nch, n, bits, gaps=True)
+        pcm[:, :3000] = 0
+    elif kind == "quiet":
+        rng = np.random.default_rng(5)
+        pcm = (rng.integers(-3, 4, (nch, n)).astype(np.int64) << 16).astype(np.int32)
+        pcm[:, ::977] = 9000 << 16                       # rare outliers in a tiny-residual block: long unary runs
+    else:
+        rng = np.random.default_rng(6)
+        x = (W.music_like(nch, n, bits, seed=2).astype(np.int64) >> 16) // 64
+        x[:, ::53] += rng.integers(-30000, 30000, x[:, ::53].shape)
+        pcm = (np.clip(x, -32768, 32767) << 16).astype(np.int32)
+    pcm = np.ascontiguousarray(pcm)
+    p = S.make_params(nch, bits, 48000, 16, 1, 8, ms, 1, 4096)
+    want = oracle.encode_whole(p, pcm)[1]
+    enc = hip.Encoder()
+    enc.set_wave_format(nch, bits, 48000)
+    enc.set_encode_parameter(16, 1, 8, ms, 1, 4096)
+    stride = (n + 63) // 64 * 64
+    d = torch.zeros((nch, stride), dtype=torch.int32, device="cuda")
+    d[:, :n] = torch.from_numpy(pcm).cuda()
+    torch.cuda.synchronize()
+    enc.analyze_device(d.data_ptr(), stride, n)
+    cap = 8 * nch * n + 65536
+    host_bytes = enc.pack(cap, on_device=False)
+    dev_bytes = enc.pack(cap, on_device=True)
+    enc.close()
+    assert host_bytes == want
+    assert dev_bytes == want
