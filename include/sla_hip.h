@@ -175,6 +175,10 @@ int sla_hip_launch_rice_write(const int32_t* d_residual, const int32_t* d_pcm, u
                               const uint8_t* d_headers, uint32_t num_channels, uint32_t raw_shift,
                               uint32_t mid_side, uint32_t* d_image, sla_hip_stream_t stream);
 
+/* int16 -> left-justified int32 (<< 16); d_in must be 8-byte aligned.  Used by the host-PCM path of
+ * SLAEncoder_EncodeWhole to halve the PCIe bytes of <= 16-bit input. */
+int sla_hip_launch_unpack16(const int16_t* d_in, int32_t* d_out, uint64_t count, sla_hip_stream_t stream);
+
 /* ---- (2) whole-file driver ---------------------------------------------- */
 
 /* Per-block results of the last analyze call, copied into caller arrays

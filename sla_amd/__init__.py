@@ -122,7 +122,7 @@ EXPORTED_SYMBOLS = [
     "SLAEncoder_EncodeHeader", "SLAEncoder_EncodeBlock", "SLAEncoder_EncodeWhole",
     # include/sla_hip.h
     "sla_hip_launch_prepass", "sla_hip_launch_lpc", "sla_hip_launch_lattice", "sla_hip_launch_tail",
-    "sla_hip_launch_ltm_acf", "sla_hip_launch_rice_len", "sla_hip_launch_rice_write", "sla_hip_pack_device",
+    "sla_hip_launch_ltm_acf", "sla_hip_launch_rice_len", "sla_hip_launch_rice_write", "sla_hip_pack_device", "sla_hip_launch_unpack16",
     "sla_hip_analyze_device", "sla_hip_pack", "sla_hip_final_residual", "sla_hip_lattice_residual",
     "sla_hip_get_trace", "sla_hip_device_name", "sla_hip_bind_residual_planes",
 ]
@@ -216,17 +216,21 @@ class Encoder:
         ptrs = (i32p * pcm.shape[0])(*[pcm[c].ctypes.data_as(i32p) for c in range(pcm.shape[0])])
         return pcm, ptrs
 
-    def encode_whole(self, pcm, capacity=None):
-        """planar left-justified int32 [C][N] on the host -> .sla bytes"""
+    def encode_whole(self, pcm, capacity=None, out=None):
+        """planar left-justified int32 [C][N] on the host -> .sla bytes.  `out`: optional preallocated
+        uint8 array to encode into (a view of it is returned instead of a bytes copy)"""
         pcm, ptrs = self._planes(pcm)
         n = pcm.shape[1]
-        cap = capacity if capacity is not None else 8 * pcm.shape[0] * n + 65536
-        out = np.zeros(cap, np.uint8)
+        if out is None:
+            cap = capacity if capacity is not None else 8 * pcm.shape[0] * n + 65536
+            buf = np.zeros(cap, np.uint8)
+        else:
+            buf, cap = out, len(out)
         size = C.c_uint32(0)
-        self._check(self._lib.SLAEncoder_EncodeWhole(self._h, ptrs, n, out.ctypes.data_as(u8p), cap, C.byref(size)),
+        self._check(self._lib.SLAEncoder_EncodeWhole(self._h, ptrs, n, buf.ctypes.data_as(u8p), cap, C.byref(size)),
                     "SLAEncoder_EncodeWhole")
         self.num_samples = n
-        return out[:size.value].tobytes()
+        return buf[:size.value] if out is not None else buf[:size.value].tobytes()
 
     def encode_block(self, pcm, capacity=None):
         pcm, ptrs = self._planes(pcm)

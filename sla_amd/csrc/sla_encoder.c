@@ -66,6 +66,7 @@ struct SLAEncoder {
   pinbuf_t h_nz, h_groups, h_cands, h_lpc_out, h_code, h_kint, h_rshift, h_chunks, h_jobs, h_fold, h_res, h_pcm, h_acf_jobs, h_acf,
            h_bgroups, h_bcands, h_blk_out, h_pk_jobs, h_pk_blocks, h_pk_hdr;
   uint32_t* h_or;
+  pinbuf_t h_stage[2]; devbuf_t d_stage[2]; hipEvent_t ev_stage[2];
 
   /* window pool: tables for every block length seen so far */
   double*   win_host; size_t win_count, win_cap;
@@ -250,6 +251,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
       || hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess
       || hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess) { free(e); return NULL; }
   for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { if (hipEventCreate(&e->ev[i]) != hipSuccess) { free(e); return NULL; } }
+  if (hipEventCreate(&e->ev_stage[0]) != hipSuccess || hipEventCreate(&e->ev_stage[1]) != hipSuccess) { free(e); return NULL; }
   e->chunks = 2;
   env = getenv("SLA_HIP_CHUNKS");
   if (env != NULL && atoi(env) > 0) { e->chunks = (uint32_t)atoi(env); }
@@ -290,6 +292,11 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   h[17] = &e->h_pk_jobs; h[18] = &e->h_pk_blocks; h[19] = &e->h_pk_hdr;
   for (i = 0; i < 20; i++) { if (h[i]->ptr != NULL) { (void)hipHostFree(h[i]->ptr); } }
   if (e->h_or != NULL) { (void)hipHostFree(e->h_or); }
+  for (i = 0; i < 2; i++) {
+    if (e->h_stage[i].ptr != NULL) { (void)hipHostFree(e->h_stage[i].ptr); }
+    if (e->d_stage[i].ptr != NULL) { (void)hipFree(e->d_stage[i].ptr); }
+    (void)hipEventDestroy(e->ev_stage[i]);
+  }
   for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { (void)hipEventDestroy(e->ev[i]); }
   (void)hipStreamDestroy(e->stream); (void)hipStreamDestroy(e->stream2); (void)hipStreamDestroy(e->stream3);
   slai_fft_plan_destroy(e->fft);
@@ -1237,6 +1244,8 @@ int sla_hip_pack(struct SLAEncoder* e, uint8_t* data, uint32_t data_size, uint32
  * Rice/Golomb/gamma coding, block assembly and CRC16 on the device.  The host only
  * packs the few header bytes of every block (it owns the per-block parameters), turns the per-channel
  * bit counts into block sizes/offsets, and writes the 43-byte file header. */
+static int download_bytes(struct SLAEncoder* e, uint8_t* dst, const uint8_t* d_src, size_t bytes);
+
 int sla_hip_pack_device(struct SLAEncoder* e, uint8_t* data, uint32_t data_size, uint32_t* output_size)
 {
   uint32_t C, O1, nb, b, ch, njobs = 0, maxblk = 0, maxbps = 0;
@@ -1345,8 +1354,7 @@ int sla_hip_pack_device(struct SLAEncoder* e, uint8_t* data, uint32_t data_size,
                                       e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS,
                                       (uint32_t*)e->d_image.ptr, e->stream));
     }
-    HIPCHK(hipMemcpyAsync(data, e->d_image.ptr, (size_t)cur, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    RCCHK(download_bytes(e, data, (const uint8_t*)e->d_image.ptr, (size_t)cur));
   }
   hinfo.wave_format = e->wave_format; hinfo.wave_format.offset_lshift = (uint8_t)e->lshift;
   hinfo.encode_param = e->encode_param; hinfo.num_samples = e->num_samples; hinfo.num_blocks = nb;
@@ -1358,18 +1366,109 @@ int sla_hip_pack_device(struct SLAEncoder* e, uint8_t* data, uint32_t data_size,
 
 /* -------------------------------------------------------------- public encode API */
 
+/* ---- PCIe path: pageable host memory <-> device through two pinned staging slots.  Host threads fill
+ * (or drain) one slot while the other one is on the bus; input of <= 16 significant bits crosses as int16. */
+#define XFER_SLOT_BYTES (8u << 20)
+#define XFER_GRAIN      (64u << 10)          /* samples / bytes per host-thread work item */
+
+typedef struct { const int32_t* src; int16_t* dst16; int32_t* dst32; size_t count; uint32_t lowbits; } stage_in_t;
+static void stage_in_one(void* vctx, uint32_t i)
+{
+  stage_in_t* c = (stage_in_t*)vctx;
+  const size_t lo = (size_t)i * XFER_GRAIN, hi = (lo + XFER_GRAIN < c->count) ? lo + XFER_GRAIN : c->count;
+  size_t k;
+  if (c->dst16 != NULL) {
+    uint32_t low = 0;
+    for (k = lo; k < hi; k++) { const int32_t v = c->src[k]; low |= (uint32_t)v & 0xFFFFu; c->dst16[k] = (int16_t)(v >> 16); }
+    if (low) { __atomic_fetch_or(&c->lowbits, low, __ATOMIC_RELAXED); }
+  } else {
+    memcpy(c->dst32 + lo, c->src + lo, sizeof(int32_t) * (hi - lo));
+  }
+}
+
+static int upload_pass(struct SLAEncoder* e, const int32_t* const* input, uint32_t n, uint64_t stride, int mode16, uint32_t* lowbits)
+{
+  extern int sla_hip_launch_unpack16(const int16_t*, int32_t*, uint64_t, sla_hip_stream_t);
+  const uint32_t C = e->wave_format.num_channels;
+  const size_t slot_samples = mode16 ? (XFER_SLOT_BYTES / 2) : (XFER_SLOT_BYTES / 4);
+  uint32_t ch, k = 0;
+  size_t o;
+  stage_in_t ctx;
+  ctx.lowbits = 0;
+  for (ch = 0; ch < C; ch++) {
+    for (o = 0; o < n; o += slot_samples, k++) {
+      const uint32_t slot = k & 1;
+      const size_t count = (n - o < slot_samples) ? (n - o) : slot_samples;
+      int32_t* dst = (int32_t*)e->d_pcm.ptr + (size_t)ch * stride + o;
+      if (k >= 2) { HIPCHK(hipEventSynchronize(e->ev_stage[slot])); }
+      ctx.src = input[ch] + o; ctx.count = count;
+      ctx.dst16 = mode16 ? (int16_t*)e->h_stage[slot].ptr : NULL;
+      ctx.dst32 = mode16 ? NULL : (int32_t*)e->h_stage[slot].ptr;
+      parallel_for(e->pool, (uint32_t)((count + XFER_GRAIN - 1) / XFER_GRAIN), stage_in_one, &ctx);
+      if (mode16) {
+        HIPCHK(hipMemcpyAsync(e->d_stage[slot].ptr, e->h_stage[slot].ptr, count * 2, hipMemcpyHostToDevice, e->stream));
+        RCCHK(sla_hip_launch_unpack16((const int16_t*)e->d_stage[slot].ptr, dst, count, e->stream));
+      } else {
+        HIPCHK(hipMemcpyAsync(dst, e->h_stage[slot].ptr, count * 4, hipMemcpyHostToDevice, e->stream));
+      }
+      HIPCHK(hipEventRecord(e->ev_stage[slot], e->stream));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  *lowbits = ctx.lowbits;
+  return 0;
+}
+
 static int upload_pcm(struct SLAEncoder* e, const int32_t* const* input, uint32_t n)
 {
   const uint32_t C = e->wave_format.num_channels;
-  uint32_t ch;
   const uint64_t stride = ((uint64_t)n + 63) & ~(uint64_t)63;
+  uint32_t ch, lowbits = 0;
+  int mode16 = (e->wave_format.bit_per_sample <= 16);
+  for (ch = 0; ch < C; ch++) { if (input[ch] == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; } }
   RCCHK(dev_reserve(&e->d_pcm, sizeof(int32_t) * (size_t)C * (stride + 64)));
-  for (ch = 0; ch < C; ch++) {
-    if (input[ch] == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
-    HIPCHK(hipMemcpyAsync((int32_t*)e->d_pcm.ptr + (size_t)ch * stride, input[ch], sizeof(int32_t) * n, hipMemcpyHostToDevice, e->stream));
+  for (ch = 0; ch < 2; ch++) {
+    RCCHK(pin_reserve(&e->h_stage[ch], XFER_SLOT_BYTES));
+    RCCHK(dev_reserve(&e->d_stage[ch], XFER_SLOT_BYTES));
   }
-  HIPCHK(hipStreamSynchronize(e->stream));
+  RCCHK(upload_pass(e, input, n, stride, mode16, &lowbits));
+  if (mode16 && lowbits != 0) {            /* not really <= 16-bit data: keep every bit, as the reference would */
+    RCCHK(upload_pass(e, input, n, stride, 0, &lowbits));
+  }
   e->pcm_dev = (const int32_t*)e->d_pcm.ptr; e->stride = stride; e->num_samples = n;
+  return 0;
+}
+
+typedef struct { const uint8_t* src; uint8_t* dst; size_t count; } stage_out_t;
+static void stage_out_one(void* vctx, uint32_t i)
+{
+  stage_out_t* c = (stage_out_t*)vctx;
+  const size_t lo = (size_t)i * XFER_GRAIN, hi = (lo + XFER_GRAIN < c->count) ? lo + XFER_GRAIN : c->count;
+  memcpy(c->dst + lo, c->src + lo, hi - lo);
+}
+
+/* device -> pageable host, double-buffered through the pinned slots */
+static int download_bytes(struct SLAEncoder* e, uint8_t* dst, const uint8_t* d_src, size_t bytes)
+{
+  size_t o, k = 0, nslots = (bytes + XFER_SLOT_BYTES - 1) / XFER_SLOT_BYTES;
+  stage_out_t ctx;
+  uint32_t s;
+  for (s = 0; s < 2; s++) { RCCHK(pin_reserve(&e->h_stage[s], XFER_SLOT_BYTES)); }
+  for (k = 0; k <= nslots; k++) {
+    if (k < nslots) {
+      o = k * XFER_SLOT_BYTES;
+      HIPCHK(hipMemcpyAsync(e->h_stage[k & 1].ptr, d_src + o, (bytes - o < XFER_SLOT_BYTES) ? (bytes - o) : XFER_SLOT_BYTES,
+                            hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipEventRecord(e->ev_stage[k & 1], e->stream));
+    }
+    if (k >= 1) {
+      o = (k - 1) * XFER_SLOT_BYTES;
+      HIPCHK(hipEventSynchronize(e->ev_stage[(k - 1) & 1]));
+      ctx.src = (const uint8_t*)e->h_stage[(k - 1) & 1].ptr; ctx.dst = dst + o;
+      ctx.count = (bytes - o < XFER_SLOT_BYTES) ? (bytes - o) : XFER_SLOT_BYTES;
+      parallel_for(e->pool, (uint32_t)((ctx.count + XFER_GRAIN - 1) / XFER_GRAIN), stage_out_one, &ctx);
+    }
+  }
   return 0;
 }
 

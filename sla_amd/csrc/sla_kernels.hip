@@ -1007,3 +1007,30 @@ extern "C" int sla_hip_launch_rice_write(const int32_t* d_residual, const int32_
   hipLaunchKernelGGL(k_block_crc, dim3((num_blocks + 63) / 64), dim3(64), 0, st, d_blocks, num_blocks, d_image);
   return hip_rc(hipGetLastError());
 }
+
+// ---------------------------------------------------------------------------------------------
+// k_unpack16: PCIe-side helper of SLAEncoder_EncodeWhole.  Input of <= 16 significant bits crosses the
+// bus as int16 (the API's left-justified int32 has 16 zero low bits, checked on the host) and is
+// re-expanded to the planar int32 layout every kernel reads.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_unpack16(const int16_t* __restrict__ in, int32_t* __restrict__ out, uint64_t count)
+{
+  const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 4 <= count) {
+    const short4 v = *reinterpret_cast<const short4*>(in + i);
+    int32_t* o = out + i;
+    o[0] = (int32_t)v.x << 16; o[1] = (int32_t)v.y << 16; o[2] = (int32_t)v.z << 16; o[3] = (int32_t)v.w << 16;
+  } else {
+    for (uint64_t k = i; k < count; k++) { out[k] = (int32_t)in[k] << 16; }
+  }
+}
+
+extern "C" int sla_hip_launch_unpack16(const int16_t* d_in, int32_t* d_out, uint64_t count, sla_hip_stream_t stream)
+{
+  if (d_in == nullptr || d_out == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (count == 0) { return 0; }
+  const uint64_t threads = (count + 3) / 4;
+  hipLaunchKernelGGL(k_unpack16, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_in, d_out, count);
+  return hip_rc(hipGetLastError());
+}
