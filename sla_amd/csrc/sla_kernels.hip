@@ -485,81 +485,95 @@ void k_tail(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, u
 // ---------------------------------------------------------------------------------------------
 #define ACF_THREADS 512
 
-__device__ __forceinline__ void acf_stages(double* z, uint32_t log2npts, const double* __restrict__ twr,
+// LDS layout: complex slot c (re, im = 16 B, always moved as one b128 access) lives at slot c ^ S(c), where
+// S folds the higher nibbles of c into the low one.  Every access pattern of a power-of-two FFT is
+// "base + j * 2^s": without the fold all 16 lanes of an access group hit the same 4 banks (measured: 13
+// bank-conflict cycles per LDS instruction); with it the 16 lanes land on 16 different slots for s >= 4
+// and for the bit-reversed scatter.
+__device__ __forceinline__ uint32_t acf_sw(uint32_t c) { return c ^ (((c >> 4) ^ (c >> 8) ^ (c >> 12)) & 15u); }
+
+__device__ __forceinline__ void acf_stages(double2* z, uint32_t log2npts, const double* __restrict__ twr,
                                            const double* __restrict__ twi)
 {
   const uint32_t npts = 1u << log2npts;
   uint32_t log2h = 0;
-  for (uint32_t mmax = 2; mmax < 2 * npts; mmax <<= 1, log2h++) {
-    const uint32_t h = mmax >> 1, base = h - 1;
+  for (uint32_t h = 1; h < npts; h <<= 1, log2h++) {          // h = half-span in complex points
+    const uint32_t base = h - 1;
     for (uint32_t b = threadIdx.x; b < (npts >> 1); b += ACF_THREADS) {
       const uint32_t k = b & (h - 1), blk = b >> log2h;
-      const uint32_t i = 2 * k + blk * 2 * mmax, q = i + mmax;
+      const uint32_t ci = k + blk * 2 * h, cq = ci + h;
       const double wr = twr[base + k], wi = twi[base + k];
-      const double zq0 = z[q], zq1 = z[q + 1], zi0 = z[i], zi1 = z[i + 1];
-      const double tr = wr * zq0 - wi * zq1;
-      const double ti = wr * zq1 + wi * zq0;
-      z[q] = zi0 - tr;
-      z[q + 1] = zi1 - ti;
-      z[i] = zi0 + tr;
-      z[i + 1] = zi1 + ti;
+      const double2 zq = z[acf_sw(cq)], zi = z[acf_sw(ci)];
+      const double tr = wr * zq.x - wi * zq.y;
+      const double ti = wr * zq.y + wi * zq.x;
+      z[acf_sw(cq)] = make_double2(zi.x - tr, zi.y - ti);
+      z[acf_sw(ci)] = make_double2(zi.x + tr, zi.y + ti);
     }
     __syncthreads();
   }
 }
 
-// the h1/h2 recombination pass shared by the forward and the inverse real transform
-__device__ __forceinline__ void acf_real_pass(double* d, uint32_t F, double c2, const double* __restrict__ rtr,
+// the h1/h2 recombination pass shared by the forward and the inverse real transform; complex slot i-1
+// holds the reference's (data[i1], data[i2]), slot npts-(i-1) its (data[i3], data[i4])
+__device__ __forceinline__ void acf_real_pass(double2* z, uint32_t npts, double c2, const double* __restrict__ rtr,
                                               const double* __restrict__ rti)
 {
   const double c1 = 0.5;
-  for (uint32_t i = 2 + threadIdx.x; i <= (F >> 2); i += ACF_THREADS) {
-    const uint32_t i1 = 2 * i - 2, i2 = i1 + 1, i3 = F - i1, i4 = i3 + 1;
+  for (uint32_t i = 2 + threadIdx.x; i <= (npts >> 1); i += ACF_THREADS) {
+    const uint32_t ca = i - 1, cb = npts - (i - 1);
     const double wr = rtr[i - 2], wi = rti[i - 2];
-    const double a1 = d[i1], a2 = d[i2], a3 = d[i3], a4 = d[i4];
-    const double h1r = c1 * (a1 + a3);
-    const double h1i = c1 * (a2 - a4);
-    const double h2r = -c2 * (a2 + a4);
-    const double h2i = c2 * (a1 - a3);
-    d[i1] = h1r + wr * h2r - wi * h2i;
-    d[i2] = h1i + wr * h2i + wi * h2r;
-    d[i3] = h1r - wr * h2r + wi * h2i;
-    d[i4] = -h1i + wr * h2i + wi * h2r;
+    const double2 A = z[acf_sw(ca)], B = z[acf_sw(cb)];
+    const double h1r = c1 * (A.x + B.x);
+    const double h1i = c1 * (A.y - B.y);
+    const double h2r = -c2 * (A.y + B.y);
+    const double h2i = c2 * (A.x - B.x);
+    z[acf_sw(ca)] = make_double2(h1r + wr * h2r - wi * h2i, h1i + wr * h2i + wi * h2r);
+    z[acf_sw(cb)] = make_double2(h1r - wr * h2r + wi * h2i, -h1i + wr * h2i + wi * h2r);
   }
 }
 
-// Pitch candidate from the autocorrelation, a one-pass restatement of the reference's nested scans
-// (src/SLAPredictor.c:866-924): segments run from an upward zero crossing to the next downward one
-// (inclusive, capped at lag 256; a search that reaches 256 inspects lags 256 and 257), each segment
-// contributes its largest strict local maximum, and the earliest of the globally largest wins.
-// Every element is read once and the read address never depends on the scan state.
-__device__ __forceinline__ void acf_pick(const double* d, uint32_t& chosen, uint32_t& ncand)
+__device__ __forceinline__ double acf_at(const double2* z, uint32_t j)      // real element j of the array
 {
-  double top = 0.0, val = 0.0, prev = d[0], cur = d[1];
-  uint32_t start = 0, arg = 0;
-  bool in_seg = false, done = false;
+  const double2 v = z[acf_sw(j >> 1)];
+  return (j & 1u) ? v.y : v.x;
+}
+
+// Pitch candidate from the autocorrelation (reference src/SLAPredictor.c:866-924): segments run from an
+// upward zero crossing to the next downward one (inclusive, capped at lag 256; a search that reaches 256
+// inspects lags 256 and 257), each segment contributes its largest strict positive local maximum, and the
+// earliest of the globally largest wins.  The three per-lag predicates are evaluated by 320 threads and
+// ballotted into bit masks; one lane then hops from crossing to crossing with find-first-set and only
+// touches the values of local maxima.
+#define ACF_PICK_LAGS 320
+
+__device__ __forceinline__ uint32_t first_set_from(const unsigned long long* m, uint32_t pos, uint32_t limit)
+{
+  while (pos < limit) {
+    const unsigned long long w = m[pos >> 6] >> (pos & 63);
+    if (w != 0) {
+      const uint32_t hit = pos + (uint32_t)__builtin_ctzll(w);
+      return (hit < limit) ? hit : limit;
+    }
+    pos = (pos | 63u) + 1u;
+  }
+  return limit;
+}
+
+__device__ __forceinline__ void acf_pick(const double* v, const unsigned long long* up, const unsigned long long* down,
+                                         const unsigned long long* lm, uint32_t& chosen, uint32_t& ncand)
+{
+  double top = 0.0;
+  uint32_t i = 1;
   chosen = 0; ncand = 0;
-  for (uint32_t j = 1; j <= 257 && !done; j++) {
-    const double next = d[j + 1];
-    if (!in_seg) {
-      if (j < 256) {
-        if (prev < 0.0 && cur > 0.0) { in_seg = true; start = j; arg = 0; val = 0.0; }
-      } else {
-        in_seg = true; start = 256; arg = 0; val = 0.0;
-      }
+  while (i < 256) {
+    uint32_t start = first_set_from(up, i, 256), end, arg = 0;
+    double val = 0.0;
+    end = (start < 256) ? first_set_from(down, start + 1, 256) : 257;
+    for (uint32_t j = first_set_from(lm, start, end + 1); j <= end; j = first_set_from(lm, j + 1, end + 1)) {
+      if (v[j] > val) { arg = j; val = v[j]; }
     }
-    if (in_seg) {
-      if (cur > prev && cur > next && cur > val) { arg = j; val = cur; }
-      bool is_end;
-      if (start == 256) { is_end = (j == 257); }
-      else { is_end = (j >= start + 1) && ((j < 256) ? (cur > 0.0 && next < 0.0) : true); }
-      if (is_end) {
-        if (arg != 0) { ncand++; if (val > top) { top = val; chosen = arg; } }
-        in_seg = false;
-        if (j + 1 >= 256) { done = true; }
-      }
-    }
-    prev = cur; cur = next;
+    if (arg != 0) { ncand++; if (val > top) { top = val; chosen = arg; } }
+    i = end + 1;
   }
 }
 
@@ -567,11 +581,13 @@ template <bool IN_LDS>
 __global__ __launch_bounds__(ACF_THREADS)
 void k_ltm_acf(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_acf_job* __restrict__ jobs,
                uint32_t njobs, uint32_t log2F, const double* __restrict__ tw, double* __restrict__ scratch,
-               double* __restrict__ out, uint32_t head)
+               double* __restrict__ out, uint32_t head, uint32_t dbg_skip)
 {
-  extern __shared__ double lds[];
+  extern __shared__ double2 lds2[];
+  __shared__ double s_acf[ACF_PICK_LAGS];
+  __shared__ unsigned long long s_mask[3][ACF_PICK_LAGS / 64];
   const uint32_t F = 1u << log2F, npts = F >> 1, log2npts = log2F - 1;
-  double* d = IN_LDS ? lds : (scratch + (uint64_t)blockIdx.x * F);
+  double2* z = IN_LDS ? lds2 : reinterpret_cast<double2*>(scratch + (uint64_t)blockIdx.x * F);
   const double* twr_f = tw;            const double* twi_f = tw + (F >> 1);
   const double* twr_i = tw + F;        const double* twi_i = tw + F + (F >> 1);
   const double* rtr_f = tw + 2 * F;    const double* rti_f = rtr_f + (F >> 2);
@@ -585,61 +601,68 @@ void k_ltm_acf(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_a
     // load, zero-padded, straight into bit-reversed complex order
     for (uint32_t k = threadIdx.x; k < npts; k += ACF_THREADS) {
       const uint32_t j = __brev(k) >> (32 - log2npts);
-      d[2 * j]     = (2 * k < n)     ? (double)src[2 * k] * scale     : 0.0;
-      d[2 * j + 1] = (2 * k + 1 < n) ? (double)src[2 * k + 1] * scale : 0.0;
+      z[acf_sw(j)] = make_double2((2 * k < n) ? (double)src[2 * k] * scale : 0.0,
+                                  (2 * k + 1 < n) ? (double)src[2 * k + 1] * scale : 0.0);
     }
     __syncthreads();
-    acf_stages(d, log2npts, twr_f, twi_f);
-    acf_real_pass(d, F, -0.5, rtr_f, rti_f);
+    if (!(dbg_skip & 1)) { acf_stages(z, log2npts, twr_f, twi_f); }
+    if (!(dbg_skip & 8)) { acf_real_pass(z, npts, -0.5, rtr_f, rti_f); }
     __syncthreads();
     if (threadIdx.x == 0) {
-      const double h = d[0];
-      const double s0 = h + d[1], s1 = h - d[1];
-      d[0] = s0 * s0;                    // DC and Nyquist power
-      d[1] = s1 * s1;
+      const double2 v = z[0];
+      const double s0 = v.x + v.y, s1 = v.x - v.y;
+      z[0] = make_double2(s0 * s0, s1 * s1);           // DC and Nyquist power
     }
     for (uint32_t i = 1 + threadIdx.x; i < npts; i += ACF_THREADS) {
-      const double re = d[2 * i], im = d[2 * i + 1];
-      d[2 * i] = re * re + im * im;
-      d[2 * i + 1] = 0.0;
+      const double2 v = z[acf_sw(i)];
+      z[acf_sw(i)] = make_double2(v.x * v.x + v.y * v.y, 0.0);
     }
     __syncthreads();
-    acf_real_pass(d, F, 0.5, rtr_i, rti_i);
+    if (!(dbg_skip & 8)) { acf_real_pass(z, npts, 0.5, rtr_i, rti_i); }
     __syncthreads();
     if (threadIdx.x == 0) {
-      const double h = d[0], g = d[1];
-      d[0] = 0.5 * (h + g);
-      d[1] = 0.5 * (h - g);
+      const double2 v = z[0];
+      z[0] = make_double2(0.5 * (v.x + v.y), 0.5 * (v.x - v.y));
     }
     __syncthreads();
     // in-place bit reversal, then the inverse stages
     for (uint32_t k = threadIdx.x; k < npts; k += ACF_THREADS) {
       const uint32_t j = __brev(k) >> (32 - log2npts);
       if (j > k) {
-        const double a = d[2 * k], b = d[2 * k + 1];
-        d[2 * k] = d[2 * j]; d[2 * k + 1] = d[2 * j + 1];
-        d[2 * j] = a; d[2 * j + 1] = b;
+        const double2 a = z[acf_sw(k)], b = z[acf_sw(j)];
+        z[acf_sw(k)] = b; z[acf_sw(j)] = a;
       }
     }
     __syncthreads();
-    acf_stages(d, log2npts, twr_i, twi_i);
+    if (!(dbg_skip & 2)) { acf_stages(z, log2npts, twr_i, twi_i); }
     if (head == SLA_HIP_ACF_RECORD) {
       // compact record: {code, chosen lag, acf[0..4], acf[chosen-2..chosen+2]}; the Toeplitz solve (x87
       // long double in the reference) is left to the host
+      __syncthreads();
+      if (threadIdx.x < ACF_PICK_LAGS) {
+        const uint32_t j = threadIdx.x;
+        const double vc = acf_at(z, j), vm = (j >= 1) ? acf_at(z, j - 1) : 0.0, vp = acf_at(z, j + 1);
+        s_acf[j] = vc;
+        const unsigned long long bu = __ballot(j >= 1 && j < 256 && vm < 0.0 && vc > 0.0);
+        const unsigned long long bd = __ballot(j >= 1 && j < 256 && vc > 0.0 && vp < 0.0);
+        const unsigned long long bl = __ballot(j >= 1 && j <= 257 && vc > vm && vc > vp && vc > 0.0);
+        if ((j & 63) == 0) { s_mask[0][j >> 6] = bu; s_mask[1][j >> 6] = bd; s_mask[2][j >> 6] = bl; }
+      }
+      __syncthreads();
       if (threadIdx.x == 0) {
         double* o = out + (uint64_t)job * SLA_HIP_ACF_RECORD;
         uint32_t chosen = 0, ncand = 0;
         double code = 0.0;                                   // 0: silent block
-        if (fabs(d[0]) > (double)FLT_MIN) {
-          acf_pick(d, chosen, ncand);
+        if (fabs(s_acf[0]) > (double)FLT_MIN && !(dbg_skip & 4)) {
+          acf_pick(s_acf, s_mask[0], s_mask[1], s_mask[2], chosen, ncand);
           code = (ncand == 0) ? 2.0 : 1.0;                   // 2: no pitch candidate
         }
         o[0] = code; o[1] = (double)chosen;
-        for (uint32_t k = 0; k < 5; k++) { o[2 + k] = d[k]; }
-        for (uint32_t k = 0; k < 5; k++) { o[7 + k] = (chosen + k >= 2) ? d[chosen + k - 2] : 0.0; }
+        for (uint32_t k = 0; k < 5; k++) { o[2 + k] = s_acf[k]; }
+        for (uint32_t k = 0; k < 5; k++) { o[7 + k] = (chosen + k >= 2) ? s_acf[chosen + k - 2] : 0.0; }
       }
     } else {
-      for (uint32_t t = threadIdx.x; t < head; t += ACF_THREADS) { out[(uint64_t)job * head + t] = d[t]; }
+      for (uint32_t t = threadIdx.x; t < head; t += ACF_THREADS) { out[(uint64_t)job * head + t] = acf_at(z, t); }
     }
     __syncthreads();
   }
@@ -741,17 +764,18 @@ extern "C" int sla_hip_launch_ltm_acf(const int32_t* d_residual, uint64_t plane_
   uint32_t log2F = 0;
   while ((1u << log2F) < fft_size) { log2F++; }
   hipStream_t st = (hipStream_t)stream;
+  const uint32_t dbg = (uint32_t)(getenv("SLA_HIP_ACF_SKIP") ? atoi(getenv("SLA_HIP_ACF_SKIP")) : 0);
   const size_t lds = sizeof(double) * (size_t)fft_size;
   if (lds <= SLA_HIP_LDS_BUDGET) {
     hipError_t e = hipFuncSetAttribute((const void*)k_ltm_acf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { return hip_rc(e); }
     hipLaunchKernelGGL(k_ltm_acf<true>, dim3(num_jobs), dim3(ACF_THREADS), lds, st, d_residual, plane_stride, d_jobs, num_jobs,
-                       log2F, d_twiddles, (double*)nullptr, d_acf_head, head);
+                       log2F, d_twiddles, (double*)nullptr, d_acf_head, head, dbg);
   } else {
     if (d_scratch == nullptr || scratch_slots == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
     uint32_t grid = (num_jobs < scratch_slots) ? num_jobs : scratch_slots;
     hipLaunchKernelGGL(k_ltm_acf<false>, dim3(grid), dim3(ACF_THREADS), 0, st, d_residual, plane_stride, d_jobs, num_jobs,
-                       log2F, d_twiddles, d_scratch, d_acf_head, head);
+                       log2F, d_twiddles, d_scratch, d_acf_head, head, dbg);
   }
   return hip_rc(hipGetLastError());
 }

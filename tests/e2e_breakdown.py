@@ -24,5 +24,11 @@ for rep in range(3):
     b = enc.pack(cap, on_device=False); t3 = time.perf_counter()
     c = enc.encode_whole(pcm); t4 = time.perf_counter()
     assert a == b == c
+    if rep == 0:
+        outbuf = np.zeros(cap, np.uint8)
+        enc.encode_whole(pcm, out=outbuf)
+    t5 = time.perf_counter(); v = enc.encode_whole(pcm, out=outbuf); t6 = time.perf_counter()
+    assert bytes(v) == a
+    print("   encode_whole into a reused output buffer: %.2f ms = %.0f Msamples/s" % ((t6 - t5) * 1e3, n / (t6 - t5) / 1e6))
     print("n=%d analyze %.2f ms | device pack %.2f ms | host pack %.2f ms | encode_whole (H2D+analyze+device pack) %.2f ms = %.0f Msamples/s"
           % (n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, n / (t4 - t3) / 1e6))
