@@ -880,39 +880,55 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
   return 0;
 }
 
+typedef struct { struct SLAEncoder* e; uint32_t blk_lo; } raw_ctx_t;
+
+/* copy one block's device results into the encoder and decide COMPRESS vs RAW */
+static void raw_one(void* vctx, uint32_t rel)
+{
+  raw_ctx_t* c = (raw_ctx_t*)vctx;
+  struct SLAEncoder* e = c->e;
+  const uint32_t b = c->blk_lo + rel;
+  const uint32_t C = e->wave_format.num_channels, bps = e->wave_format.bit_per_sample;
+  const uint32_t order = e->encode_param.parcor_order, O1 = order + 1, O2 = order + 2;
+  blk_t* blk = &e->blk[b];
+  uint32_t ch;
+  if (blk->type == SLAI_BLK_SILENT) { return; }
+  for (ch = 0; ch < C; ch++) {
+    const size_t slot = (size_t)b * C + ch;
+    const double* o = (const double*)e->h_blk_out.ptr + slot * O2;
+    double est;
+    memcpy(e->parcor + slot * O1, o + 1, sizeof(double) * O1);
+    memcpy(e->code + slot * O1, (const int32_t*)e->h_code.ptr + slot * O1, sizeof(int32_t) * O1);
+    memcpy(e->kint + slot * O1, (const int32_t*)e->h_kint.ptr + slot * O1, sizeof(int32_t) * O1);
+    e->bc[slot].rshift = ((const uint32_t*)e->h_rshift.ptr)[slot];
+    est = slai_code_length(o[0], blk->nsmpl, bps, o + 1, order);
+    est = (8 * est) / bps;
+    if (est >= SLAI_RAW_THRESHOLD) { blk->type = SLAI_BLK_RAW; break; }
+  }
+}
+
 /* host + stage 3 of chunk c: RAW decision, long-term solve, then k_tail */
 static int tail_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
 {
   chunk_t* k = &a->ck[c];
-  const uint32_t C = e->wave_format.num_channels, bps = e->wave_format.bit_per_sample;
-  const uint32_t order = e->encode_param.parcor_order, O1 = order + 1, O2 = order + 2;
+  const uint32_t C = e->wave_format.num_channels;
   const uint32_t ntaps = e->encode_param.longterm_order, lms = e->encode_param.lms_order_per_filter;
   sla_hip_tail_job* jobs = (sla_hip_tail_job*)e->h_jobs.ptr;
   hipEvent_t* ev = a->ev + (size_t)c * EV_PER_CHUNK;
   uint32_t b, ch, j, t, nj;
 
   k->job_lo = a->njobs;
-  /* RAW decision per block: any channel's estimate >= 0.95        src/SLAEncoder.c:553-565 */
+  /* RAW decision per block (any channel's estimate >= 0.95, src/SLAEncoder.c:553-565) on the host threads */
+  {
+    raw_ctx_t rc;
+    rc.e = e; rc.blk_lo = k->blk_lo;
+    parallel_for(e->pool, k->blk_hi - k->blk_lo, raw_one, &rc);
+  }
   for (b = k->blk_lo; b < k->blk_hi; b++) {
-    blk_t* blk = &e->blk[b];
-    if (blk->type == SLAI_BLK_SILENT) { continue; }
+    if (e->blk[b].type != SLAI_BLK_COMPRESS) { continue; }
     for (ch = 0; ch < C; ch++) {
-      const size_t slot = (size_t)b * C + ch;
-      const double* o = (const double*)e->h_blk_out.ptr + slot * O2;
-      double est;
-      memcpy(e->parcor + slot * O1, o + 1, sizeof(double) * O1);
-      memcpy(e->code + slot * O1, (const int32_t*)e->h_code.ptr + slot * O1, sizeof(int32_t) * O1);
-      memcpy(e->kint + slot * O1, (const int32_t*)e->h_kint.ptr + slot * O1, sizeof(int32_t) * O1);
-      e->bc[slot].rshift = ((const uint32_t*)e->h_rshift.ptr)[slot];
-      est = slai_code_length(o[0], blk->nsmpl, bps, o + 1, order);
-      est = (8 * est) / bps;
-      if (est >= SLAI_RAW_THRESHOLD) { blk->type = SLAI_BLK_RAW; break; }
-    }
-    if (blk->type == SLAI_BLK_COMPRESS) {
-      for (ch = 0; ch < C; ch++) {
-        a->job_blk[a->njobs] = b; a->job_ch[a->njobs] = ch; a->job_grp[a->njobs] = a->grp_of_slot[(size_t)b * C + ch];
-        a->njobs++;
-      }
+      a->job_blk[a->njobs] = b; a->job_ch[a->njobs] = ch; a->job_grp[a->njobs] = a->grp_of_slot[(size_t)b * C + ch];
+      a->njobs++;
     }
   }
   k->job_hi = a->njobs;

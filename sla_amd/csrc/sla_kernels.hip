@@ -98,12 +98,23 @@ void k_prepass(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t nch, u
 
 __device__ __forceinline__ double chain_lag0(const double* __restrict__ xs, uint32_t n)
 {
+  // software pipelined: the next CHAIN_U operands are requested before the current ones are summed (the
+  // LDS queue of a CU is kept busy by the gather loads of the lag chains, so a request can take long)
   double acc = 0.0;
   uint32_t i = 0;
-  for (; i + CHAIN_U <= n; i += CHAIN_U) {
+  if (n >= CHAIN_U) {
     double v[CHAIN_U];
 #pragma unroll
-    for (int u = 0; u < CHAIN_U; u++) { v[u] = xs[i + u]; }
+    for (int u = 0; u < CHAIN_U; u++) { v[u] = xs[u]; }
+    for (i = CHAIN_U; i + CHAIN_U <= n; i += CHAIN_U) {
+      double w[CHAIN_U];
+#pragma unroll
+      for (int u = 0; u < CHAIN_U; u++) { w[u] = xs[i + u]; }
+#pragma unroll
+      for (int u = 0; u < CHAIN_U; u++) { acc += v[u] * v[u]; }
+#pragma unroll
+      for (int u = 0; u < CHAIN_U; u++) { v[u] = w[u]; }
+    }
 #pragma unroll
     for (int u = 0; u < CHAIN_U; u++) { acc += v[u] * v[u]; }
   }
@@ -154,46 +165,77 @@ __device__ __forceinline__ int32_t f64_to_i32_x86(double v)
   return (int32_t)v;
 }
 
+#define LPC_MAX_PACK 4      // windows ("groups") one workgroup stages side by side
+
+// A workgroup takes `pack` consecutive groups: their windows sit next to each other in LDS and their
+// (candidate, lag) chains are numbered through, so that one wave-instruction of the chain loop carries
+// up to 64 busy lanes even when a single group has only a few chains (chosen blocks: `order` chains).
+// The chain loop is bound by FP64 / LDS issue per WAVE, not per lane, so lanes are what has to be filled.
 __global__ __launch_bounds__(256)
 void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
-           const sla_hip_lpc_group* __restrict__ groups, const sla_hip_lpc_cand* __restrict__ cands,
+           const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, uint32_t pack,
+           const sla_hip_lpc_cand* __restrict__ cands,
            const double* __restrict__ window_pool, double* __restrict__ out,
            int32_t* __restrict__ out_code, int32_t* __restrict__ out_kint, uint32_t* __restrict__ out_rshift,
            uint32_t x_region, uint32_t dbg_skip)
 {
   extern __shared__ double lds[];
-  const sla_hip_lpc_group g = groups[blockIdx.x];
-  const uint32_t W = g.num_samples, nc = g.cand_count, O1 = order + 1, O2 = order + 2;
-  double* x = lds;                 // [x_region]: staged samples; re-used as Levinson scratch afterwards
-  double* r = x + x_region;        // [nc*O1]
-  double* av = x;                  // [nc*O2] overlay (x is dead once every chain has finished)
-  double* vv = x + nc * O2;        // [nc*O2] overlay
-  const sla_hip_lpc_cand* cd = cands + g.cand_first;
-  const bool windowed = (g.win_off != SLA_HIP_NO_WINDOW);
-  const double* win = window_pool + (windowed ? g.win_off : 0);
-  __shared__ uint32_t s_maxabs[4];
-
-  // ---- stage the window (A0 + A4): convert, mid/side, window, pre-emphasis --------------------
-  uint32_t maxabs = 0;
-  for (uint32_t s = threadIdx.x; s < W; s += blockDim.x) {
-    double cur = load_f64(pcm, stride, ms, g.channel, g.pcm_off + s);
-    if (windowed) {
-      cur *= win[s];
-      double prev = (s > 0) ? load_f64(pcm, stride, ms, g.channel, g.pcm_off + s - 1) * win[s - 1] : 0.0;
-      cur -= prev * 0.96875;        // (2^5-1)*2^-5, src/SLAPredictor.c:1803-1809
-    }
-    x[s] = cur;
-    if (out_code != nullptr) {
-      int32_t v = load_int(pcm, stride, ms, g.channel, g.pcm_off + s, g.int_shift);
-      uint32_t a = (v > 0) ? (uint32_t)v : (0u - (uint32_t)v);
-      maxabs = (a > maxabs) ? a : maxabs;
-    }
-  }
-  if (out_code != nullptr) {
-    maxabs = umax_wave(maxabs);
-    if ((threadIdx.x & 63) == 0) { s_maxabs[threadIdx.x >> 6] = maxabs; }
+  __shared__ sla_hip_lpc_group s_g[LPC_MAX_PACK];
+  __shared__ uint32_t s_coff[LPC_MAX_PACK + 1];      // running candidate count
+  __shared__ uint32_t s_maxabs[LPC_MAX_PACK];
+  const uint32_t O1 = order + 1, O2 = order + 2;
+  const uint32_t g0 = blockIdx.x * pack;
+  const uint32_t ng = (num_groups - g0 < pack) ? (num_groups - g0) : pack;
+  if (threadIdx.x < LPC_MAX_PACK) {
+    if (threadIdx.x < ng) { s_g[threadIdx.x] = groups[g0 + threadIdx.x]; }
+    s_maxabs[threadIdx.x] = 0;
   }
   __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (uint32_t k = 0; k < ng; k++) { s_coff[k] = acc; acc += s_g[k].cand_count; }
+    for (uint32_t k = ng; k <= LPC_MAX_PACK; k++) { s_coff[k] = acc; }
+  }
+  __syncthreads();
+  const uint32_t nc = s_coff[ng];                    // candidates of the whole pack
+  double* r = lds + (size_t)pack * x_region;         // [nc*O1] after the windows
+  double* av = lds;                                  // [nc*O2] overlay (windows are dead once every chain finished)
+  double* vv = lds + (size_t)nc * O2;                // [nc*O2] overlay
+
+  // ---- stage the windows (A0 + A4): convert, mid/side, window, pre-emphasis -------------------
+  for (uint32_t k = 0; k < ng; k++) {
+    const sla_hip_lpc_group g = s_g[k];
+    double* x = lds + (size_t)k * x_region;
+    const bool windowed = (g.win_off != SLA_HIP_NO_WINDOW);
+    const double* win = window_pool + (windowed ? g.win_off : 0);
+    uint32_t maxabs = 0;
+    for (uint32_t s = threadIdx.x; s < g.num_samples; s += blockDim.x) {
+      double cur = load_f64(pcm, stride, ms, g.channel, g.pcm_off + s);
+      if (windowed) {
+        cur *= win[s];
+        double prev = (s > 0) ? load_f64(pcm, stride, ms, g.channel, g.pcm_off + s - 1) * win[s - 1] : 0.0;
+        cur -= prev * 0.96875;        // (2^5-1)*2^-5, src/SLAPredictor.c:1803-1809
+      }
+      x[s] = cur;
+      if (out_code != nullptr) {
+        int32_t v = load_int(pcm, stride, ms, g.channel, g.pcm_off + s, g.int_shift);
+        uint32_t a = (v > 0) ? (uint32_t)v : (0u - (uint32_t)v);
+        maxabs = (a > maxabs) ? a : maxabs;
+      }
+    }
+    if (out_code != nullptr) {
+      maxabs = umax_wave(maxabs);
+      if ((threadIdx.x & 63) == 0) { atomicMax(&s_maxabs[k], maxabs); }
+    }
+  }
+  __syncthreads();
+
+  // pack-wide candidate index -> (group k, candidate entry)
+  auto locate = [&](uint32_t cidx, uint32_t& k) -> const sla_hip_lpc_cand* {
+    k = 0;
+    while (k + 1 < ng && cidx >= s_coff[k + 1]) { k++; }
+    return cands + s_g[k].cand_first + (cidx - s_coff[k]);
+  };
 
   // ---- autocorrelation chains -----------------------------------------------------------------
   // waves 0..2 walk the lag >= 1 chains, wave 3 the lag-0 (energy) chains.  (Measured on C2: running the
@@ -203,24 +245,32 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
   } else if (threadIdx.x < 192) {
     const uint32_t nchains = nc * order;
     for (uint32_t q = threadIdx.x; q < nchains; q += 192) {
-      const uint32_t c = q / order, lag = 1 + (q - c * order);
-      const uint32_t n = cd[c].len;
-      r[c * O1 + lag] = (dbg_skip & 8) ? 0.0 : ((lag < n) ? chain_lag(x + cd[c].start, n, lag) : 0.0);
+      const uint32_t cidx = q / order, lag = 1 + (q - cidx * order);
+      uint32_t k;
+      const sla_hip_lpc_cand* cd = locate(cidx, k);
+      const uint32_t n = cd->len;
+      const double* xs = lds + (size_t)k * x_region + cd->start;
+      r[cidx * O1 + lag] = (dbg_skip & 8) ? 0.0 : ((lag < n) ? chain_lag(xs, n, lag) : 0.0);
     }
   } else {
-    for (uint32_t c = threadIdx.x - 192; c < nc; c += 64) {
-      r[c * O1] = (dbg_skip & 4) ? 1.0 : chain_lag0(x + cd[c].start, cd[c].len);
+    for (uint32_t cidx = threadIdx.x - 192; cidx < nc; cidx += 64) {
+      uint32_t k;
+      const sla_hip_lpc_cand* cd = locate(cidx, k);
+      r[cidx * O1] = (dbg_skip & 4) ? 1.0 : chain_lag0(lds + (size_t)k * x_region + cd->start, cd->len);
     }
   }
   __syncthreads();
 
-  // ---- Levinson-Durbin, one thread per candidate ----------------------------------------------
-  for (uint32_t c = threadIdx.x; c < nc && !(dbg_skip & 2); c += blockDim.x) {
-    const uint32_t n = cd[c].len;
-    const double* rc = r + c * O1;
-    double* a = av + c * O2;
-    double* v = vv + c * O2;
-    double* o = out + (uint64_t)(g.slot_first + c) * O2;
+  // ---- Levinson-Durbin (+ quantiser for chosen blocks), one thread per candidate ----------------
+  for (uint32_t cidx = threadIdx.x; cidx < nc && !(dbg_skip & 2); cidx += blockDim.x) {
+    uint32_t k;
+    const sla_hip_lpc_cand* cd = locate(cidx, k);
+    const uint32_t n = cd->len;
+    const uint64_t slot = (uint64_t)s_g[k].slot_first + (cidx - s_coff[k]);
+    const double* rc = r + cidx * O1;
+    double* a = av + cidx * O2;
+    double* v = vv + cidx * O2;
+    double* o = out + slot * O2;
     o[0] = rc[0];
     if (n < order || fabs(rc[0]) < (double)FLT_EPSILON) {
       for (uint32_t i = 0; i < O1; i++) { o[1 + i] = 0.0; }
@@ -243,30 +293,25 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
         o[2 + d] = -gamma;
       }
     }
-  }
-
-  // ---- coefficient quantiser (chosen blocks only: one candidate per group); serial in the
-  //      thread that ran the recursion, so it reads its own stores ------------------------------
-  if (out_code != nullptr && threadIdx.x == 0) {
-    uint32_t m = s_maxabs[0];
-    for (uint32_t w = 1; w < (blockDim.x >> 6); w++) { m = (s_maxabs[w] > m) ? s_maxabs[w] : m; }
-    // bit width = ceil(log2(max|x|)) + 1, at least 1                  src/SLAUtility.c:677-696
-    const uint32_t l2c = (m > 1) ? (32u - (uint32_t)__builtin_clz(m - 1u)) : 0u;
-    const uint32_t bitwidth = (m > 0) ? (l2c + 1u) : 1u;
-    const uint32_t rshift = (bitwidth > 16) ? (bitwidth - 16) : 0;
-    const uint64_t slot = g.slot_first;
-    const double* o = out + slot * O2;
-    out_rshift[slot] = rshift; out_code[slot * O1] = 0; out_kint[slot * O1] = 0;
-    for (uint32_t ord = 1; ord <= order; ord++) {
-      const uint32_t q = (ord < 4) ? 16 : 8;
-      const int32_t lim = 1 << (q - 1);
-      double k = o[1 + ord] * (double)lim;
-      double rk = (k >= 0.0) ? floor(k + 0.5) : -floor(-k + 0.5);
-      int32_t code = f64_to_i32_x86(rk);
-      code = (code < -lim) ? -lim : code;
-      code = (code > lim - 1) ? (lim - 1) : code;
-      out_code[slot * O1 + ord] = code;
-      out_kint[slot * O1 + ord] = (int32_t)((uint32_t)code << (16u - q)) >> rshift;
+    // coefficient quantiser (chosen blocks: one candidate per group); the thread reads its own stores
+    if (out_code != nullptr) {
+      const uint32_t m = s_maxabs[k];
+      // bit width = ceil(log2(max|x|)) + 1, at least 1                  src/SLAUtility.c:677-696
+      const uint32_t l2c = (m > 1) ? (32u - (uint32_t)__builtin_clz(m - 1u)) : 0u;
+      const uint32_t bitwidth = (m > 0) ? (l2c + 1u) : 1u;
+      const uint32_t rshift = (bitwidth > 16) ? (bitwidth - 16) : 0;
+      out_rshift[slot] = rshift; out_code[slot * O1] = 0; out_kint[slot * O1] = 0;
+      for (uint32_t ord = 1; ord <= order; ord++) {
+        const uint32_t q = (ord < 4) ? 16 : 8;
+        const int32_t lim = 1 << (q - 1);
+        double kq = o[1 + ord] * (double)lim;
+        double rk = (kq >= 0.0) ? floor(kq + 0.5) : -floor(-kq + 0.5);
+        int32_t code = f64_to_i32_x86(rk);
+        code = (code < -lim) ? -lim : code;
+        code = (code > lim - 1) ? (lim - 1) : code;
+        out_code[slot * O1 + ord] = code;
+        out_kint[slot * O1 + ord] = (int32_t)((uint32_t)code << (16u - q)) >> rshift;
+      }
     }
   }
 }
@@ -703,14 +748,27 @@ extern "C" int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, u
   if ((d_code != nullptr) != (d_kint != nullptr) || (d_code != nullptr) != (d_rshift != nullptr)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (d_code != nullptr && max_cands_per_group != 1) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (num_groups == 0) { return 0; }
+  // windows per workgroup: as many as the LDS budget takes, at most what fills the three chain waves
   size_t x_region = (size_t)max_window;
-  if (x_region < 2 * (size_t)max_cands_per_group * (order + 2)) { x_region = 2 * (size_t)max_cands_per_group * (order + 2); }
-  size_t lds = sizeof(double) * (x_region + (size_t)max_cands_per_group * (order + 1));
+  const size_t per_group_r = (size_t)max_cands_per_group * (order + 1);
+  uint32_t pack = 1;
+  for (uint32_t p = 2 /* measured on C2/C3: 2 beats 1 and 4 */; p >= 1; p--) {
+    size_t xr = (size_t)max_window;
+    if (xr * p < 2 * (size_t)p * max_cands_per_group * (order + 2)) { xr = 2 * (size_t)max_cands_per_group * (order + 2); }
+    const size_t bytes = sizeof(double) * ((size_t)p * xr + (size_t)p * per_group_r);
+    if (bytes <= SLA_HIP_LDS_BUDGET && ((size_t)(p - 1) * max_cands_per_group * order < 192 || p == 1)) { pack = p; x_region = xr; break; }
+  }
+  {
+    const char* env = getenv("SLA_HIP_LPC_PACK");
+    if (env != nullptr && atoi(env) >= 1 && (uint32_t)atoi(env) < pack) { pack = (uint32_t)atoi(env); }
+  }
+  if (x_region * pack < 2 * (size_t)pack * max_cands_per_group * (order + 2)) { x_region = 2 * (size_t)max_cands_per_group * (order + 2); }
+  size_t lds = sizeof(double) * ((size_t)pack * x_region + (size_t)pack * per_group_r);
   if (lds > SLA_HIP_LDS_BUDGET) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
   hipError_t e = hipFuncSetAttribute((const void*)k_lpc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { return hip_rc(e); }
-  hipLaunchKernelGGL(k_lpc, dim3(num_groups), dim3(256), lds, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
-                     d_groups, d_cands, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)x_region,
+  hipLaunchKernelGGL(k_lpc, dim3((num_groups + pack - 1) / pack), dim3(256), lds, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
+                     d_groups, num_groups, pack, d_cands, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)x_region,
                      (uint32_t)(getenv("SLA_HIP_LPC_SKIP") ? atoi(getenv("SLA_HIP_LPC_SKIP")) : 0));
   return hip_rc(hipGetLastError());
 }
