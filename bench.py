@@ -130,20 +130,27 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel (HIP-event durations measured inside the library, on the
         #      stream the kernels run on) ---------------------------------------------------------------
-        kern = np.array(list(kernel_ms[:5]) + [kernel_ms[8]])
-        dom = int(np.argmax(kern))
-        algo_bytes = float(n) * nch * ALGO_BYTES_PER_SAMPLE
-        achieved = algo_bytes / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
-        out["roofline"] = {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": round(achieved, 2),
+        # per-step kernel time, launches per step and passes over the data, by kernel name (k_lpc runs twice
+        # over the file: partition search and chosen blocks; chunked stages launch once per chunk)
+        nchunks = max(int(round(kernel_ms[9])), 1)
+        kernels = {"k_prepass": (kernel_ms[0], 1, 1), "k_lpc": (kernel_ms[1] + kernel_ms[2], 2 * nchunks, 2),
+                   "k_lattice": (kernel_ms[3], nchunks, 1), "k_ltm_acf": (kernel_ms[8], nchunks, 1),
+                   "k_tail": (kernel_ms[4], nchunks, 1)}
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        t_step, launches, passes = kernels[dom]
+        launch_ms = t_step / launches
+        algo_bytes = float(n) * nch * ALGO_BYTES_PER_SAMPLE * passes / launches      # per launch
+        achieved = algo_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2),
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                           "traffic": None, "kernel_ms": round(float(kern[dom]), 4),
-                           "algorithmic_bytes_per_launch": algo_bytes}
+                           "traffic": None, "kernel_ms": round(float(launch_ms), 4), "launches_per_step": launches,
+                           "algorithmic_bytes_per_launch": algo_bytes,
+                           "note": "kernel_ms = average HIP-event duration of one launch of this kernel inside the timed region"}
         # HBM traffic per launch of that kernel from the committed rocprofv3 --pmc passes (same config only)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.config.lower())))
-            key = KERNEL_NAMES[dom].split(" ")[0]
             if args.seconds is None:
-                out["roofline"]["traffic"] = pmc["bytes_per_launch"][key]["total"]
+                out["roofline"]["traffic"] = pmc["bytes_per_launch"][dom]["total"]
                 out["roofline"]["traffic_source"] = pmc["source"]
         except (OSError, KeyError, ValueError):
             pass
