@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=None, help="override the audio duration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -61,11 +62,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
 
     nch, bits, rate, seconds, order, ltm, lms, ms, win, maxb, cap = CONFIGS[args.config]
     if args.seconds is not None:
@@ -91,7 +96,10 @@ def main():
     def step():
         t = enc.analyze_device(d_pcm.data_ptr(), stride, n)
         if world > 1:
-            sdist.all_gather_planes(d_fin, gathered)          # RCCL over xGMI: re-assemble the residual stream
+            if args.backend == "nccl":
+                sdist.all_gather_planes(d_fin, gathered)      # RCCL over xGMI: re-assemble the residual stream
+            else:                                             # rehearsal backend: stage through the host
+                gathered.copy_(sdist.all_gather_planes(d_fin.cpu()))
         return t
 
     for _ in range(args.warmup):
@@ -108,7 +116,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        elapsed = sdist.max_over_ranks(elapsed, "cuda")
+        elapsed = sdist.max_over_ranks(elapsed, "cuda" if args.backend == "nccl" else "cpu")
     kernel_ms /= max(args.steps, 1)
 
     total_samples = float(n) * nch * world * args.steps
