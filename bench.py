@@ -141,9 +141,13 @@ def main():
         # per-step kernel time, launches per step and passes over the data, by kernel name (k_lpc runs twice
         # over the file: partition search and chosen blocks; chunked stages launch once per chunk)
         nchunks = max(int(round(kernel_ms[9])), 1)
-        kernels = {"k_prepass": (kernel_ms[0], 1, 1), "k_lpc": (kernel_ms[1] + kernel_ms[2], 2 * nchunks, 2),
+        exact_search = kernel_ms[11] > 0.5      # partition search ran on tile sums, k_lpc only on the chosen blocks
+        kernels = {"k_prepass": (kernel_ms[0], 1, 1),
+                   "k_lpc": (kernel_ms[2], nchunks, 1) if exact_search else (kernel_ms[1] + kernel_ms[2], 2 * nchunks, 2),
                    "k_lattice": (kernel_ms[3], nchunks, 1), "k_ltm_acf": (kernel_ms[8], nchunks, 1),
                    "k_tail": (kernel_ms[4], nchunks, 1)}
+        if exact_search:
+            kernels["k_acf_tiles+k_search_finish"] = (kernel_ms[1], nchunks, 1)
         dom = max(kernels, key=lambda k: kernels[k][0])
         t_step, launches, passes = kernels[dom]
         launch_ms = t_step / launches
@@ -162,7 +166,9 @@ def main():
                 out["roofline"]["traffic_source"] = pmc["source"]
         except (OSError, KeyError, ValueError):
             pass
-        out["stage_ms"] = {"k_prepass": round(float(kernel_ms[0]), 4), "k_lpc_search": round(float(kernel_ms[1]), 4),
+        out["stage_ms"] = {"k_prepass": round(float(kernel_ms[0]), 4),
+                           ("search_tile_sums" if exact_search else "k_lpc_search"): round(float(kernel_ms[1]), 4),
+                           "search_fallback_groups": round(float(kernel_ms[10]), 2),
                            "k_lpc_blocks": round(float(kernel_ms[2]), 4), "k_lattice": round(float(kernel_ms[3]), 4),
                            "k_tail": round(float(kernel_ms[4]), 4), "k_ltm_acf": round(float(kernel_ms[8]), 4), "host_plan": round(float(kernel_ms[5]), 4),
                            "host_longterm": round(float(kernel_ms[6]), 4), "analyze_total": round(float(kernel_ms[7]), 4)}

@@ -137,6 +137,26 @@ int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid
                        double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
                        sla_hip_stream_t stream);
 
+/* Partition search without serial chains (reference src/SLAPredictor.c:1615-1649 + :331-388).
+ * The search analyses the un-windowed samples: integers times a power of two.  As long as the energy of
+ * a group's window stays below `exact_limit` (= 2^51 units^2, unit = the common power-of-two factor of
+ * the samples) every product and every partial sum of the reference's autocorrelation is exactly
+ * representable, so the order of summation is free: each wave sums one SLA_HIP_XTILE-sample tile per lag,
+ * candidates are prefix differences of tile sums minus the pairs that straddle the candidate's end, and
+ * the result is bit-identical to the serial order.  Groups: one per (super-frame, channel) listing ALL its
+ * candidates; candidates must start on a tile boundary and end on one or at the end of the window.
+ * d_tile_sums: num_groups * SLA_HIP_XTILES * 2 * sla_hip_search_exact_lags(order) doubles of scratch.
+ * A group whose energy reaches the limit gets NaN in r[0] of every candidate: the caller reruns those
+ * groups through sla_hip_launch_lpc. */
+#define SLA_HIP_XTILE  1024u
+#define SLA_HIP_XTILES 16u
+uint32_t sla_hip_search_exact_lags(uint32_t order);      /* padded lag count, 0: order not supported */
+int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                                const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                                uint32_t max_cands_per_group,
+                                const sla_hip_lpc_cand* d_cands, double* d_tile_sums, double* d_out,
+                                double exact_limit, sla_hip_stream_t stream);
+
 /* Integer pre-emphasis + PARCOR lattice; one wave per chunk. */
 int sla_hip_launch_lattice(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
                            const sla_hip_lattice_chunk* d_chunks, uint32_t num_chunks,
@@ -201,7 +221,8 @@ typedef struct sla_hip_trace {
  * residual planes and, on the host, the block table and per-block parameters.
  * `timing_ms` (may be NULL) receives 12 floats [ms]: HIP-event durations of k_prepass, k_lpc (search),
  * k_lpc (blocks), k_lattice, k_tail; host wall time of planning and of the long-term solve; total
- * wall time; HIP-event duration of k_ltm_acf; 3 reserved. */
+ * wall time; HIP-event duration of k_ltm_acf; number of pipeline chunks; search groups that had to rerun
+ * as serial chains; 1 if the search ran on tile sums (sla_hip_launch_search_exact), else 0. */
 int sla_hip_analyze_device(struct SLAEncoder* encoder, const int32_t* d_pcm, uint64_t plane_stride,
                            uint32_t num_samples, sla_hip_stream_t stream, float* timing_ms);
 
@@ -229,6 +250,9 @@ int sla_hip_get_trace(struct SLAEncoder* encoder, sla_hip_trace* trace);
 
 /* Name of the device the library bound to ("" when none). */
 const char* sla_hip_device_name(void);
+
+/* The 12 floats of the last analysis (sla_hip_analyze_device or SLAEncoder_EncodeWhole/Block). */
+int sla_hip_last_timing(const struct SLAEncoder* encoder, float* timing_ms);
 
 #ifdef __cplusplus
 }

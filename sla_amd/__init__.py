@@ -112,6 +112,8 @@ def lib():
         L.sla_hip_lattice_residual.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.sla_hip_bind_residual_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         L.sla_hip_device_name.restype = C.c_char_p
+        L.sla_hip_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.sla_hip_search_exact_lags.restype = C.c_uint32
         _lib = L
     return _lib
 
@@ -124,7 +126,8 @@ EXPORTED_SYMBOLS = [
     "sla_hip_launch_prepass", "sla_hip_launch_lpc", "sla_hip_launch_lattice", "sla_hip_launch_tail",
     "sla_hip_launch_ltm_acf", "sla_hip_launch_rice_len", "sla_hip_launch_rice_write", "sla_hip_pack_device", "sla_hip_launch_unpack16",
     "sla_hip_analyze_device", "sla_hip_pack", "sla_hip_final_residual", "sla_hip_lattice_residual",
-    "sla_hip_get_trace", "sla_hip_device_name", "sla_hip_bind_residual_planes",
+    "sla_hip_get_trace", "sla_hip_device_name", "sla_hip_last_timing", "sla_hip_launch_search_exact",
+    "sla_hip_search_exact_lags", "sla_hip_bind_residual_planes",
 ]
 
 
@@ -250,6 +253,12 @@ class Encoder:
                                                      C.c_void_p(stream) if stream else None, timing),
                     "sla_hip_analyze_device")
         self.num_samples = num_samples
+        return list(timing)
+
+    def last_timing(self):
+        """the 12 stage timings / counters of the last analysis (see include/sla_hip.h)"""
+        timing = (C.c_float * 12)()
+        self._check(self._lib.sla_hip_last_timing(self._h, timing), "sla_hip_last_timing")
         return list(timing)
 
     def bind_residual_planes(self, lattice_ptr, final_ptr, plane_stride):

@@ -54,17 +54,21 @@ struct SLAEncoder {
   hipStream_t stream, stream2, stream3;
   hipEvent_t  ev[2 + 8 * 12];       /* prepass pair + MAX_CHUNKS x EV_PER_CHUNK */
   uint32_t chunks;
+  int      search_exact;            /* 1: tile-sum search where it is provably bit-exact (default), 0: chains only */
+  int      exact_bits;              /* log2 of the energy limit in units^2 (51; lowered by tests to force the fallback) */
+  uint32_t fallback_groups;         /* last analysis: search groups that had to take the chain kernel */
   slai_fft_plan* fft;
   uint32_t threads;
   struct slai_pool* pool;
 
   /* device workspace */
   devbuf_t d_pcm, d_res1, d_res2, d_or, d_nz, d_groups, d_cands, d_lpc_out, d_code, d_kint, d_rshift,
-           d_winpool, d_chunks, d_jobs, d_fold, d_acf_jobs, d_acf, d_acf_scratch, d_twiddle, d_bgroups, d_bcands, d_blk_out, d_kk, d_pk_jobs, d_pk_blocks, d_pk_hdr, d_image;
+           d_winpool, d_chunks, d_jobs, d_fold, d_acf_jobs, d_acf, d_acf_scratch, d_twiddle, d_bgroups, d_bcands, d_blk_out, d_kk, d_pk_jobs, d_pk_blocks, d_pk_hdr, d_image,
+           d_xgroups, d_tile_sums, d_fgroups;
   int twiddle_ready;
   /* pinned host staging */
   pinbuf_t h_nz, h_groups, h_cands, h_lpc_out, h_code, h_kint, h_rshift, h_chunks, h_jobs, h_fold, h_res, h_pcm, h_acf_jobs, h_acf,
-           h_bgroups, h_bcands, h_blk_out, h_pk_jobs, h_pk_blocks, h_pk_hdr;
+           h_bgroups, h_bcands, h_blk_out, h_pk_jobs, h_pk_blocks, h_pk_hdr, h_xgroups, h_fgroups;
   uint32_t* h_or;
   pinbuf_t h_stage[2]; devbuf_t d_stage[2]; hipEvent_t ev_stage[2];
 
@@ -255,6 +259,11 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   e->chunks = 2;
   env = getenv("SLA_HIP_CHUNKS");
   if (env != NULL && atoi(env) > 0) { e->chunks = (uint32_t)atoi(env); }
+  e->search_exact = 1; e->exact_bits = 51;
+  env = getenv("SLA_HIP_SEARCH");
+  if (env != NULL && strcmp(env, "chain") == 0) { e->search_exact = 0; }
+  env = getenv("SLA_HIP_EXACT_BITS");
+  if (env != NULL && atoi(env) > 0 && atoi(env) < 51) { e->exact_bits = atoi(env); }
   if (hipHostMalloc((void**)&e->h_or, 64, hipHostMallocDefault) != hipSuccess) { free(e); return NULL; }
   {
     uint32_t fft = 1;
@@ -274,8 +283,8 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
 
 void SLAEncoder_Destroy(struct SLAEncoder* e)
 {
-  devbuf_t* d[27];
-  pinbuf_t* h[20];
+  devbuf_t* d[30];
+  pinbuf_t* h[22];
   int i;
   if (e == NULL) { return; }
   (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3);
@@ -285,12 +294,13 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   d[15] = &e->d_acf_jobs; d[16] = &e->d_acf; d[17] = &e->d_acf_scratch; d[18] = &e->d_twiddle;
   d[19] = &e->d_bgroups; d[20] = &e->d_bcands; d[21] = &e->d_blk_out;
   d[22] = &e->d_kk; d[23] = &e->d_pk_jobs; d[24] = &e->d_pk_blocks; d[25] = &e->d_pk_hdr; d[26] = &e->d_image;
-  for (i = 0; i < 27; i++) { if (d[i]->ptr != NULL) { (void)hipFree(d[i]->ptr); } }
+  d[27] = &e->d_xgroups; d[28] = &e->d_tile_sums; d[29] = &e->d_fgroups;
+  for (i = 0; i < 30; i++) { if (d[i]->ptr != NULL) { (void)hipFree(d[i]->ptr); } }
   h[0] = &e->h_nz; h[1] = &e->h_groups; h[2] = &e->h_cands; h[3] = &e->h_lpc_out; h[4] = &e->h_code; h[5] = &e->h_kint;
   h[6] = &e->h_rshift; h[7] = &e->h_chunks; h[8] = &e->h_jobs; h[9] = &e->h_fold; h[10] = &e->h_res; h[11] = &e->h_pcm;
   h[12] = &e->h_acf_jobs; h[13] = &e->h_acf; h[14] = &e->h_bgroups; h[15] = &e->h_bcands; h[16] = &e->h_blk_out;
-  h[17] = &e->h_pk_jobs; h[18] = &e->h_pk_blocks; h[19] = &e->h_pk_hdr;
-  for (i = 0; i < 20; i++) { if (h[i]->ptr != NULL) { (void)hipHostFree(h[i]->ptr); } }
+  h[17] = &e->h_pk_jobs; h[18] = &e->h_pk_blocks; h[19] = &e->h_pk_hdr; h[20] = &e->h_xgroups; h[21] = &e->h_fgroups;
+  for (i = 0; i < 22; i++) { if (h[i]->ptr != NULL) { (void)hipHostFree(h[i]->ptr); } }
   if (e->h_or != NULL) { (void)hipHostFree(e->h_or); }
   for (i = 0; i < 2; i++) {
     if (e->h_stage[i].ptr != NULL) { (void)hipHostFree(e->h_stage[i].ptr); }
@@ -391,13 +401,14 @@ static int blocks_push(struct SLAEncoder* e, uint32_t start, uint32_t nsmpl, uin
 enum { EV_SEARCH_S, EV_SEARCH_E, EV_SEARCH_DONE, EV_LPCB_S, EV_LPCB_E, EV_LAT_E, EV_ACF_S, EV_ACF_E, EV_BLOCK_DONE,
        EV_TAIL_S, EV_TAIL_E, EV_TAIL_DONE, EV_PER_CHUNK };
 
-typedef struct { uint32_t start, window, min_blk, shape, slot_base, grp_lo, grp_hi; } sframe_t;
+typedef struct { uint32_t start, window, min_blk, shape, slot_base, grp_lo, grp_hi, xg; } sframe_t;
 typedef struct { uint32_t window, min_blk, nodes, ncand, cand_first; uint32_t pair[SLAI_MAX_NODES * SLAI_MAX_NODES]; } shape_t;
 
 typedef struct {
   uint32_t sf_lo, sf_hi;          /* super-frames of this chunk                                  */
   uint32_t grp_lo, grp_hi;        /* search work-groups                                          */
   uint32_t slot_lo, slot_hi;      /* search output slots                                         */
+  uint32_t xg_lo, xg_hi;          /* exact-search groups: one per (live super-frame, channel)    */
   uint32_t blk_lo, blk_hi;        /* blocks the plan produced                                    */
   uint32_t bg_lo, bg_hi;          /* (non-silent block, channel) groups = k_lpc groups = acf jobs */
   uint32_t lc_lo, lc_hi;          /* lattice chunks                                              */
@@ -407,7 +418,8 @@ typedef struct {
 typedef struct {
   sframe_t* sf; uint32_t nsf;
   shape_t* shapes; uint32_t nshapes;
-  uint32_t ncands, nsgroups, nslots, max_window, max_cpg;
+  uint32_t ncands, nsgroups, nslots, max_window, max_cpg, nxg, max_xcands;
+  int exact;                                      /* this run searches with tile sums            */
   uint32_t blocks_bound, lchunks_bound;
   uint32_t nbg, nlc, njobs;                       /* running counters of the block stage */
   uint32_t *job_blk, *job_ch, *job_grp, *grp_of_slot;
@@ -626,9 +638,13 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
       total_groups += C * ((sh->ncand + cpg - 1) / cpg);
     }
     RCCHK(pin_reserve(&e->h_groups, sizeof(sla_hip_lpc_group) * total_groups));
+    RCCHK(pin_reserve(&e->h_xgroups, sizeof(sla_hip_lpc_group) * ((size_t)a->nsf * C + 1)));
   }
   groups = (sla_hip_lpc_group*)e->h_groups.ptr;
-  a->max_window = 1; a->max_cpg = 1;
+  a->max_window = 1; a->max_cpg = 1; a->max_xcands = 1;
+  /* candidates start on multiples of SLAI_SEARCH_DELTA and end on one or with the window: tile aligned */
+  a->exact = (e->search_exact && SLAI_SEARCH_DELTA == SLA_HIP_XTILE && maxb <= SLA_HIP_XTILE * SLA_HIP_XTILES
+              && sla_hip_search_exact_lags(order) != 0 && e->h_or[0] != 0);
   for (i = 0; i < a->nsf; i++) {
     sframe_t* f = &a->sf[i];
     const shape_t* sh;
@@ -651,6 +667,15 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
       }
     }
     f->grp_hi = a->nsgroups;
+    f->xg = a->nxg;
+    if (sh->ncand > a->max_xcands) { a->max_xcands = sh->ncand; }
+    for (ch = 0; ch < C; ch++) {          /* the same work as one group per channel with every candidate */
+      sla_hip_lpc_group* g = (sla_hip_lpc_group*)e->h_xgroups.ptr + a->nxg++;
+      g->pcm_off = f->start; g->num_samples = sh->window; g->channel = ch;
+      g->win_off = SLA_HIP_NO_WINDOW; g->int_shift = 32 - bps;
+      g->cand_first = sh->cand_first; g->cand_count = sh->ncand;
+      g->slot_first = a->nslots + ch * sh->ncand; g->pad_ = 0;
+    }
     a->nslots += C * sh->ncand;
     if (sh->window > a->max_window) { a->max_window = sh->window; }
   }
@@ -668,6 +693,12 @@ static int pipeline_reserve(struct SLAEncoder* e, const actx_t* a)
   RCCHK(dev_reserve(&e->d_cands, sizeof(sla_hip_lpc_cand) * (a->ncands + 1)));
   RCCHK(dev_reserve(&e->d_lpc_out, sizeof(double) * ((size_t)a->nslots + 1) * O2));
   RCCHK(pin_reserve(&e->h_lpc_out, sizeof(double) * ((size_t)a->nslots + 1) * O2));
+  if (a->exact) {
+    RCCHK(dev_reserve(&e->d_xgroups, sizeof(sla_hip_lpc_group) * ((size_t)a->nxg + 1)));
+    RCCHK(dev_reserve(&e->d_tile_sums, sizeof(double) * ((size_t)a->nxg + 1) * SLA_HIP_XTILES * 2 * sla_hip_search_exact_lags(order)));
+    RCCHK(pin_reserve(&e->h_fgroups, sizeof(sla_hip_lpc_group) * ((size_t)a->nsgroups + 1)));
+    RCCHK(dev_reserve(&e->d_fgroups, sizeof(sla_hip_lpc_group) * ((size_t)a->nsgroups + 1)));
+  }
   /* blocks */
   RCCHK(pin_reserve(&e->h_bgroups, sizeof(sla_hip_lpc_group) * nslots));
   RCCHK(pin_reserve(&e->h_bcands, sizeof(sla_hip_lpc_cand) * nslots));
@@ -741,12 +772,26 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
   const uint32_t ng = k->grp_hi - k->grp_lo;
   HIPCHK(hipEventRecord(ev[EV_SEARCH_S], e->stream));
   if (ng > 0) {
-    const sla_hip_lpc_group* hg = (const sla_hip_lpc_group*)e->h_groups.ptr + k->grp_lo;
-    sla_hip_lpc_group* dg = (sla_hip_lpc_group*)e->d_groups.ptr + k->grp_lo;
-    HIPCHK(hipMemcpyAsync(dg, hg, sizeof(sla_hip_lpc_group) * ng, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipEventRecord(ev[EV_SEARCH_S], e->stream));
-    RCCHK(sla_hip_launch_lpc(e->pcm_dev, e->stride, ms, order, dg, ng, a->max_window, a->max_cpg,
-                             (const sla_hip_lpc_cand*)e->d_cands.ptr, NULL, (double*)e->d_lpc_out.ptr, NULL, NULL, NULL, e->stream));
+    if (a->exact) {
+      /* unit of the samples the search sees: 2^(ntz-31), halved by the mid channel's /2 */
+      const int ntz = __builtin_ctz(e->h_or[0]);
+      const double limit = ldexp(1.0, e->exact_bits + 2 * (ntz - 31 - (int)ms));
+      const uint32_t nx = k->xg_hi - k->xg_lo;
+      const sla_hip_lpc_group* hx = (const sla_hip_lpc_group*)e->h_xgroups.ptr + k->xg_lo;
+      sla_hip_lpc_group* dx = (sla_hip_lpc_group*)e->d_xgroups.ptr + k->xg_lo;
+      HIPCHK(hipMemcpyAsync(dx, hx, sizeof(sla_hip_lpc_group) * nx, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipEventRecord(ev[EV_SEARCH_S], e->stream));
+      RCCHK(sla_hip_launch_search_exact(e->pcm_dev, e->stride, ms, order, dx, nx, a->max_window, a->max_xcands, (const sla_hip_lpc_cand*)e->d_cands.ptr,
+                                        (double*)e->d_tile_sums.ptr + (size_t)k->xg_lo * SLA_HIP_XTILES * 2 * sla_hip_search_exact_lags(order),
+                                        (double*)e->d_lpc_out.ptr, limit, e->stream));
+    } else {
+      const sla_hip_lpc_group* hg = (const sla_hip_lpc_group*)e->h_groups.ptr + k->grp_lo;
+      sla_hip_lpc_group* dg = (sla_hip_lpc_group*)e->d_groups.ptr + k->grp_lo;
+      HIPCHK(hipMemcpyAsync(dg, hg, sizeof(sla_hip_lpc_group) * ng, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipEventRecord(ev[EV_SEARCH_S], e->stream));
+      RCCHK(sla_hip_launch_lpc(e->pcm_dev, e->stride, ms, order, dg, ng, a->max_window, a->max_cpg,
+                               (const sla_hip_lpc_cand*)e->d_cands.ptr, NULL, (double*)e->d_lpc_out.ptr, NULL, NULL, NULL, e->stream));
+    }
     HIPCHK(hipEventRecord(ev[EV_SEARCH_E], e->stream));
     HIPCHK(hipMemcpyAsync((double*)e->h_lpc_out.ptr + (size_t)k->slot_lo * O2, (double*)e->d_lpc_out.ptr + (size_t)k->slot_lo * O2,
                           sizeof(double) * (size_t)(k->slot_hi - k->slot_lo) * O2, hipMemcpyDeviceToHost, e->stream));
@@ -754,6 +799,40 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     HIPCHK(hipEventRecord(ev[EV_SEARCH_E], e->stream));
   }
   HIPCHK(hipEventRecord(ev[EV_SEARCH_DONE], e->stream));
+  return 0;
+}
+
+/* exact search only: super-frames whose window energy reached the exactness limit come back with NaN in
+ * r[0]; their groups take the serial-chain kernel now (rare: loud material wider than 16 bits) */
+static int search_fallback(struct SLAEncoder* e, actx_t* a, uint32_t c)
+{
+  const chunk_t* k = &a->ck[c];
+  const uint32_t C = e->wave_format.num_channels, order = e->encode_param.parcor_order, O2 = order + 2;
+  const uint32_t ms = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
+  const double* out = (const double*)e->h_lpc_out.ptr;
+  sla_hip_lpc_group* fg = (sla_hip_lpc_group*)e->h_fgroups.ptr;
+  uint32_t i, ch, n = 0;
+  for (i = k->sf_lo; i < k->sf_hi; i++) {
+    const sframe_t* f = &a->sf[i];
+    int flagged = 0;
+    if (f->shape == 0xFFFFFFFFu) { continue; }
+    for (ch = 0; ch < C; ch++) {
+      const double r0 = out[(size_t)(f->slot_base + ch * a->shapes[f->shape].ncand) * O2];
+      if (r0 != r0) { flagged = 1; }
+    }
+    if (flagged) {
+      memcpy(fg + n, (const sla_hip_lpc_group*)e->h_groups.ptr + f->grp_lo, sizeof(sla_hip_lpc_group) * (f->grp_hi - f->grp_lo));
+      n += f->grp_hi - f->grp_lo;
+    }
+  }
+  if (n == 0) { return 0; }
+  e->fallback_groups += n;
+  HIPCHK(hipMemcpyAsync(e->d_fgroups.ptr, fg, sizeof(sla_hip_lpc_group) * n, hipMemcpyHostToDevice, e->stream));
+  RCCHK(sla_hip_launch_lpc(e->pcm_dev, e->stride, ms, order, (const sla_hip_lpc_group*)e->d_fgroups.ptr, n, a->max_window, a->max_cpg,
+                           (const sla_hip_lpc_cand*)e->d_cands.ptr, NULL, (double*)e->d_lpc_out.ptr, NULL, NULL, NULL, e->stream));
+  HIPCHK(hipMemcpyAsync((double*)e->h_lpc_out.ptr + (size_t)k->slot_lo * O2, (double*)e->d_lpc_out.ptr + (size_t)k->slot_lo * O2,
+                        sizeof(double) * (size_t)(k->slot_hi - k->slot_lo) * O2, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
 }
 
@@ -981,8 +1060,13 @@ static void finish_rice(struct SLAEncoder* e, const actx_t* a)
 static float ev_ms(hipEvent_t s, hipEvent_t t) { float ms = 0.f; return (hipEventElapsedTime(&ms, s, t) == hipSuccess) ? ms : 0.f; }
 
 /* run the pipeline.  preset_blocks != 0: the block table is already in e->blk (EncodeBlock), no search. */
+/* SLA_HIP_TRACE=1: host-side timeline of one analysis on stderr (ms since the start of run_pipeline) */
+#define TRACE(label, c) do { if (trace) { fprintf(stderr, "[sla_hip] %8.3f ms  %s %d\n", now_ms() - t_begin, (label), (int)(c)); } } while (0)
+
 static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
 {
+  const int trace = (getenv("SLA_HIP_TRACE") != NULL);
+  const double t_begin = now_ms();
   const uint32_t C = e->wave_format.num_channels;
   actx_t a;
   uint32_t c, i, want_chunks;
@@ -991,6 +1075,7 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   memset(&a, 0, sizeof(a));
   a.ev = e->ev + 2;
 
+  e->fallback_groups = 0;
   if (!preset_blocks) {
     e->num_blocks = 0;
     if ((rc = pipeline_prepare(e, &a)) != 0) { actx_free(&a); return rc; }
@@ -1016,7 +1101,9 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
     a.status = (int*)calloc((size_t)a.nsf + 1, sizeof(int));
     if (!a.job_blk || !a.job_ch || !a.job_grp || !a.grp_of_slot || !a.parts || !a.nparts || !a.status) { actx_free(&a); return SLA_APIRESULT_NG; }
   }
+  TRACE("prepared (prepass + tables)", a.nsf);
   if ((rc = pipeline_reserve(e, &a)) != 0) { actx_free(&a); return rc; }
+  TRACE("reserved", 0);
 
   /* chunking: equal runs of super-frames */
   want_chunks = e->chunks;
@@ -1036,6 +1123,7 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
       if (first_live != 0xFFFFFFFFu) {
         k->slot_lo = a.sf[first_live].slot_base;
         k->slot_hi = a.sf[last_live].slot_base + C * a.shapes[a.sf[last_live].shape].ncand;
+        k->xg_lo = a.sf[first_live].xg; k->xg_hi = a.sf[last_live].xg + C;
       }
     }
   }
@@ -1045,6 +1133,7 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
       HIPCHK(hipMemcpyAsync(e->d_cands.ptr, e->h_cands.ptr, sizeof(sla_hip_lpc_cand) * a.ncands, hipMemcpyHostToDevice, e->stream));
     }
     for (c = 0; c < a.nchunks && rc == 0; c++) { rc = search_launch(e, &a, c); }
+    TRACE("search launched", a.nchunks);
   } else {
     a.ck[0].blk_lo = 0; a.ck[0].blk_hi = e->num_blocks;
   }
@@ -1053,31 +1142,40 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
     hipEvent_t* ev = a.ev + (size_t)c * EV_PER_CHUNK;
     if (!preset_blocks) {
       if (hipEventSynchronize(ev[EV_SEARCH_DONE]) != hipSuccess) { rc = SLA_APIRESULT_NG; break; }
+      TRACE("search done", c);
+      if (a.exact && (rc = search_fallback(e, &a, c)) != 0) { break; }
       t0 = now_ms();
       rc = plan_chunk(e, &a, c);
       t_host += now_ms() - t0;
       if (rc != 0) { break; }
+      TRACE("planned", c);
     }
     if ((rc = blocks_launch(e, &a, c)) != 0) { break; }
+    TRACE("blocks launched", c);
     if (c >= 1) {
       hipEvent_t* pv = a.ev + (size_t)(c - 1) * EV_PER_CHUNK;
       if (hipEventSynchronize(pv[EV_BLOCK_DONE]) != hipSuccess) { rc = SLA_APIRESULT_NG; break; }
+      TRACE("blocks done", c - 1);
       t0 = now_ms();
       rc = tail_launch(e, &a, c - 1);
       e->timing[6] += (float)(now_ms() - t0);
+      TRACE("tail launched", c - 1);
     }
   }
   if (rc == 0) {
     hipEvent_t* pv = a.ev + (size_t)(a.nchunks - 1) * EV_PER_CHUNK;
     if (hipEventSynchronize(pv[EV_BLOCK_DONE]) != hipSuccess) { rc = SLA_APIRESULT_NG; }
     else {
+      TRACE("blocks done", a.nchunks - 1);
       t0 = now_ms();
       rc = tail_launch(e, &a, a.nchunks - 1);
       e->timing[6] += (float)(now_ms() - t0);
+      TRACE("tail launched", a.nchunks - 1);
     }
   }
   if (hipStreamSynchronize(e->stream) != hipSuccess || hipStreamSynchronize(e->stream2) != hipSuccess
       || hipStreamSynchronize(e->stream3) != hipSuccess) { if (rc == 0) { rc = SLA_APIRESULT_NG; } }
+  TRACE("all streams idle", 0);
   if (rc == 0) {
     finish_rice(e, &a);
     e->timing[0] = preset_blocks ? 0.f : ev_ms(e->ev[0], e->ev[1]);
@@ -1091,6 +1189,8 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
       e->timing[4] += ev_ms(ev[EV_TAIL_S], ev[EV_TAIL_E]);
     }
     e->timing[9] = (float)a.nchunks;
+    e->timing[10] = (float)e->fallback_groups;
+    e->timing[11] = (float)a.exact;
   }
   actx_free(&a);
   return rc;
@@ -1130,6 +1230,13 @@ int sla_hip_analyze_device(struct SLAEncoder* e, const int32_t* d_pcm, uint64_t 
   e->timing[7] = (float)(now_ms() - t_start);
   if (timing_ms != NULL) { memcpy(timing_ms, e->timing, sizeof(e->timing)); }
   e->analysed = 1;
+  return 0;
+}
+
+int sla_hip_last_timing(const struct SLAEncoder* e, float* timing_ms)
+{
+  if (e == NULL || timing_ms == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  memcpy(timing_ms, e->timing, sizeof(e->timing));
   return 0;
 }
 

@@ -165,6 +165,35 @@ __device__ __forceinline__ int32_t f64_to_i32_x86(double v)
   return (int32_t)v;
 }
 
+// Levinson-Durbin in the reference's u/v formulation (src/SLAPredictor.c:253-328): o = { r0, parcor[0..order] }.
+// a, v: order+2 doubles of work space each.
+__device__ __forceinline__ void levinson_out(const double* rc, double* a, double* v, double* o, uint32_t order, uint32_t n)
+{
+  const uint32_t O1 = order + 1, O2 = order + 2;
+  o[0] = rc[0];
+  if (n < order || fabs(rc[0]) < (double)FLT_EPSILON) {
+    for (uint32_t i = 0; i < O1; i++) { o[1 + i] = 0.0; }
+  } else {
+    for (uint32_t i = 0; i < O2; i++) { a[i] = 0.0; v[i] = 0.0; }
+    a[0] = 1.0;
+    a[1] = -rc[1] / rc[0];
+    o[1] = 0.0;
+    o[2] = rc[1] / rc[0];
+    double e = rc[0] + rc[1] * a[1];
+    for (uint32_t d = 1; d < order; d++) {
+      double gamma = 0.0;
+      for (uint32_t i = 0; i < d + 1; i++) { gamma += a[i] * rc[d + 1 - i]; }
+      gamma /= (-e);
+      e = (1.0 - gamma * gamma) * e;
+      for (uint32_t i = 0; i < d; i++) { v[d - i] = a[i + 1]; }
+      v[0] = 0.0; v[d + 1] = 1.0;
+      a[0] = 1.0; a[d + 1] = 0.0;
+      for (uint32_t i = 0; i < d + 2; i++) { a[i] = a[i] + gamma * v[i]; }
+      o[2 + d] = -gamma;
+    }
+  }
+}
+
 #define LPC_MAX_PACK 4      // windows ("groups") one workgroup stages side by side
 
 // A workgroup takes `pack` consecutive groups: their windows sit next to each other in LDS and their
@@ -271,28 +300,7 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
     double* a = av + cidx * O2;
     double* v = vv + cidx * O2;
     double* o = out + slot * O2;
-    o[0] = rc[0];
-    if (n < order || fabs(rc[0]) < (double)FLT_EPSILON) {
-      for (uint32_t i = 0; i < O1; i++) { o[1 + i] = 0.0; }
-    } else {
-      for (uint32_t i = 0; i < O2; i++) { a[i] = 0.0; v[i] = 0.0; }
-      a[0] = 1.0;
-      a[1] = -rc[1] / rc[0];
-      o[1] = 0.0;
-      o[2] = rc[1] / rc[0];
-      double e = rc[0] + rc[1] * a[1];
-      for (uint32_t d = 1; d < order; d++) {
-        double gamma = 0.0;
-        for (uint32_t i = 0; i < d + 1; i++) { gamma += a[i] * rc[d + 1 - i]; }
-        gamma /= (-e);
-        e = (1.0 - gamma * gamma) * e;
-        for (uint32_t i = 0; i < d; i++) { v[d - i] = a[i + 1]; }
-        v[0] = 0.0; v[d + 1] = 1.0;
-        a[0] = 1.0; a[d + 1] = 0.0;
-        for (uint32_t i = 0; i < d + 2; i++) { a[i] = a[i] + gamma * v[i]; }
-        o[2 + d] = -gamma;
-      }
-    }
+    levinson_out(rc, a, v, o, order, n);
     // coefficient quantiser (chosen blocks: one candidate per group); the thread reads its own stores
     if (out_code != nullptr) {
       const uint32_t m = s_maxabs[k];
@@ -313,6 +321,197 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
         out_kint[slot * O1 + ord] = (int32_t)((uint32_t)code << (16u - q)) >> rshift;
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact partition search (see include/sla_hip.h): k_acf_tiles + k_search_finish.
+//
+// k_acf_tiles: one wave per (group, 1024-sample tile).  A lane owns 4 consecutive samples m[0..3]; the
+// partner values x[m+lag] of lag block 4k..4k+3 are the 4-sample runs of lanes t+k and t+k+1, which
+// arrive by a one-lane DPP shift per block -- 16 FMAs per 8 shifted dwords.  The last NB lanes
+// of a pass only supply partners (their own multipliers are zero), so a pass advances (64-NB)*4
+// samples; all passes' samples are requested before the first one is used.  Partners beyond the
+// group's window are zero, partners beyond the tile are not: P[lag] holds every pair whose FIRST sample
+// lies in the tile, X[lag] the ones among them whose second sample lies beyond it (a candidate ending
+// with this tile has to give them back).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double shl1_f64(double v)       // lane t <- lane t+1, lane 63 <- 0
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)        // all source lanes valid for the row permutations used
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// sum over the 64 lanes, valid in every lane (order of the additions is free: callers' sums are exact).
+// In-row steps are DPP moves; the four row totals travel through SGPRs (ds_bpermute measured ~8x dearer).
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+  v += dpp_f64<0xB1>(v);        // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);        // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);       // row_half_mirror
+  v += dpp_f64<0x140>(v);       // row_mirror
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+typedef int32_t i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+
+// 4 consecutive raw samples of one plane, zero from `limit` on
+__device__ __forceinline__ void load4_raw(const int32_t* __restrict__ plane, uint64_t base, uint32_t idx, uint32_t limit, int32_t (&v)[4])
+{
+  if (idx + 3 < limit) {
+    const i32x4_u t = *(const i32x4_u*)(plane + base + idx);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; q++) { v[q] = (idx + q < limit) ? plane[base + idx + q] : 0; }
+  }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256)
+void k_acf_tiles(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
+                 const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, uint32_t tiles_per_group,
+                 double* __restrict__ tile_sums, uint32_t dbg)
+{
+  constexpr uint32_t OL = 64 - NB;             // lanes of a pass that own samples
+  constexpr uint32_t STEP = OL * 4, PASSES = (SLA_HIP_XTILE + STEP - 1) / STEP, LAGS = NB * 4;
+  __shared__ double s_edge[4][2 * LAGS];       // x[t1-LAGS .. t1+LAGS) of each wave's tile end t1
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t w = blockIdx.x * 4 + wv;
+  const uint32_t gi = w / tiles_per_group, tile = w - gi * tiles_per_group;
+  if (gi >= num_groups) { return; }
+  const sla_hip_lpc_group g = groups[gi];
+  const uint32_t N = g.num_samples, t0 = tile * SLA_HIP_XTILE;
+  if (t0 >= N) { return; }
+  const uint32_t t1 = (t0 + SLA_HIP_XTILE < N) ? (t0 + SLA_HIP_XTILE) : N;
+  const double scale = 4.656612873077392578125e-10;   // 2^-31, exact (same arithmetic as load_f64)
+
+  int32_t ra[PASSES][4], rb[PASSES][4];
+#pragma unroll
+  for (uint32_t p = 0; p < PASSES; p++) {
+    const uint32_t idx = t0 + p * STEP + 4 * lane;
+    if (t0 + p * STEP < t1) {
+      load4_raw(pcm + (ms ? 0 : (uint64_t)g.channel * stride), g.pcm_off, idx, N, ra[p]);
+      if (ms) { load4_raw(pcm + stride, g.pcm_off, idx, N, rb[p]); }
+    }
+  }
+  for (uint32_t i = lane; i < 2 * LAGS; i += 64) { s_edge[wv][i] = 0.0; }
+
+  double acc[LAGS];
+#pragma unroll
+  for (int i = 0; i < (int)LAGS; i++) { acc[i] = 0.0; }
+#pragma unroll
+  for (uint32_t p = 0; p < PASSES; p++) {
+    const uint32_t s0 = t0 + p * STEP;
+    if (s0 < t1 && !(dbg & 1)) {
+      double cur[4], own[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t idx = s0 + 4 * lane + q;
+        if (ms) {
+          const double l = (double)ra[p][q] * scale, r = (double)rb[p][q] * scale;
+          cur[q] = (g.channel == 0) ? ((l + r) / 2) : (l - r);
+        } else {
+          cur[q] = (double)ra[p][q] * scale;
+        }
+        own[q] = (lane < OL && idx < t1) ? cur[q] : 0.0;
+        const int rel = (int)idx - ((int)t1 - (int)LAGS);
+        if (rel >= 0 && rel < (int)(2 * LAGS)) { s_edge[wv][rel] = cur[q]; }
+      }
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        double nxt[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { nxt[q] = shl1_f64(cur[q]); }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const double partner = (q + j < 4) ? cur[q + j] : nxt[q + j - 4];
+            acc[4 * k + j] = __builtin_fma(own[q], partner, acc[4 * k + j]);     // exact below the limit: fusing is free
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { cur[q] = nxt[q]; }
+      }
+    }
+  }
+  double* dst = tile_sums + ((uint64_t)gi * SLA_HIP_XTILES + tile) * (2 * LAGS);
+#pragma unroll
+  for (int i = 0; i < (int)LAGS; i++) {
+    double v = acc[i];
+    if (!(dbg & 2)) { v = wave_sum_f64(v); }
+    if (lane == 0) { dst[i] = v; }
+  }
+  if (dbg & 4) { return; }
+  // pairs that straddle t1: lane = lag
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane < LAGS) {
+    double x = 0.0;
+    const double* e = s_edge[wv];
+    for (uint32_t j = 0; j < lane; j++) { x = __builtin_fma(e[LAGS - lane + j], e[LAGS + j], x); }
+    dst[LAGS + lane] = x;
+  }
+}
+
+// k_search_finish: one wave per group.  r[lag] of candidate [start, end) = P of its tiles minus X of its
+// last tile, then Levinson-Durbin per candidate exactly as in k_lpc.
+#define XF_BATCH 64          // candidates one pass of the wave takes (at most)
+__global__ __launch_bounds__(64)
+void k_search_finish(uint32_t order, uint32_t lags, uint32_t batch,
+                     const sla_hip_lpc_group* __restrict__ groups, const sla_hip_lpc_cand* __restrict__ cands,
+                     const double* __restrict__ tile_sums, double* __restrict__ out, double exact_limit)
+{
+  extern __shared__ double lds[];
+  const uint32_t O1 = order + 1, O2 = order + 2;
+  const sla_hip_lpc_group g = groups[blockIdx.x];
+  const uint32_t N = g.num_samples;
+  const uint32_t ntiles = (N + SLA_HIP_XTILE - 1) / SLA_HIP_XTILE;
+  const double* ts = tile_sums + (uint64_t)blockIdx.x * SLA_HIP_XTILES * 2 * lags;
+  double energy = 0.0;
+  for (uint32_t t = 0; t < ntiles; t++) { energy += ts[(uint64_t)t * 2 * lags]; }
+  const bool exact = (energy < exact_limit);
+  double* r = lds;                                   // [batch][O1]
+  double* av = lds + (size_t)batch * O1;             // [batch][O2]
+  double* vv = av + (size_t)batch * O2;              // [batch][O2]
+  for (uint32_t c0 = 0; c0 < g.cand_count; c0 += batch) {
+    const uint32_t nb = (g.cand_count - c0 < batch) ? (g.cand_count - c0) : batch;
+    for (uint32_t q = threadIdx.x; q < nb * O1; q += blockDim.x) {
+      const uint32_t ci = q / O1, lag = q - ci * O1;
+      const sla_hip_lpc_cand cd = cands[g.cand_first + c0 + ci];
+      const uint32_t end = cd.start + cd.len;
+      double sum = 0.0;
+      if (lag < cd.len) {
+        const uint32_t tl = (end - 1) / SLA_HIP_XTILE;
+        for (uint32_t t = cd.start / SLA_HIP_XTILE; t <= tl; t++) { sum += ts[(uint64_t)t * 2 * lags + lag]; }
+        sum -= ts[(uint64_t)tl * 2 * lags + lags + lag];
+      }
+      r[ci * O1 + lag] = sum;
+    }
+    __syncthreads();
+    for (uint32_t ci = threadIdx.x; ci < nb; ci += blockDim.x) {
+      const sla_hip_lpc_cand cd = cands[g.cand_first + c0 + ci];
+      double* o = out + ((uint64_t)g.slot_first + c0 + ci) * O2;
+      levinson_out(r + ci * O1, av + ci * O2, vv + ci * O2, o, order, cd.len);
+      if (!exact) { o[0] = __longlong_as_double(0x7FF8000000000000ll); }
+    }
+    __syncthreads();
   }
 }
 
@@ -770,6 +969,47 @@ extern "C" int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, u
   hipLaunchKernelGGL(k_lpc, dim3((num_groups + pack - 1) / pack), dim3(256), lds, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
                      d_groups, num_groups, pack, d_cands, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)x_region,
                      (uint32_t)(getenv("SLA_HIP_LPC_SKIP") ? atoi(getenv("SLA_HIP_LPC_SKIP")) : 0));
+  return hip_rc(hipGetLastError());
+}
+
+extern "C" uint32_t sla_hip_search_exact_lags(uint32_t order)
+{
+  const uint32_t nb = (order + 1 + 3) / 4;
+  if (order < 1) { return 0; }
+  return (nb <= 3) ? 12 : (nb <= 5) ? 20 : (nb <= 9) ? 36 : (nb <= 13) ? 52 : 0;
+}
+
+extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                                           const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                                           uint32_t max_cands_per_group,
+                                           const sla_hip_lpc_cand* d_cands, double* d_tile_sums, double* d_out,
+                                           double exact_limit, sla_hip_stream_t stream)
+{
+  if (d_pcm == nullptr || d_groups == nullptr || d_cands == nullptr || d_tile_sums == nullptr || d_out == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  const uint32_t lags = sla_hip_search_exact_lags(order);
+  if (lags == 0 || max_window > SLA_HIP_XTILE * SLA_HIP_XTILES) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
+  if (max_window == 0 || max_cands_per_group == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (num_groups == 0) { return 0; }
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t tiles = (max_window + SLA_HIP_XTILE - 1) / SLA_HIP_XTILE;       // waves per group
+  const uint32_t waves = num_groups * tiles;
+  const dim3 grid((waves + 3) / 4), block(256);
+  const uint32_t dbg = (uint32_t)(getenv("SLA_HIP_XDBG") ? atoi(getenv("SLA_HIP_XDBG")) : 0);
+  switch (lags) {
+    case 12: hipLaunchKernelGGL(k_acf_tiles<3>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, dbg); break;
+    case 20: hipLaunchKernelGGL(k_acf_tiles<5>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, dbg); break;
+    case 36: hipLaunchKernelGGL(k_acf_tiles<9>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, dbg); break;
+    default: hipLaunchKernelGGL(k_acf_tiles<13>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, dbg); break;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { return hip_rc(e); }
+  if (dbg & 8) { return 0; }
+  const uint32_t batch = (max_cands_per_group < XF_BATCH) ? max_cands_per_group : XF_BATCH;
+  const size_t lds = sizeof(double) * (size_t)batch * ((order + 1) + 2 * (size_t)(order + 2));
+  e = hipFuncSetAttribute((const void*)k_search_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { return hip_rc(e); }
+  hipLaunchKernelGGL(k_search_finish, dim3(num_groups), dim3(64), lds, st, order, lags, batch,
+                     d_groups, d_cands, d_tile_sums, d_out, exact_limit);
   return hip_rc(hipGetLastError());
 }
 

@@ -351,6 +351,114 @@ def test_lpc_launcher_candidates(oracle, hip):
         assert np.array_equal(out[i, 1:].view(np.uint64), par.view(np.uint64)), (i, s, n)
 
 
+@pytest.mark.parametrize("order,nch,bits,ms", [(16, 1, 16, 0), (32, 2, 16, 1), (5, 2, 24, 1), (48, 1, 24, 0), (10, 1, 8, 0)])
+def test_search_exact_launcher_equals_serial_chains(oracle, hip, order, nch, bits, ms):
+    """sla_hip_launch_search_exact (tile sums, any summation order) == oracle autocorr+Levinson in the
+    reference's serial order, bit for bit, on every candidate of a ragged 16-node window; a window whose
+    energy is over the limit is flagged with NaN instead"""
+    import torch
+    L = hip.lib()
+    L.sla_hip_search_exact_lags.restype = C.c_uint32
+    lags = L.sla_hip_search_exact_lags(order)
+    assert lags >= order + 1
+    W_ = 15 * 1024 + 333
+    # quiet enough that 24-bit material stays below 2^51 units^2 over the window
+    pcm = W.music_like(nch, W_ + 500, bits, seed=order)[:, 200:200 + W_ + 100]
+    if bits == 24:
+        pcm = (pcm >> 12) << 8
+    pcm = np.ascontiguousarray(pcm)
+    stride = pcm.shape[1]
+    cand = []
+    for i in range(17):
+        for j in range(i + 1, 17):
+            ln = min((j - i) * 1024, W_ - i * 1024)
+            if i * 1024 < W_ and ln >= 1 and (j - i) <= 9:
+                cand.append((i * 1024, ln))
+    cand = sorted(set(cand))
+
+    class Group(C.Structure):
+        _fields_ = [("pcm_off", C.c_uint64)] + [(n, C.c_uint32) for n in (
+            "num_samples", "channel", "win_off", "int_shift", "cand_first", "cand_count", "slot_first", "pad_")]
+    off = 50
+    groups = (Group * nch)(*[Group(off, W_, ch, 0xFFFFFFFF, 32 - bits, 0, len(cand), ch * len(cand), 0) for ch in range(nch)])
+    d_pcm = torch.from_numpy(pcm).cuda()
+    d_g = torch.frombuffer(bytearray(bytes(groups)), dtype=torch.uint8).cuda()
+    d_c = torch.from_numpy(np.array(cand, np.uint32)).cuda()
+    d_ts = torch.zeros(nch * 16 * 2 * lags, dtype=torch.float64, device="cuda")
+    d_out = torch.zeros(nch * len(cand) * (order + 2), dtype=torch.float64, device="cuda")
+    ntz = 32 - bits
+    limit = 2.0 ** (51 + 2 * (ntz - 31 - ms))
+    torch.cuda.synchronize()
+
+    def run(lim):
+        rc = L.sla_hip_launch_search_exact(C.c_void_p(d_pcm.data_ptr()), C.c_uint64(stride), ms, order,
+                                           C.c_void_p(d_g.data_ptr()), nch, W_, len(cand), C.c_void_p(d_c.data_ptr()),
+                                           C.c_void_p(d_ts.data_ptr()), C.c_void_p(d_out.data_ptr()), C.c_double(lim), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return d_out.cpu().numpy().reshape(nch, len(cand), order + 2)
+    out = run(limit)
+    x = pcm.astype(np.float64) * 2.0 ** -31
+    if ms:
+        x = np.stack([(x[0] + x[1]) / 2, x[0] - x[1]])
+    for ch in range(nch):
+        for i, (s, n) in enumerate(cand):
+            xs = np.ascontiguousarray(x[ch, off + s:off + s + n])
+            r0 = oracle.autocorr(xs, 1)[0]
+            _, par = oracle.parcor(xs, order)
+            assert out[ch, i, 0].hex() == r0.hex(), (ch, i, s, n)
+            assert np.array_equal(out[ch, i, 1:].view(np.uint64), par.view(np.uint64)), (ch, i, s, n)
+    assert np.isnan(run(limit * 2.0 ** -40)[:, :, 0]).all()
+
+
+def _encode_with_env(hip, monkeypatch, p, pcm, **env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    enc = hip.Encoder(p.cap_channels, p.cap_block_samples, p.cap_parcor_order, p.cap_longterm_order, p.cap_lms_order)
+    try:
+        enc.set_wave_format(p.num_channels, p.bits_per_sample, p.sampling_rate)
+        enc.set_encode_parameter(p.parcor_order, p.longterm_order, p.lms_order, p.ch_process_method,
+                                 p.window_type, p.max_block_samples)
+        data = enc.encode_whole(pcm)
+        return data, enc.last_timing()
+    finally:
+        enc.close()
+
+
+@pytest.mark.parametrize("nch,bits,ms,maxb", [(1, 16, 0, 4096), (2, 24, 1, 16384), (2, 16, 1, 12288)])
+def test_search_paths_agree(oracle, hip, monkeypatch, nch, bits, ms, maxb):
+    """the three ways a partition search can run -- tile sums, tile sums with every group over a lowered
+    limit (serial-chain fallback), serial chains only -- give the oracle's bytes"""
+    n = 200000
+    pcm = W.music_like(nch, n, bits, seed=77)
+    p = S.make_params(nch, bits, 48000, parcor=16, ltm=1, lms=8, ms=ms, max_block=maxb)
+    ret, want, _ = oracle.encode_trace(p, pcm)
+    assert ret == 0
+    a, ta = _encode_with_env(hip, monkeypatch, p, pcm)
+    b, tb = _encode_with_env(hip, monkeypatch, p, pcm, SLA_HIP_EXACT_BITS="1")
+    c, tc = _encode_with_env(hip, monkeypatch, p, pcm, SLA_HIP_SEARCH="chain")
+    assert a == want and b == want and c == want
+    assert ta[11] == 1.0 and tb[11] == 1.0 and tc[11] == 0.0
+    assert tb[10] > 0 and tc[10] == 0
+    if bits <= 16:
+        assert ta[10] == 0          # 16-bit material can never reach the limit
+
+
+def test_search_loud_24bit_takes_the_fallback_where_needed(oracle, hip, monkeypatch):
+    """full-scale 24-bit noise has > 2^51 units^2 per window: flagged groups rerun as serial chains"""
+    rng = np.random.default_rng(5)
+    n = 70000
+    loud = rng.integers(-2 ** 23, 2 ** 23 - 1, (2, n), dtype=np.int64).astype(np.int32)
+    loud[:, 30000:] >>= 9           # second half quiet: stays on the tile-sum path
+    pcm = np.ascontiguousarray(loud << 8)
+    p = S.make_params(2, 24, 96000, parcor=32, ltm=3, lms=16, ms=1, max_block=8192)
+    ret, want, _ = oracle.encode_trace(p, pcm)
+    assert ret == 0
+    got, t = _encode_with_env(hip, monkeypatch, p, pcm)
+    assert got == want
+    assert t[11] == 1.0 and t[10] > 0
+
+
 # ------------------------------------------------------------------ BASELINE sizes: size-independent properties
 
 def _full_size_check(oracle, hip, p, pcm, prefix_frames):

@@ -32,8 +32,7 @@ def test_library_exports_every_declared_symbol(L):
     declared = set()
     for hdr in ("SLAEncoder.h", "sla_hip.h"):
         text = open(os.path.join(ROOT, "include", hdr)).read()
-        declared |= set(re.findall(r"\b(SLAEncoder_\w+|sla_hip_(?:launch_\w+|analyze_device|pack|final_residual|"
-                                   r"lattice_residual|get_trace|device_name|bind_residual_planes|pack_device))\s*\(", text))
+        declared |= set(re.findall(r"\b(SLAEncoder_\w+|sla_hip_\w+)\s*\(", text))
     assert declared == set(sla_amd.EXPORTED_SYMBOLS)
     for name in sorted(declared):
         assert hasattr(L, name), name
