@@ -54,6 +54,7 @@ struct SLAEncoder {
   hipStream_t stream, stream2, stream3;
   hipEvent_t  ev[2 + 8 * 12];       /* prepass pair + MAX_CHUNKS x EV_PER_CHUNK */
   uint32_t chunks;
+  uint32_t split[8], split_count, chunk_cut[9];   /* relative chunk sizes (SLA_HIP_CHUNK_SPLIT="1,3,1"), boundaries of this run */
   int      search_exact;            /* 1: tile-sum search where it is provably bit-exact (default), 0: chains only */
   int      exact_bits;              /* log2 of the energy limit in units^2 (51; lowered by tests to force the fallback) */
   uint32_t fallback_groups;         /* last analysis: search groups that had to take the chain kernel */
@@ -259,6 +260,17 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   e->chunks = 2;
   env = getenv("SLA_HIP_CHUNKS");
   if (env != NULL && atoi(env) > 0) { e->chunks = (uint32_t)atoi(env); }
+  env = getenv("SLA_HIP_CHUNK_SPLIT");
+  if (env != NULL) {
+    const char* q = env;
+    while (*q != '\0' && e->split_count < 8) {
+      const long v = strtol(q, (char**)&q, 10);
+      if (v <= 0) { e->split_count = 0; break; }
+      e->split[e->split_count++] = (uint32_t)v;
+      if (*q == ',') { q++; }
+    }
+    if (e->split_count > 0) { e->chunks = e->split_count; }
+  }
   e->search_exact = 1; e->exact_bits = 51;
   env = getenv("SLA_HIP_SEARCH");
   if (env != NULL && strcmp(env, "chain") == 0) { e->search_exact = 0; }
@@ -1112,10 +1124,18 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   if (want_chunks > MAX_CHUNKS) { want_chunks = MAX_CHUNKS; }
   if (want_chunks < 1) { want_chunks = 1; }
   a.nchunks = want_chunks;
+  /* chunk boundaries in 1/1000 of the super-frames: equal parts unless SLA_HIP_CHUNK_SPLIT gave the shares */
+  if (e->split_count != a.nchunks) {
+    for (c = 0; c <= a.nchunks; c++) { e->chunk_cut[c] = 1000u * c / a.nchunks; }
+  } else {
+    uint32_t acc = 0, sum = 0;
+    for (c = 0; c < a.nchunks; c++) { sum += e->split[c]; }
+    for (c = 0; c <= a.nchunks; c++) { e->chunk_cut[c] = 1000u * acc / sum; if (c < a.nchunks) { acc += e->split[c]; } }
+  }
   for (c = 0; c < a.nchunks; c++) {
     chunk_t* k = &a.ck[c];
-    k->sf_lo = (uint32_t)((uint64_t)a.nsf * c / a.nchunks);
-    k->sf_hi = (uint32_t)((uint64_t)a.nsf * (c + 1) / a.nchunks);
+    k->sf_lo = (uint32_t)((uint64_t)a.nsf * e->chunk_cut[c] / 1000);
+    k->sf_hi = (c + 1 == a.nchunks) ? a.nsf : (uint32_t)((uint64_t)a.nsf * e->chunk_cut[c + 1] / 1000);
     if (!preset_blocks && k->sf_hi > k->sf_lo) {
       uint32_t last_live = 0xFFFFFFFFu, first_live = 0xFFFFFFFFu;
       k->grp_lo = a.sf[k->sf_lo].grp_lo; k->grp_hi = a.sf[k->sf_hi - 1].grp_hi;

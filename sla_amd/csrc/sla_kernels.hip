@@ -19,6 +19,8 @@
 #include <stdint.h>
 #include <float.h>
 #include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
 
 #include "sla_hip.h"
 
@@ -208,7 +210,7 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
            int32_t* __restrict__ out_code, int32_t* __restrict__ out_kint, uint32_t* __restrict__ out_rshift,
            uint32_t x_region, uint32_t dbg_skip)
 {
-  extern __shared__ double lds[];
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ sla_hip_lpc_group s_g[LPC_MAX_PACK];
   __shared__ uint32_t s_coff[LPC_MAX_PACK + 1];      // running candidate count
   __shared__ uint32_t s_maxabs[LPC_MAX_PACK];
@@ -321,6 +323,250 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
         out_kint[slot * O1 + ord] = (int32_t)((uint32_t)code << (16u - q)) >> rshift;
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_lpc_blocks: the chosen blocks (one candidate per group = the whole windowed block).
+//
+// A serial chain only has to be serial in its ADDITIONS: the terms c*(a+b) are independent.  So the work
+// is split by role.  Waves 1-2 ("producers") compute LB_K consecutive terms of every chain of the pack
+// into an LDS tile, in the chain's own order (pairs i-major, then the leftover products; 0.0 past the
+// end, which leaves an accumulator untouched bit for bit); wave 0 owns one accumulator per (window, lag)
+// and adds the previous tile, one ds_read + one v_add_f64 per step for up to 64 chains at once; wave 3
+// does the same for the energy sums (two squares per step).  One barrier per tile, two tile buffers.
+// Measured on C2 (shader clock per workgroup): chains 265k ticks in the one-wave-per-chain loop of k_lpc.
+// Then Levinson-Durbin runs lane-parallel, one wave per window: lane j holds a[j]; the dot product is
+// multiplied in parallel and summed in the reference's order through v_readlane; the reversed vector is a
+// ds_bpermute.  The quantiser runs one lane per coefficient.
+// LDS: x[pack][x_region] | terms[2][nch][LB_K+2] | sq[2][pack][2*LB_K] | r[pack][order+1]
+// ---------------------------------------------------------------------------------------------
+#define LB_K 24
+__device__ unsigned long long g_lpc_clk[8];   // SLA_HIP_LPC_CLK=1: shader-clock ticks per phase, summed over workgroups
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)      // lane must be wave-uniform
+{
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+#define LB_ROW (LB_K + 2)     // terms of one chain and tile, padded: 16-byte aligned rows that spread over the banks
+
+template <int S>              // producer lanes per chain: 2, 4 or 8
+__global__ __launch_bounds__(256)
+void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
+                  const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, uint32_t pack,
+                  const double* __restrict__ window_pool, double* __restrict__ out,
+                  int32_t* __restrict__ out_code, int32_t* __restrict__ out_kint, uint32_t* __restrict__ out_rshift,
+                  uint32_t x_region, uint32_t nch, uint32_t clk)
+{
+  constexpr uint32_t Q = LB_K / S;              // consecutive terms a producer lane makes per tile
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const unsigned long long t_start = clk ? clock64() : 0;
+  __shared__ sla_hip_lpc_group s_g[LPC_MAX_PACK];
+  __shared__ uint32_t s_maxabs[LPC_MAX_PACK];
+  __shared__ uint32_t s_tiles;
+  const uint32_t O1 = order + 1, O2 = order + 2;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint32_t g0 = blockIdx.x * pack;
+  const uint32_t ng = (num_groups - g0 < pack) ? (num_groups - g0) : pack;
+  if (tid < LPC_MAX_PACK) {
+    if (tid < ng) { s_g[tid] = groups[g0 + tid]; }
+    s_maxabs[tid] = 0;
+  }
+  if (tid == 0) { s_tiles = 0; }
+  __syncthreads();
+  double* terms = lds + (size_t)pack * x_region;            // [2][nch][LB_ROW]
+  double* sq = terms + (size_t)2 * nch * LB_ROW;            // [2][pack][2*LB_K]
+  double* r = sq + (size_t)2 * 2 * LB_K * pack;             // [pack][O1]
+
+  // ---- stage the windows: convert, mid/side, window, pre-emphasis (as k_lpc); a batch of samples is
+  //      requested before the first one is used (one memory latency per batch, not per sample) ----------
+  for (uint32_t k = 0; k < ng; k++) {
+    const sla_hip_lpc_group g = s_g[k];
+    double* x = lds + (size_t)k * x_region;
+    const double* win = window_pool + g.win_off;
+    uint32_t maxabs = 0;
+    for (uint32_t base = 0; base < g.num_samples; base += 256 * 8) {
+      double cur[8], prev[8], w0[8], w1[8];
+      int32_t iv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t s = base + u * 256 + tid;
+        const bool in = (s < g.num_samples);
+        const uint32_t sc = in ? s : 0, sp = (in && s > 0) ? (s - 1) : 0;
+        cur[u] = load_f64(pcm, stride, ms, g.channel, g.pcm_off + sc);
+        prev[u] = load_f64(pcm, stride, ms, g.channel, g.pcm_off + sp);
+        w0[u] = win[sc]; w1[u] = win[sp];
+        iv[u] = load_int(pcm, stride, ms, g.channel, g.pcm_off + sc, g.int_shift);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t s = base + u * 256 + tid;
+        if (s < g.num_samples) {
+          const double c = cur[u] * w0[u];
+          const double pv = (s > 0) ? (prev[u] * w1[u]) : 0.0;
+          x[s] = c - pv * 0.96875;            // (2^5-1)*2^-5, src/SLAPredictor.c:1803-1809
+          const uint32_t a = (iv[u] > 0) ? (uint32_t)iv[u] : (0u - (uint32_t)iv[u]);
+          maxabs = (a > maxabs) ? a : maxabs;
+        }
+      }
+    }
+    maxabs = umax_wave(maxabs);
+    if (lane == 0) { atomicMax(&s_maxabs[k], maxabs); }
+  }
+
+  // ---- chain geometry: the consumer lane and the producer lanes of a chain derive the same numbers ------
+  const uint32_t nchains = ng * order;
+  const bool producer = (wv == 1 || wv == 2);
+  const uint32_t pl = tid - 64;                             // producer lane number (valid when producer)
+  const uint32_t ch = (wv == 0) ? lane : (producer ? (pl % nch) : 0xFFFFFFFFu);
+  const uint32_t j = producer ? (pl / nch) : 0;             // which Q-term piece of the tile this producer lane makes
+  const bool has_chain = (ch < nchains) && (!producer || j < (uint32_t)S);
+  const uint32_t ck = has_chain ? (ch / order) : 0;
+  const uint32_t lag = has_chain ? (1 + ch - ck * order) : 1;
+  const uint32_t n = s_g[ck].num_samples;
+  const uint32_t lag2 = lag << 1;
+  const uint32_t grp = (has_chain && 3 * lag < n) ? (1 + (n - 3 * lag) / lag2) : 0;
+  const uint32_t span = grp * lag2;
+  const uint32_t npair = grp * lag;
+  const uint32_t total = (has_chain && lag < n) ? (npair + (n - span - lag)) : 0;     // terms of this chain
+  const double* xs = lds + (size_t)ck * x_region;
+  {
+    uint32_t need = (total + LB_K - 1) / LB_K;
+    if (tid < ng) { const uint32_t e = (s_g[tid].num_samples + 2 * LB_K - 1) / (2 * LB_K); need = (e > need) ? e : need; }
+    need = umax_wave(need);
+    if (lane == 0) { atomicMax(&s_tiles, need); }
+  }
+  __syncthreads();
+  const uint32_t ntiles = s_tiles;
+  const unsigned long long t_staged = clk ? clock64() : 0;
+  unsigned long long t_prod = 0, t_cons = 0;
+
+  // producer position: term kk = tile*LB_K + j*Q sits at (run pi, step pg) while it is a pair term
+  uint32_t kk = j * Q;
+  uint32_t pi = (grp != 0) ? (kk / grp) : 0, pg = (grp != 0) ? (kk - (kk / grp) * grp) : 0;
+  // energy producer: lane e < 2*LB_K*ng makes the square of sample tile*2*LB_K + es of window ew
+  const uint32_t nsq = 2 * LB_K * ng;
+  const uint32_t ew = pl / (2 * LB_K), es = pl - ew * (2 * LB_K);      // 2*LB_K*LPC_MAX_PACK = 192 > 128: second round below
+
+  double acc = 0.0;
+  for (uint32_t t = 0; t <= ntiles; t++) {
+    const unsigned long long t_a = clk ? clock64() : 0;
+    if (producer && t < ntiles) {
+      if (has_chain) {
+        double* dst = terms + ((size_t)(t & 1) * nch + ch) * LB_ROW + j * Q;
+        uint32_t ii = pi, gg = pg, pos = pi + pg * lag2;
+        uint32_t ia[Q]; bool pr[Q], vl[Q];
+#pragma unroll
+        for (int q = 0; q < (int)Q; q++) {
+          const uint32_t kq = kk + q;
+          pr[q] = (kq < npair); vl[q] = (kq < total);
+          ia[q] = pr[q] ? pos : (vl[q] ? (span + (kq - npair)) : 0u);
+          const bool wrap = (gg + 1 == grp);
+          gg = wrap ? 0u : (gg + 1);
+          ii += wrap ? 1u : 0u;
+          pos = wrap ? ii : (pos + lag2);
+        }
+        double va[Q], vc[Q], vb[Q];
+#pragma unroll
+        for (int q = 0; q < (int)Q; q++) { va[q] = xs[ia[q]]; vc[q] = xs[ia[q] + lag]; vb[q] = xs[ia[q] + lag2]; }
+#pragma unroll
+        for (int q = 0; q < (int)Q; q++) {
+          const double tv = vc[q] * (va[q] + (pr[q] ? vb[q] : 0.0));      // leftover products: c*a (a+0.0 == a up to the sign of zero, which a sum that starts at +0.0 cannot see)
+          dst[q] = vl[q] ? tv : 0.0;
+        }
+        kk += LB_K;
+        if (grp != 0) { pg += LB_K; while (pg >= grp) { pg -= grp; pi++; } }
+      }
+      double* dq = sq + (size_t)(t & 1) * 2 * LB_K * pack;
+      if (pl < nsq) {
+        const uint32_t idx = t * 2 * LB_K + es;
+        const double v = (idx < s_g[ew].num_samples) ? lds[(size_t)ew * x_region + idx] : 0.0;
+        dq[ew * 2 * LB_K + es] = v * v;
+      }
+      if (pl + 128 < nsq) {
+        const uint32_t e2 = pl + 128, w2 = e2 / (2 * LB_K), s2 = e2 - w2 * (2 * LB_K);
+        const uint32_t idx = t * 2 * LB_K + s2;
+        const double v = (idx < s_g[w2].num_samples) ? lds[(size_t)w2 * x_region + idx] : 0.0;
+        dq[w2 * 2 * LB_K + s2] = v * v;
+      }
+    }
+    const unsigned long long t_b = clk ? clock64() : 0;
+    if (t >= 1) {
+      if (wv == 0 && has_chain) {
+        const double2* src = (const double2*)(terms + ((size_t)((t - 1) & 1) * nch + ch) * LB_ROW);
+#pragma unroll
+        for (int q = 0; q < LB_K / 2; q++) { const double2 v = src[q]; acc += v.x; acc += v.y; }
+      } else if (wv == 3 && lane < ng) {
+        const double2* src = (const double2*)(sq + (size_t)((t - 1) & 1) * 2 * LB_K * pack + lane * 2 * LB_K);
+#pragma unroll
+        for (int q = 0; q < LB_K; q++) { const double2 v = src[q]; acc += v.x; acc += v.y; }
+      }
+    }
+    if (clk) { const unsigned long long t_c = clock64(); t_prod += t_b - t_a; t_cons += t_c - t_b; }
+    __syncthreads();
+  }
+  if (wv == 0 && has_chain) { r[ck * O1 + lag] = acc; }
+  if (wv == 3 && lane < ng) { r[lane * O1] = acc; }
+  __syncthreads();
+  const unsigned long long t_chained = clk ? clock64() : 0;
+
+  // ---- Levinson-Durbin, one wave per window, lane j = coefficient j   src/SLAPredictor.c:253-328 ------
+  if (wv < ng) {
+    const sla_hip_lpc_group g = s_g[wv];
+    const uint64_t slot = g.slot_first;
+    double* o = out + slot * O2;
+    const double rc = (lane <= order) ? r[wv * O1 + lane] : 0.0;
+    const double r0 = readlane_f64(rc, 0), r1 = readlane_f64(rc, 1);
+    double par = 0.0;                               // lane j: parcor[j]
+    if (!(g.num_samples < order || fabs(r0) < (double)FLT_EPSILON)) {
+      const double a1 = -r1 / r0;
+      double a = (lane == 0) ? 1.0 : ((lane == 1) ? a1 : 0.0);
+      par = (lane == 1) ? (r1 / r0) : 0.0;
+      double e = r0 + r1 * a1;
+      for (uint32_t d = 1; d < order; d++) {
+        const int src = (int)(d + 1) - (int)lane;                   // lanes 0..d read r[d+1-i] / a[d+1-i]
+        const double rrev = __shfl(rc, src & 63);
+        const double prod = a * rrev;
+        double gamma = 0.0;
+        for (uint32_t i = 0; i <= d; i++) { gamma += readlane_f64(prod, (int)i); }
+        gamma /= (-e);
+        e = (1.0 - gamma * gamma) * e;
+        const double arev = __shfl(a, src & 63);
+        const double v = (lane == 0) ? 0.0 : ((lane == d + 1) ? 1.0 : ((lane <= d) ? arev : 0.0));
+        const double a_old = (lane == d + 1) ? 0.0 : a;
+        a = a_old + gamma * v;
+        par = (lane == d + 1) ? (-gamma) : par;
+      }
+    }
+    if (lane <= order) { o[1 + lane] = par; }
+    if (lane == 0) { o[0] = r0; }
+    // coefficient quantiser, lane = coefficient                          src/SLAEncoder.c:567-589
+    const uint32_t m = s_maxabs[wv];
+    const uint32_t l2c = (m > 1) ? (32u - (uint32_t)__builtin_clz(m - 1u)) : 0u;    // src/SLAUtility.c:677-696
+    const uint32_t bitwidth = (m > 0) ? (l2c + 1u) : 1u;
+    const uint32_t rshift = (bitwidth > 16) ? (bitwidth - 16) : 0;
+    if (lane == 0) { out_rshift[slot] = rshift; out_code[slot * O1] = 0; out_kint[slot * O1] = 0; }
+    if (lane >= 1 && lane <= order) {
+      const uint32_t qb = (lane < 4) ? 16 : 8;
+      const int32_t lim = 1 << (qb - 1);
+      const double kq = par * (double)lim;
+      const double rk = (kq >= 0.0) ? floor(kq + 0.5) : -floor(-kq + 0.5);
+      int32_t code = f64_to_i32_x86(rk);
+      code = (code < -lim) ? -lim : code;
+      code = (code > lim - 1) ? (lim - 1) : code;
+      out_code[slot * O1 + lane] = code;
+      out_kint[slot * O1 + lane] = (int32_t)((uint32_t)code << (16u - qb)) >> rshift;
+    }
+  }
+  if (clk && lane == 0) {
+    const unsigned long long t_end = clock64();
+    if (wv == 0) {
+      atomicAdd(&g_lpc_clk[0], t_staged - t_start); atomicAdd(&g_lpc_clk[1], t_chained - t_staged);
+      atomicAdd(&g_lpc_clk[2], t_end - t_chained); atomicAdd(&g_lpc_clk[3], 1ull); atomicAdd(&g_lpc_clk[4], t_cons);
+    }
+    if (wv == 1) { atomicAdd(&g_lpc_clk[5], t_prod); }
+    if (wv == 3) { atomicAdd(&g_lpc_clk[6], t_cons); }
   }
 }
 
@@ -478,7 +724,7 @@ void k_search_finish(uint32_t order, uint32_t lags, uint32_t batch,
                      const sla_hip_lpc_group* __restrict__ groups, const sla_hip_lpc_cand* __restrict__ cands,
                      const double* __restrict__ tile_sums, double* __restrict__ out, double exact_limit)
 {
-  extern __shared__ double lds[];
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   const uint32_t O1 = order + 1, O2 = order + 2;
   const sla_hip_lpc_group g = groups[blockIdx.x];
   const uint32_t N = g.num_samples;
@@ -947,6 +1193,54 @@ extern "C" int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, u
   if ((d_code != nullptr) != (d_kint != nullptr) || (d_code != nullptr) != (d_rshift != nullptr)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (d_code != nullptr && max_cands_per_group != 1) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (num_groups == 0) { return 0; }
+  if (d_code != nullptr && order <= 64 && !(getenv("SLA_HIP_LPC_BLOCKS") != nullptr && strcmp(getenv("SLA_HIP_LPC_BLOCKS"), "chains") == 0)) {
+    // chosen blocks: term tiles + lane-parallel Levinson (k_lpc_blocks)
+    if (d_window_pool == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+    uint32_t pmax = 64 / order;
+    if (pmax > LPC_MAX_PACK) { pmax = LPC_MAX_PACK; }
+    if (pmax > 2) { pmax = 2; }
+    {
+      const char* env = getenv("SLA_HIP_LPC_PACK");
+      if (env != nullptr && atoi(env) >= 1 && (uint32_t)atoi(env) <= LPC_MAX_PACK && (uint32_t)atoi(env) * order <= 64) { pmax = (uint32_t)atoi(env); }
+    }
+    for (uint32_t p = pmax; p >= 1; p--) {
+      uint32_t nch = 16;
+      while (nch < p * order) { nch <<= 1; }
+      const size_t xr = ((size_t)max_window + 1) & ~(size_t)1;       // even: the term rows behind the windows are read as 16-byte pairs
+      const size_t bytes = sizeof(double) * ((size_t)p * xr + (size_t)2 * LB_ROW * nch + (size_t)2 * 2 * LB_K * p + (size_t)p * (order + 1));
+      if (bytes > SLA_HIP_LDS_BUDGET) { continue; }
+      const uint32_t spl = (128 / nch < 8) ? (128 / nch) : 8;       // producer lanes per chain
+      const void* fn = (spl == 2) ? (const void*)k_lpc_blocks<2> : (spl == 4) ? (const void*)k_lpc_blocks<4> : (const void*)k_lpc_blocks<8>;
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (e != hipSuccess) { return hip_rc(e); }
+      const dim3 grid((num_groups + p - 1) / p), block(256);
+      const uint32_t clk = (uint32_t)(getenv("SLA_HIP_LPC_CLK") != nullptr);
+      if (spl == 2) {
+        hipLaunchKernelGGL(k_lpc_blocks<2>, grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
+                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk);
+      } else if (spl == 4) {
+        hipLaunchKernelGGL(k_lpc_blocks<4>, grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
+                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk);
+      } else {
+        hipLaunchKernelGGL(k_lpc_blocks<8>, grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
+                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk);
+      }
+      if (getenv("SLA_HIP_LPC_CLK") != nullptr) {
+        unsigned long long h[8] = {0}, z[8] = {0};
+        hipStreamSynchronize((hipStream_t)stream);
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lpc_clk), sizeof(h));
+        hipMemcpyToSymbol(HIP_SYMBOL(g_lpc_clk), z, sizeof(z));
+        int occ = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, bytes);
+        if (h[3] != 0) {
+          fprintf(stderr, "[k_lpc_blocks] LDS %zu B, %d workgroups per CU; ", bytes, occ);
+          fprintf(stderr, "[k_lpc_blocks] %llu workgroups (pack %u), ticks per workgroup: stage %llu, chains %llu (lag consumer busy %llu, producer busy %llu, energy consumer busy %llu), levinson+quantiser %llu\n",
+                  h[3], p, h[0] / h[3], h[1] / h[3], h[4] / h[3], h[5] / h[3], h[6] / h[3], h[2] / h[3]);
+        }
+      }
+      return hip_rc(hipGetLastError());
+    }
+    return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY;
+  }
   // windows per workgroup: as many as the LDS budget takes, at most what fills the three chain waves
   size_t x_region = (size_t)max_window;
   const size_t per_group_r = (size_t)max_cands_per_group * (order + 1);
