@@ -1125,7 +1125,10 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   if (want_chunks < 1) { want_chunks = 1; }
   a.nchunks = want_chunks;
   /* chunk boundaries in 1/1000 of the super-frames: equal parts unless SLA_HIP_CHUNK_SPLIT gave the shares */
-  if (e->split_count != a.nchunks) {
+  if (e->split_count != a.nchunks && a.nchunks == 2) {
+    /* measured on C2: a short first chunk fills the pipeline sooner (the host plans it while nothing else can run) */
+    e->chunk_cut[0] = 0; e->chunk_cut[1] = 300; e->chunk_cut[2] = 1000;
+  } else if (e->split_count != a.nchunks) {
     for (c = 0; c <= a.nchunks; c++) { e->chunk_cut[c] = 1000u * c / a.nchunks; }
   } else {
     uint32_t acc = 0, sum = 0;

@@ -330,18 +330,21 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
 // k_lpc_blocks: the chosen blocks (one candidate per group = the whole windowed block).
 //
 // A serial chain only has to be serial in its ADDITIONS: the terms c*(a+b) are independent.  So the work
-// is split by role.  Waves 1-2 ("producers") compute LB_K consecutive terms of every chain of the pack
-// into an LDS tile, in the chain's own order (pairs i-major, then the leftover products; 0.0 past the
-// end, which leaves an accumulator untouched bit for bit); wave 0 owns one accumulator per (window, lag)
-// and adds the previous tile, one ds_read + one v_add_f64 per step for up to 64 chains at once; wave 3
-// does the same for the energy sums (two squares per step).  One barrier per tile, two tile buffers.
-// Measured on C2 (shader clock per workgroup): chains 265k ticks in the one-wave-per-chain loop of k_lpc.
-// Then Levinson-Durbin runs lane-parallel, one wave per window: lane j holds a[j]; the dot product is
-// multiplied in parallel and summed in the reference's order through v_readlane; the reversed vector is a
-// ds_bpermute.  The quantiser runs one lane per coefficient.
+// is split by role (512 threads).  Waves 2-7 ("producers") compute LB_K consecutive terms of every chain
+// of the pack into an LDS tile, in the chain's own order (pairs i-major, then the leftover products; 0.0
+// past the end, which leaves an accumulator untouched bit for bit); wave 0 owns one accumulator per
+// (window, lag) and adds the previous tile -- half a ds_read_b128 and one v_add_f64 per step for up to 64
+// chains at once; wave 1 does the same for the energy sums (two squares per step).  One barrier per tile,
+// two tile buffers.  Measured on C2 (shader clock per workgroup of two 4096-sample windows): 265k ticks for
+// the chains in k_lpc's one-lane-per-chain loop, 140k here; staging 62k -> 20k (straight-line batches);
+// Levinson-Durbin + quantiser 60k -> 16k: it runs lane-parallel, one wave per window, lane j holds a[j]; the
+// dot product is multiplied in parallel and summed in the reference's order through v_readlane; the
+// reversed vector is a ds_bpermute.  The quantiser runs one lane per coefficient.
 // LDS: x[pack][x_region] | terms[2][nch][LB_K+2] | sq[2][pack][2*LB_K] | r[pack][order+1]
 // ---------------------------------------------------------------------------------------------
 #define LB_K 24
+#define LB_THREADS 512          // wave 0: lag accumulators, wave 1: energy accumulators, waves 2-7: term producers
+#define LB_PRODUCERS (LB_THREADS - 128)
 __device__ unsigned long long g_lpc_clk[8];   // SLA_HIP_LPC_CLK=1: shader-clock ticks per phase, summed over workgroups
 
 __device__ __forceinline__ double readlane_f64(double v, int lane)      // lane must be wave-uniform
@@ -349,10 +352,62 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)      // lane 
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 
+// Stage one analysis window into LDS: x[s] = w[s]*in[s] - 0.96875 * w[s-1]*in[s-1] (src/SLAEncoder.c:505-515,
+// 540-543, src/SLAPredictor.c:1803-1809) and return the wave's max |integer sample| (for the quantiser's
+// shift).  MS is a template parameter so that the batch below is straight-line code: all its samples are
+// requested before the first one is used (one memory latency per batch of 8, not per sample).
+template <bool MS>
+__device__ __forceinline__ uint32_t stage_window(const int32_t* __restrict__ pcm, uint64_t stride, const sla_hip_lpc_group& g,
+                                                 const double* __restrict__ win, double* __restrict__ x, uint32_t tid)
+{
+  const double scale = 4.656612873077392578125e-10;   // 2^-31, exact
+  const int32_t* p0 = pcm + (MS ? 0 : (uint64_t)g.channel * stride) + g.pcm_off;
+  const int32_t* p1 = pcm + stride + g.pcm_off;        // right channel (MS only)
+  uint32_t maxabs = 0;
+  for (uint32_t base = 0; base < g.num_samples; base += LB_THREADS * 8) {
+    int32_t l0[8], l1[8], r0[8], r1[8];
+    double w0[8], w1[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const uint32_t s = base + u * LB_THREADS + tid;
+      const bool in = (s < g.num_samples);
+      const uint32_t sc = in ? s : 0, sp = (in && s > 0) ? (s - 1) : 0;
+      l0[u] = p0[sc]; l1[u] = p0[sp];
+      if (MS) { r0[u] = p1[sc]; r1[u] = p1[sp]; }
+      w0[u] = win[sc]; w1[u] = win[sp];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const uint32_t s = base + u * LB_THREADS + tid;
+      if (s < g.num_samples) {
+        double cur, prev;
+        int32_t iv;
+        if (MS) {
+          // mid = (l+r)/2, side = l-r in double (src/SLAUtility.c:382-387); integers: (L+R)>>1, L-R on the shifted samples (:403-411)
+          const double a = (double)l0[u] * scale, b = (double)r0[u] * scale, c = (double)l1[u] * scale, d = (double)r1[u] * scale;
+          cur = (g.channel == 0) ? ((a + b) / 2) : (a - b);
+          prev = (g.channel == 0) ? ((c + d) / 2) : (c - d);
+          const int32_t li = l0[u] >> g.int_shift, ri = r0[u] >> g.int_shift;
+          iv = (g.channel == 0) ? ((int32_t)((uint32_t)li + (uint32_t)ri) >> 1) : (int32_t)((uint32_t)li - (uint32_t)ri);
+        } else {
+          cur = (double)l0[u] * scale; prev = (double)l1[u] * scale;
+          iv = l0[u] >> g.int_shift;
+        }
+        const double c = cur * w0[u];
+        const double pv = (s > 0) ? (prev * w1[u]) : 0.0;
+        x[s] = c - pv * 0.96875;
+        const uint32_t a = (iv > 0) ? (uint32_t)iv : (0u - (uint32_t)iv);
+        maxabs = (a > maxabs) ? a : maxabs;
+      }
+    }
+  }
+  return umax_wave(maxabs);
+}
+
 #define LB_ROW (LB_K + 2)     // terms of one chain and tile, padded: 16-byte aligned rows that spread over the banks
 
-template <int S>              // producer lanes per chain: 2, 4 or 8
-__global__ __launch_bounds__(256)
+template <int S>              // producer lanes per chain: 6 or 12
+__global__ __launch_bounds__(LB_THREADS)
 void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
                   const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, uint32_t pack,
                   const double* __restrict__ window_pool, double* __restrict__ out,
@@ -379,46 +434,18 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
   double* sq = terms + (size_t)2 * nch * LB_ROW;            // [2][pack][2*LB_K]
   double* r = sq + (size_t)2 * 2 * LB_K * pack;             // [pack][O1]
 
-  // ---- stage the windows: convert, mid/side, window, pre-emphasis (as k_lpc); a batch of samples is
-  //      requested before the first one is used (one memory latency per batch, not per sample) ----------
+  // ---- stage the windows: convert, mid/side, window, pre-emphasis (as k_lpc) -------------------------
   for (uint32_t k = 0; k < ng; k++) {
     const sla_hip_lpc_group g = s_g[k];
-    double* x = lds + (size_t)k * x_region;
-    const double* win = window_pool + g.win_off;
-    uint32_t maxabs = 0;
-    for (uint32_t base = 0; base < g.num_samples; base += 256 * 8) {
-      double cur[8], prev[8], w0[8], w1[8];
-      int32_t iv[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const uint32_t s = base + u * 256 + tid;
-        const bool in = (s < g.num_samples);
-        const uint32_t sc = in ? s : 0, sp = (in && s > 0) ? (s - 1) : 0;
-        cur[u] = load_f64(pcm, stride, ms, g.channel, g.pcm_off + sc);
-        prev[u] = load_f64(pcm, stride, ms, g.channel, g.pcm_off + sp);
-        w0[u] = win[sc]; w1[u] = win[sp];
-        iv[u] = load_int(pcm, stride, ms, g.channel, g.pcm_off + sc, g.int_shift);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const uint32_t s = base + u * 256 + tid;
-        if (s < g.num_samples) {
-          const double c = cur[u] * w0[u];
-          const double pv = (s > 0) ? (prev[u] * w1[u]) : 0.0;
-          x[s] = c - pv * 0.96875;            // (2^5-1)*2^-5, src/SLAPredictor.c:1803-1809
-          const uint32_t a = (iv[u] > 0) ? (uint32_t)iv[u] : (0u - (uint32_t)iv[u]);
-          maxabs = (a > maxabs) ? a : maxabs;
-        }
-      }
-    }
-    maxabs = umax_wave(maxabs);
+    const uint32_t maxabs = ms ? stage_window<true>(pcm, stride, g, window_pool + g.win_off, lds + (size_t)k * x_region, tid)
+                               : stage_window<false>(pcm, stride, g, window_pool + g.win_off, lds + (size_t)k * x_region, tid);
     if (lane == 0) { atomicMax(&s_maxabs[k], maxabs); }
   }
 
   // ---- chain geometry: the consumer lane and the producer lanes of a chain derive the same numbers ------
   const uint32_t nchains = ng * order;
-  const bool producer = (wv == 1 || wv == 2);
-  const uint32_t pl = tid - 64;                             // producer lane number (valid when producer)
+  const bool producer = (wv >= 2);
+  const uint32_t pl = tid - 128;                            // producer lane number (valid when producer)
   const uint32_t ch = (wv == 0) ? lane : (producer ? (pl % nch) : 0xFFFFFFFFu);
   const uint32_t j = producer ? (pl / nch) : 0;             // which Q-term piece of the tile this producer lane makes
   const bool has_chain = (ch < nchains) && (!producer || j < (uint32_t)S);
@@ -445,17 +472,32 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
   // producer position: term kk = tile*LB_K + j*Q sits at (run pi, step pg) while it is a pair term
   uint32_t kk = j * Q;
   uint32_t pi = (grp != 0) ? (kk / grp) : 0, pg = (grp != 0) ? (kk - (kk / grp) * grp) : 0;
+  uint32_t ppos = pi + pg * lag2;                           // sample index of a of that term
   // energy producer: lane e < 2*LB_K*ng makes the square of sample tile*2*LB_K + es of window ew
   const uint32_t nsq = 2 * LB_K * ng;
-  const uint32_t ew = pl / (2 * LB_K), es = pl - ew * (2 * LB_K);      // 2*LB_K*LPC_MAX_PACK = 192 > 128: second round below
+  const uint32_t ew = pl / (2 * LB_K), es = pl - ew * (2 * LB_K);      // 2*LB_K*LPC_MAX_PACK = 192 <= LB_PRODUCERS
 
   double acc = 0.0;
   for (uint32_t t = 0; t <= ntiles; t++) {
     const unsigned long long t_a = clk ? clock64() : 0;
     if (producer && t < ntiles) {
-      if (has_chain) {
+      // most tiles: every lane of this wave makes Q consecutive pair terms of one run -- no bookkeeping, and
+      // b of one term is a of the next
+      const bool plain = !has_chain || (kk + Q <= npair && pg + Q <= grp);
+      if (__all(plain)) {
+        if (has_chain) {
+          double* dst = terms + ((size_t)(t & 1) * nch + ch) * LB_ROW + j * Q;
+          const double* p = xs + ppos;
+          double va[Q + 1], vc[Q];
+#pragma unroll
+          for (int q = 0; q < (int)Q; q++) { va[q] = p[q * lag2]; vc[q] = p[q * lag2 + lag]; }
+          va[Q] = p[Q * lag2];
+#pragma unroll
+          for (int q = 0; q < (int)Q; q++) { dst[q] = vc[q] * (va[q] + va[q + 1]); }
+        }
+      } else if (has_chain) {
         double* dst = terms + ((size_t)(t & 1) * nch + ch) * LB_ROW + j * Q;
-        uint32_t ii = pi, gg = pg, pos = pi + pg * lag2;
+        uint32_t ii = pi, gg = pg, pos = ppos;
         uint32_t ia[Q]; bool pr[Q], vl[Q];
 #pragma unroll
         for (int q = 0; q < (int)Q; q++) {
@@ -475,8 +517,10 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
           const double tv = vc[q] * (va[q] + (pr[q] ? vb[q] : 0.0));      // leftover products: c*a (a+0.0 == a up to the sign of zero, which a sum that starts at +0.0 cannot see)
           dst[q] = vl[q] ? tv : 0.0;
         }
+      }
+      if (has_chain) {
         kk += LB_K;
-        if (grp != 0) { pg += LB_K; while (pg >= grp) { pg -= grp; pi++; } }
+        if (grp != 0) { pg += LB_K; ppos += LB_K * lag2; while (pg >= grp) { pg -= grp; pi++; ppos += 1 - span; } }
       }
       double* dq = sq + (size_t)(t & 1) * 2 * LB_K * pack;
       if (pl < nsq) {
@@ -484,30 +528,32 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
         const double v = (idx < s_g[ew].num_samples) ? lds[(size_t)ew * x_region + idx] : 0.0;
         dq[ew * 2 * LB_K + es] = v * v;
       }
-      if (pl + 128 < nsq) {
-        const uint32_t e2 = pl + 128, w2 = e2 / (2 * LB_K), s2 = e2 - w2 * (2 * LB_K);
-        const uint32_t idx = t * 2 * LB_K + s2;
-        const double v = (idx < s_g[w2].num_samples) ? lds[(size_t)w2 * x_region + idx] : 0.0;
-        dq[w2 * 2 * LB_K + s2] = v * v;
-      }
     }
     const unsigned long long t_b = clk ? clock64() : 0;
     if (t >= 1) {
       if (wv == 0 && has_chain) {
         const double2* src = (const double2*)(terms + ((size_t)((t - 1) & 1) * nch + ch) * LB_ROW);
+        double2 v[LB_K / 2];
 #pragma unroll
-        for (int q = 0; q < LB_K / 2; q++) { const double2 v = src[q]; acc += v.x; acc += v.y; }
-      } else if (wv == 3 && lane < ng) {
+        for (int q = 0; q < LB_K / 2; q++) { v[q] = src[q]; }
+        __builtin_amdgcn_sched_barrier(0);          // every load of the tile is in flight before the first add waits
+#pragma unroll
+        for (int q = 0; q < LB_K / 2; q++) { acc += v[q].x; acc += v[q].y; }
+      } else if (wv == 1 && lane < ng) {
         const double2* src = (const double2*)(sq + (size_t)((t - 1) & 1) * 2 * LB_K * pack + lane * 2 * LB_K);
+        double2 v[LB_K];
 #pragma unroll
-        for (int q = 0; q < LB_K; q++) { const double2 v = src[q]; acc += v.x; acc += v.y; }
+        for (int q = 0; q < LB_K; q++) { v[q] = src[q]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < LB_K; q++) { acc += v[q].x; acc += v[q].y; }
       }
     }
     if (clk) { const unsigned long long t_c = clock64(); t_prod += t_b - t_a; t_cons += t_c - t_b; }
     __syncthreads();
   }
   if (wv == 0 && has_chain) { r[ck * O1 + lag] = acc; }
-  if (wv == 3 && lane < ng) { r[lane * O1] = acc; }
+  if (wv == 1 && lane < ng) { r[lane * O1] = acc; }
   __syncthreads();
   const unsigned long long t_chained = clk ? clock64() : 0;
 
@@ -565,8 +611,8 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
       atomicAdd(&g_lpc_clk[0], t_staged - t_start); atomicAdd(&g_lpc_clk[1], t_chained - t_staged);
       atomicAdd(&g_lpc_clk[2], t_end - t_chained); atomicAdd(&g_lpc_clk[3], 1ull); atomicAdd(&g_lpc_clk[4], t_cons);
     }
-    if (wv == 1) { atomicAdd(&g_lpc_clk[5], t_prod); }
-    if (wv == 3) { atomicAdd(&g_lpc_clk[6], t_cons); }
+    if (wv == 2) { atomicAdd(&g_lpc_clk[5], t_prod); }
+    if (wv == 1) { atomicAdd(&g_lpc_clk[6], t_cons); }
   }
 }
 
@@ -1209,20 +1255,17 @@ extern "C" int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, u
       const size_t xr = ((size_t)max_window + 1) & ~(size_t)1;       // even: the term rows behind the windows are read as 16-byte pairs
       const size_t bytes = sizeof(double) * ((size_t)p * xr + (size_t)2 * LB_ROW * nch + (size_t)2 * 2 * LB_K * p + (size_t)p * (order + 1));
       if (bytes > SLA_HIP_LDS_BUDGET) { continue; }
-      const uint32_t spl = (128 / nch < 8) ? (128 / nch) : 8;       // producer lanes per chain
-      const void* fn = (spl == 2) ? (const void*)k_lpc_blocks<2> : (spl == 4) ? (const void*)k_lpc_blocks<4> : (const void*)k_lpc_blocks<8>;
+      const uint32_t spl = (nch <= 32) ? 12 : 6;                    // producer lanes per chain: nch * spl <= LB_PRODUCERS
+      const void* fn = (spl == 12) ? (const void*)k_lpc_blocks<12> : (const void*)k_lpc_blocks<6>;
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
       if (e != hipSuccess) { return hip_rc(e); }
-      const dim3 grid((num_groups + p - 1) / p), block(256);
+      const dim3 grid((num_groups + p - 1) / p), block(LB_THREADS);
       const uint32_t clk = (uint32_t)(getenv("SLA_HIP_LPC_CLK") != nullptr);
-      if (spl == 2) {
-        hipLaunchKernelGGL(k_lpc_blocks<2>, grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
-                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk);
-      } else if (spl == 4) {
-        hipLaunchKernelGGL(k_lpc_blocks<4>, grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
+      if (spl == 12) {
+        hipLaunchKernelGGL(k_lpc_blocks<12>, grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
                            d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk);
       } else {
-        hipLaunchKernelGGL(k_lpc_blocks<8>, grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
+        hipLaunchKernelGGL(k_lpc_blocks<6>, grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
                            d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk);
       }
       if (getenv("SLA_HIP_LPC_CLK") != nullptr) {
@@ -1230,7 +1273,7 @@ extern "C" int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, u
         hipStreamSynchronize((hipStream_t)stream);
         hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lpc_clk), sizeof(h));
         hipMemcpyToSymbol(HIP_SYMBOL(g_lpc_clk), z, sizeof(z));
-        int occ = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, bytes);
+        int occ = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, LB_THREADS, bytes);
         if (h[3] != 0) {
           fprintf(stderr, "[k_lpc_blocks] LDS %zu B, %d workgroups per CU; ", bytes, occ);
           fprintf(stderr, "[k_lpc_blocks] %llu workgroups (pack %u), ticks per workgroup: stage %llu, chains %llu (lag consumer busy %llu, producer busy %llu, energy consumer busy %llu), levinson+quantiser %llu\n",
