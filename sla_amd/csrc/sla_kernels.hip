@@ -1028,24 +1028,56 @@ void k_tail(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, u
 // and for the bit-reversed scatter.
 __device__ __forceinline__ uint32_t acf_sw(uint32_t c) { return c ^ (((c >> 4) ^ (c >> 8) ^ (c >> 12)) & 15u); }
 
+// One radix-2 butterfly of the reference's four1 loop (src/SLAUtility.c:220-260): same products, same order.
+__device__ __forceinline__ void acf_bfly(double2& zi, double2& zq, double wr, double wi)
+{
+  const double tr = wr * zq.x - wi * zq.y;
+  const double ti = wr * zq.y + wi * zq.x;
+  zq = make_double2(zi.x - tr, zi.y - ti);
+  zi = make_double2(zi.x + tr, zi.y + ti);
+}
+
+// R consecutive radix-2 stages (half-spans h, 2h, .., h<<(R-1)) on the 2^R points ci + m*h that only
+// exchange data among themselves: one LDS round trip and one barrier instead of R, 2^R - 1 twiddles instead
+// of R * 2^(R-1).  Every butterfly is the radix-2 one above on the same operands, so the results are the
+// radix-2 results bit for bit (the order of butterflies inside a stage is free).
+template <int R>
+__device__ __forceinline__ void acf_pass(double2* z, uint32_t npts, uint32_t log2h, const double* __restrict__ twr,
+                                         const double* __restrict__ twi)
+{
+  constexpr uint32_t P = 1u << R;
+  const uint32_t h = 1u << log2h;
+  for (uint32_t b = threadIdx.x; b < (npts >> R); b += ACF_THREADS) {
+    const uint32_t low = b & (h - 1), ci = low + ((b >> log2h) << (log2h + R));
+    double2 v[P];
+#pragma unroll
+    for (uint32_t m = 0; m < P; m++) { v[m] = z[acf_sw(ci + m * h)]; }
+#pragma unroll
+    for (int st = 0; st < R; st++) {
+      const uint32_t hs = h << st;                      // half-span of this stage; its twiddles start at hs - 1
+#pragma unroll
+      for (uint32_t m = 0; m < P; m++) {
+        if ((m >> st) & 1u) { continue; }
+        const uint32_t k = low + (m & ((1u << st) - 1u)) * h;
+        acf_bfly(v[m], v[m + (1u << st)], twr[hs - 1 + k], twi[hs - 1 + k]);
+      }
+    }
+#pragma unroll
+    for (uint32_t m = 0; m < P; m++) { z[acf_sw(ci + m * h)] = v[m]; }
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ void acf_stages(double2* z, uint32_t log2npts, const double* __restrict__ twr,
                                            const double* __restrict__ twi)
 {
   const uint32_t npts = 1u << log2npts;
   uint32_t log2h = 0;
-  for (uint32_t h = 1; h < npts; h <<= 1, log2h++) {          // h = half-span in complex points
-    const uint32_t base = h - 1;
-    for (uint32_t b = threadIdx.x; b < (npts >> 1); b += ACF_THREADS) {
-      const uint32_t k = b & (h - 1), blk = b >> log2h;
-      const uint32_t ci = k + blk * 2 * h, cq = ci + h;
-      const double wr = twr[base + k], wi = twi[base + k];
-      const double2 zq = z[acf_sw(cq)], zi = z[acf_sw(ci)];
-      const double tr = wr * zq.x - wi * zq.y;
-      const double ti = wr * zq.y + wi * zq.x;
-      z[acf_sw(cq)] = make_double2(zi.x - tr, zi.y - ti);
-      z[acf_sw(ci)] = make_double2(zi.x + tr, zi.y + ti);
-    }
-    __syncthreads();
+  while (log2h < log2npts) {
+    const uint32_t left = log2npts - log2h;
+    if (left >= 3 && left != 4) { acf_pass<3>(z, npts, log2h, twr, twi); log2h += 3; }
+    else if (left >= 2) { acf_pass<2>(z, npts, log2h, twr, twi); log2h += 2; }
+    else { acf_pass<1>(z, npts, log2h, twr, twi); log2h += 1; }
   }
 }
 
