@@ -257,7 +257,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
       || hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess) { free(e); return NULL; }
   for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { if (hipEventCreate(&e->ev[i]) != hipSuccess) { free(e); return NULL; } }
   if (hipEventCreate(&e->ev_stage[0]) != hipSuccess || hipEventCreate(&e->ev_stage[1]) != hipSuccess) { free(e); return NULL; }
-  e->chunks = 2;
+  e->chunks = 3;
   env = getenv("SLA_HIP_CHUNKS");
   if (env != NULL && atoi(env) > 0) { e->chunks = (uint32_t)atoi(env); }
   env = getenv("SLA_HIP_CHUNK_SPLIT");
@@ -1125,9 +1125,10 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   if (want_chunks < 1) { want_chunks = 1; }
   a.nchunks = want_chunks;
   /* chunk boundaries in 1/1000 of the super-frames: equal parts unless SLA_HIP_CHUNK_SPLIT gave the shares */
-  if (e->split_count != a.nchunks && a.nchunks == 2) {
-    /* measured on C2: a short first chunk fills the pipeline sooner (the host plans it while nothing else can run) */
-    e->chunk_cut[0] = 0; e->chunk_cut[1] = 300; e->chunk_cut[2] = 1000;
+  if (e->split_count != a.nchunks && a.nchunks == 3) {
+    /* measured on C2: a shorter first chunk fills the pipeline sooner (the host plans it while nothing else can
+     * run), and k_tail -- latency-bound, one wave per SIMD -- costs the same for any chunk up to 1024 waves */
+    e->chunk_cut[0] = 0; e->chunk_cut[1] = 250; e->chunk_cut[2] = 625; e->chunk_cut[3] = 1000;
   } else if (e->split_count != a.nchunks) {
     for (c = 0; c <= a.nchunks; c++) { e->chunk_cut[c] = 1000u * c / a.nchunks; }
   } else {

@@ -893,6 +893,13 @@ __device__ __forceinline__ int32_t sgn(int32_t v)          // clamp to [-1, 1] =
   return r;
 }
 
+__device__ __forceinline__ int32_t mad24(int32_t a, int32_t b, int32_t c)      // a, b within 24 bits; c + a*b wraps like int32
+{
+  int32_t r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // all lanes of the permutation are valid, so old = 0 / bound_ctrl lets the add absorb the DPP read
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t x)
@@ -933,8 +940,10 @@ __device__ __forceinline__ int32_t tail_block(int32_t v_mine, uint32_t grp_base,
       e = (int32_t)((uint32_t)v - (uint32_t)p);
       const uint32_t mag = (uint32_t)max(e, (int32_t)(0u - (uint32_t)e));
       const int32_t lg = 32 - (int32_t)__clz((int)mag);                    // ceil(log2(|e|+1)); __clz(0) = 32
-      const int32_t step = sgn(e) * (lg >> 1);                              // table src/SLAPredictor.c:123-144
-      coef += step * sgn(h);
+      // step in [-16,16] and sign(h) in [-1,1] fit 24 bits: full-rate v_mul_i32_i24 / v_mad_i32_i24 instead of the
+      // quarter-rate 32-bit multiplies (only coef*h needs those)
+      const int32_t step = __mul24(sgn(e), lg >> 1);                        // table src/SLAPredictor.c:123-144
+      coef = mad24(step, sgn(h), coef);
       ph = p;
     }
     // history: lane t takes lane t-1; the group's first FIR / IIR lane takes the new input / prediction
