@@ -1,3 +1,4 @@
+#define _GNU_SOURCE
 /*
  * sla_encoder.c -- host orchestration of the MI355X SLA encode path (plain C).
  *
@@ -20,6 +21,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -135,19 +137,25 @@ static int pin_reserve(pinbuf_t* b, size_t bytes)
 /* Persistent host worker pool: run fn(ctx, i) for i in [0,count).  The scalar host stages between
  * kernel launches (code-length logs + Dijkstra, long-term solve, block packing) are short, so paying
  * pthread_create per stage would be a visible fraction of them. */
+/* Persistent worker pool.  The pipeline issues many short parallel loops (tens of microseconds of work each)
+ * in quick succession, so workers spin on the generation counter for a while before they go to sleep on the
+ * condition variable: a futex wake-up costs about as much as one of these loops. */
 struct slai_pool {
   pthread_t tid[64];
   uint32_t nworkers;                 /* threads besides the caller */
   pthread_mutex_t mu;
-  pthread_cond_t cv_start, cv_done;
-  uint64_t generation;
+  pthread_cond_t cv_start;
+  uint64_t generation;               /* atomic */
+  uint32_t sleepers;                 /* under mu */
   int shutdown;
   void (*fn)(void*, uint32_t);
   void* ctx;
   uint32_t count, grain;
-  volatile uint32_t next;
-  uint32_t busy;
+  uint32_t next;                     /* atomic */
+  uint32_t busy;                     /* atomic: workers that have not finished the current generation */
 };
+
+#define POOL_SPINS 40000u            /* ~200 us of pause instructions before a worker sleeps */
 
 static void pool_drain(struct slai_pool* p)
 {
@@ -163,17 +171,21 @@ static void* pool_worker(void* arg)
 {
   struct slai_pool* p = (struct slai_pool*)arg;
   uint64_t seen = 0;
-  pthread_mutex_lock(&p->mu);
   for (;;) {
-    while (!p->shutdown && p->generation == seen) { pthread_cond_wait(&p->cv_start, &p->mu); }
+    uint32_t spins = 0;
+    while (__atomic_load_n(&p->generation, __ATOMIC_ACQUIRE) == seen && spins < POOL_SPINS) { __builtin_ia32_pause(); spins++; }
+    if (__atomic_load_n(&p->generation, __ATOMIC_ACQUIRE) == seen) {
+      pthread_mutex_lock(&p->mu);
+      p->sleepers++;
+      while (!p->shutdown && __atomic_load_n(&p->generation, __ATOMIC_ACQUIRE) == seen) { pthread_cond_wait(&p->cv_start, &p->mu); }
+      p->sleepers--;
+      pthread_mutex_unlock(&p->mu);
+    }
     if (p->shutdown) { break; }
-    seen = p->generation;
-    pthread_mutex_unlock(&p->mu);
+    seen = __atomic_load_n(&p->generation, __ATOMIC_ACQUIRE);
     pool_drain(p);
-    pthread_mutex_lock(&p->mu);
-    if (--p->busy == 0) { pthread_cond_signal(&p->cv_done); }
+    __atomic_fetch_sub(&p->busy, 1, __ATOMIC_RELEASE);
   }
-  pthread_mutex_unlock(&p->mu);
   return NULL;
 }
 
@@ -184,7 +196,6 @@ static struct slai_pool* pool_create(uint32_t threads)
   if (p == NULL) { return NULL; }
   pthread_mutex_init(&p->mu, NULL);
   pthread_cond_init(&p->cv_start, NULL);
-  pthread_cond_init(&p->cv_done, NULL);
   if (threads > 64) { threads = 64; }
   for (t = 1; t < threads; t++) {
     if (pthread_create(&p->tid[p->nworkers], NULL, pool_worker, p) == 0) { p->nworkers++; }
@@ -198,10 +209,11 @@ static void pool_destroy(struct slai_pool* p)
   if (p == NULL) { return; }
   pthread_mutex_lock(&p->mu);
   p->shutdown = 1;
+  __atomic_fetch_add(&p->generation, 1, __ATOMIC_RELEASE);
   pthread_cond_broadcast(&p->cv_start);
   pthread_mutex_unlock(&p->mu);
   for (t = 0; t < p->nworkers; t++) { pthread_join(p->tid[t], NULL); }
-  pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_start); pthread_cond_destroy(&p->cv_done);
+  pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_start);
   free(p);
 }
 
@@ -213,18 +225,17 @@ static void parallel_for(struct slai_pool* p, uint32_t count, void (*fn)(void*, 
     for (i = 0; i < count; i++) { fn(ctx, i); }
     return;
   }
-  pthread_mutex_lock(&p->mu);
-  p->fn = fn; p->ctx = ctx; p->count = count; p->next = 0;
+  p->fn = fn; p->ctx = ctx; p->count = count;
+  __atomic_store_n(&p->next, 0, __ATOMIC_RELAXED);
   p->grain = count / ((p->nworkers + 1) * 8);
   if (p->grain == 0) { p->grain = 1; }
-  p->busy = p->nworkers;
-  p->generation++;
-  pthread_cond_broadcast(&p->cv_start);
+  __atomic_store_n(&p->busy, p->nworkers, __ATOMIC_RELAXED);
+  pthread_mutex_lock(&p->mu);                     /* the lock orders the bump against a worker that is about to sleep */
+  __atomic_fetch_add(&p->generation, 1, __ATOMIC_RELEASE);
+  if (p->sleepers != 0) { pthread_cond_broadcast(&p->cv_start); }
   pthread_mutex_unlock(&p->mu);
   pool_drain(p);
-  pthread_mutex_lock(&p->mu);
-  while (p->busy != 0) { pthread_cond_wait(&p->cv_done, &p->mu); }
-  pthread_mutex_unlock(&p->mu);
+  while (__atomic_load_n(&p->busy, __ATOMIC_ACQUIRE) != 0) { __builtin_ia32_pause(); }
 }
 
 /* ------------------------------------------------------------- create / destroy */
@@ -283,9 +294,13 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
     if (fft < 8) { fft = 8; }
     e->fft = slai_fft_plan_create(fft);
   }
-  e->threads = (uint32_t)sysconf(_SC_NPROCESSORS_ONLN);
+  {
+    cpu_set_t set;
+    e->threads = (uint32_t)sysconf(_SC_NPROCESSORS_ONLN);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0 && (uint32_t)CPU_COUNT(&set) < e->threads) { e->threads = (uint32_t)CPU_COUNT(&set); }
+  }
   if (e->threads < 1) { e->threads = 1; }
-  if (e->threads > 32) { e->threads = 32; }
+  if (e->threads > 16) { e->threads = 16; }       /* the loops are short: more workers only add wake-up and join time */
   env = getenv("SLA_HIP_THREADS");
   if (env != NULL && atoi(env) > 0) { e->threads = (uint32_t)atoi(env); }
   e->pool = pool_create(e->threads);
