@@ -120,8 +120,8 @@ typedef struct sla_hip_pack_block {
 
 /* ---- (1) kernel launchers ----------------------------------------------- */
 
-/* OR of every input word + one bit per sample "any channel non-zero after
- * right-justify / mid-side".  nz_mask has ceil(num_samples/64) words. */
+/* d_or_mask[0] = OR of every input word, d_or_mask[1] = number of all-zero words of the mask; d_nz_mask: one
+ * bit per sample "any channel non-zero after right-justify / mid-side", ceil(num_samples/64) words. */
 int sla_hip_launch_prepass(const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_channels,
                            uint32_t num_samples, uint32_t bits_per_sample, uint32_t mid_side,
                            uint32_t* d_or_mask, uint64_t* d_nz_mask, sla_hip_stream_t stream);

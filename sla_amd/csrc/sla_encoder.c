@@ -73,6 +73,7 @@ struct SLAEncoder {
   pinbuf_t h_nz, h_groups, h_cands, h_lpc_out, h_code, h_kint, h_rshift, h_chunks, h_jobs, h_fold, h_res, h_pcm, h_acf_jobs, h_acf,
            h_bgroups, h_bcands, h_blk_out, h_pk_jobs, h_pk_blocks, h_pk_hdr, h_xgroups, h_fgroups;
   uint32_t* h_or;
+  void* nz_ones_ptr; uint64_t nz_ones_words;     /* h_nz words [0, nz_ones_words) are known to be all ones */
   pinbuf_t h_stage[2]; devbuf_t d_stage[2]; hipEvent_t ev_stage[2];
 
   /* window pool: tables for every block length seen so far */
@@ -564,9 +565,28 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
   HIPCHK(hipEventRecord(e->ev[0], e->stream));
   RCCHK(sla_hip_launch_prepass(e->pcm_dev, e->stride, C, n, bps, ms, (uint32_t*)e->d_or.ptr, (uint64_t*)e->d_nz.ptr, e->stream));
   HIPCHK(hipEventRecord(e->ev[1], e->stream));
-  HIPCHK(hipMemcpyAsync(e->h_or, e->d_or.ptr, 4, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipMemcpyAsync(e->h_nz.ptr, e->d_nz.ptr, (size_t)nwords * 8, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
+  {
+    /* Without an all-zero mask word there is no silence to find, except at the very end of the file where the
+     * minimum block length shrinks with what is left (src/SLAEncoder.c:846-869): only the last words of the mask
+     * are fetched then, everything before them counts as "not silent" (a run of zeros shorter than the minimum
+     * block length never changes a decision). */
+    const uint64_t tail_words = (nwords < SLAI_MIN_BLOCK / 64 + 2) ? nwords : (SLAI_MIN_BLOCK / 64 + 2);
+    const uint64_t head_words = nwords - tail_words;
+    HIPCHK(hipMemcpyAsync(e->h_or, e->d_or.ptr, 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync((uint64_t*)e->h_nz.ptr + head_words, (uint64_t*)e->d_nz.ptr + head_words, (size_t)tail_words * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->h_or[1] != 0) {
+      HIPCHK(hipMemcpyAsync(e->h_nz.ptr, e->d_nz.ptr, (size_t)head_words * 8, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      e->nz_ones_words = 0;
+    } else {
+      if (e->nz_ones_ptr != e->h_nz.ptr) { e->nz_ones_ptr = e->h_nz.ptr; e->nz_ones_words = 0; }
+      if (e->nz_ones_words < head_words) {
+        memset((uint64_t*)e->h_nz.ptr + e->nz_ones_words, 0xFF, (size_t)(head_words - e->nz_ones_words) * 8);
+      }
+      e->nz_ones_words = head_words;       /* the words behind it were just overwritten by the tail copy */
+    }
+  }
   nz = (const uint64_t*)e->h_nz.ptr;
   ((uint64_t*)e->h_nz.ptr)[nwords] = 0; ((uint64_t*)e->h_nz.ptr)[nwords + 1] = 0;
 
@@ -1677,6 +1697,7 @@ SLAApiResult SLAEncoder_EncodeBlock(struct SLAEncoder* e, const int32_t* const* 
   if (hipMemcpyAsync(e->h_nz.ptr, e->d_nz.ptr, (size_t)nwords * 8, hipMemcpyDeviceToHost, e->stream) != hipSuccess
       || hipStreamSynchronize(e->stream) != hipSuccess) { return SLA_APIRESULT_NG; }
   ((uint64_t*)e->h_nz.ptr)[nwords] = 0;
+  e->nz_ones_words = 0;
   e->num_blocks = 0;
   if (blocks_push(e, 0, num_samples, slai_range_is_zero((const uint64_t*)e->h_nz.ptr, 0, num_samples) ? SLAI_BLK_SILENT : SLAI_BLK_COMPRESS) != 0) {
     return SLA_APIRESULT_NG;

@@ -57,31 +57,70 @@ __device__ __forceinline__ uint32_t umax_wave(uint32_t v)
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_prepass: one 64-bit "non-zero" word per 64 samples + OR of every raw word
+// k_prepass: one 64-bit "non-zero" word per 64 samples, OR of every raw word, count of all-zero words.
+// A wave owns 16 consecutive mask words = 1024 samples and reads them fully coalesced, four words'
+// worth of samples in flight at a time (the kernel is a pure HBM stream: 4 B per sample and channel).
+// The count lets the host skip the copy of the mask when the file has no silence to find: a silent run
+// long enough to become a block (>= 2048 samples) contains all-zero words.
 // ---------------------------------------------------------------------------------------------
+#define PREPASS_WORDS 16    // mask words per wave: enough waves in flight to cover the HBM latency
+template <int NCH>      // 1, 2 or 0 = any
 __global__ __launch_bounds__(256)
-void k_prepass(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t nch, uint32_t n,
+void k_prepass(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t nch_rt, uint32_t n,
                uint32_t shift, uint32_t ms, uint32_t* __restrict__ or_mask, uint64_t* __restrict__ nz_mask)
 {
+  const uint32_t nch = (NCH != 0) ? (uint32_t)NCH : nch_rt;
   const uint32_t lane = threadIdx.x & 63;
   const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint64_t nwords = ((uint64_t)n + 63) / 64;
-  uint32_t acc = 0;
-  // each wave owns 64 consecutive mask words = 4096 samples, read fully coalesced
-  for (uint32_t w = 0; w < 64; w++) {
-    uint64_t word = wave * 64 + w;
-    if (word >= nwords) { break; }
-    uint64_t idx = word * 64 + lane;
-    bool nz = false;
-    if (idx < n) {
-      for (uint32_t c = 0; c < nch; c++) { acc |= (uint32_t)pcm[(uint64_t)c * stride + idx]; }
-      for (uint32_t c = 0; c < nch; c++) { nz = nz || (load_int(pcm, stride, ms, c, idx, shift) != 0); }
+  uint32_t acc = 0, zero_words = 0;
+  for (uint32_t w0 = 0; w0 < PREPASS_WORDS; w0 += 4) {
+    const uint64_t word0 = wave * PREPASS_WORDS + w0;
+    if (word0 >= nwords) { break; }
+    if (NCH == 1 || NCH == 2) {
+      int32_t a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint64_t idx = (word0 + u) * 64 + lane;
+        const bool in = (idx < n);
+        a[u] = in ? pcm[idx] : 0;
+        b[u] = (NCH == 2 && in) ? pcm[stride + idx] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        acc |= (uint32_t)a[u] | (uint32_t)b[u];
+        bool nz;
+        if (NCH == 2 && ms) {
+          const int32_t l = a[u] >> shift, r = b[u] >> shift;
+          nz = (((int32_t)((uint32_t)l + (uint32_t)r) >> 1) != 0) || ((uint32_t)l != (uint32_t)r);
+        } else {
+          nz = ((a[u] >> shift) != 0) || ((b[u] >> shift) != 0);
+        }
+        const uint64_t bits = __ballot(nz);
+        if (word0 + u < nwords) {
+          if (lane == 0) { nz_mask[word0 + u] = bits; }
+          zero_words += (bits == 0) ? 1u : 0u;
+        }
+      }
+    } else {
+      for (uint32_t u = 0; u < 4; u++) {
+        const uint64_t idx = (word0 + u) * 64 + lane;
+        bool nz = false;
+        if (idx < n) {
+          for (uint32_t c = 0; c < nch; c++) { acc |= (uint32_t)pcm[(uint64_t)c * stride + idx]; }
+          for (uint32_t c = 0; c < nch; c++) { nz = nz || (load_int(pcm, stride, ms, c, idx, shift) != 0); }
+        }
+        const uint64_t bits = __ballot(nz);
+        if (word0 + u < nwords) {
+          if (lane == 0) { nz_mask[word0 + u] = bits; }
+          zero_words += (bits == 0) ? 1u : 0u;
+        }
+      }
     }
-    uint64_t bits = __ballot(nz);
-    if (lane == 0) { nz_mask[word] = bits; }
   }
   for (int off = 32; off > 0; off >>= 1) { acc |= __shfl_xor(acc, off); }
   if (lane == 0 && acc != 0) { atomicOr(or_mask, acc); }
+  if (lane == 0 && zero_words != 0) { atomicAdd(or_mask + 1, zero_words); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1258,13 +1297,19 @@ extern "C" int sla_hip_launch_prepass(const int32_t* d_pcm, uint64_t plane_strid
   if (num_channels == 0 || num_channels > 8 || bits_per_sample == 0 || bits_per_sample > 32
       || plane_stride < num_samples || (mid_side && num_channels != 2)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(d_or_mask, 0, sizeof(uint32_t), st);
+  hipError_t e = hipMemsetAsync(d_or_mask, 0, 2 * sizeof(uint32_t), st);
   if (e != hipSuccess) { return hip_rc(e); }
   if (num_samples == 0) { return 0; }
   uint64_t nwords = ((uint64_t)num_samples + 63) / 64;
-  uint32_t nblocks = (uint32_t)((nwords + 255) / 256);
-  hipLaunchKernelGGL(k_prepass, dim3(nblocks), dim3(256), 0, st, d_pcm, plane_stride, num_channels, num_samples,
-                     32u - bits_per_sample, mid_side, d_or_mask, d_nz_mask);
+  uint32_t nblocks = (uint32_t)((nwords + 4 * PREPASS_WORDS - 1) / (4 * PREPASS_WORDS));
+  const uint32_t shift = 32u - bits_per_sample;
+  if (num_channels == 1) {
+    hipLaunchKernelGGL(k_prepass<1>, dim3(nblocks), dim3(256), 0, st, d_pcm, plane_stride, num_channels, num_samples, shift, mid_side, d_or_mask, d_nz_mask);
+  } else if (num_channels == 2) {
+    hipLaunchKernelGGL(k_prepass<2>, dim3(nblocks), dim3(256), 0, st, d_pcm, plane_stride, num_channels, num_samples, shift, mid_side, d_or_mask, d_nz_mask);
+  } else {
+    hipLaunchKernelGGL(k_prepass<0>, dim3(nblocks), dim3(256), 0, st, d_pcm, plane_stride, num_channels, num_samples, shift, mid_side, d_or_mask, d_nz_mask);
+  }
   return hip_rc(hipGetLastError());
 }
 

@@ -191,6 +191,18 @@ def test_silence_inside_a_frame(oracle, hip):
     assert_same_as_oracle(oracle, hip, p, pcm)
 
 
+@pytest.mark.parametrize("tail", [1, 10, 63, 64, 100, 2047])
+def test_short_silent_tail_without_a_zero_mask_word(oracle, hip, tail):
+    """the last super-frame may be a silent block shorter than one 64-sample mask word: the host must not
+    rely on the all-zero-word count there (it only fetches the end of the mask when the count is 0)"""
+    n = 3 * 4096 + tail
+    pcm = W.music_like(2, n, 16, seed=tail)
+    pcm[pcm == 0] = 1 << 16                 # no accidental zero samples elsewhere
+    pcm[:, 3 * 4096:] = 0
+    p = S.make_params(2, 16, 44100, parcor=8, ltm=1, lms=4, ms=1, max_block=4096)
+    assert_same_as_oracle(oracle, hip, p, np.ascontiguousarray(pcm))
+
+
 def test_raw_fallback(oracle, hip):
     pcm = W.gen("white", 2, 20000, 16, seed=2)
     p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096)
