@@ -119,7 +119,8 @@ void k_prepass(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t nch_rt
     }
   }
   for (int off = 32; off > 0; off >>= 1) { acc |= __shfl_xor(acc, off); }
-  if (lane == 0 && acc != 0) { atomicOr(or_mask, acc); }
+  // thousands of waves, one word: only the few that still add a bit pay for the atomic (a stale read just costs one)
+  if (lane == 0 && (acc & ~__atomic_load_n(or_mask, __ATOMIC_RELAXED)) != 0) { atomicOr(or_mask, acc); }
   if (lane == 0 && zero_words != 0) { atomicAdd(or_mask + 1, zero_words); }
 }
 
