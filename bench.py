@@ -143,11 +143,13 @@ def main():
         nchunks = max(int(round(kernel_ms[9])), 1)
         exact_search = kernel_ms[11] > 0.5      # partition search ran on tile sums, k_lpc only on the chosen blocks
         kernels = {"k_prepass": (kernel_ms[0], 1, 1),
-                   "k_lpc": (kernel_ms[2], nchunks, 1) if exact_search else (kernel_ms[1] + kernel_ms[2], 2 * nchunks, 2),
+                   "k_lpc_blocks": (kernel_ms[2], nchunks, 1),
                    "k_lattice": (kernel_ms[3], nchunks, 1), "k_ltm_acf": (kernel_ms[8], nchunks, 1),
                    "k_tail": (kernel_ms[4], nchunks, 1)}
         if exact_search:
-            kernels["k_acf_tiles+k_search_finish"] = (kernel_ms[1], nchunks, 1)
+            kernels["k_acf_tiles"] = (kernel_ms[1], nchunks, 1)      # the event pair also spans k_search_finish
+        else:
+            kernels["k_lpc"] = (kernel_ms[1], nchunks, 1)            # serial-chain partition search
         dom = max(kernels, key=lambda k: kernels[k][0])
         t_step, launches, passes = kernels[dom]
         launch_ms = t_step / launches

@@ -968,27 +968,41 @@ __device__ __forceinline__ int32_t tail_block(int32_t v_mine, uint32_t grp_base,
 {
   constexpr int G = 2 * ORDER;
   int32_t e_mine = 0;
+  // the G inputs of the block: all requested up front, so no step of the serial chain waits for the LDS crossbar
+  int32_t vs[G];
+#pragma unroll
+  for (int u = 0; u < G; u++) { vs[u] = __shfl(v_mine, (int)(grp_base + u)); }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int u = 0; u < G; u++) {
-    const int32_t v = __shfl(v_mine, (int)(grp_base + u));
+    const int32_t v = vs[u];
     int32_t e, ph;
     if (FIRST && u < ORDER) {
       e = v; ph = v;
     } else {
+      // The chain coef -> sum -> p -> e -> |e| -> log -> coef is what bounds the kernel (one wave per SIMD): e and
+      // -e are formed side by side, the sign product does not wait for the logarithm, and step * sign goes
+      // through the full-rate 24-bit multiply-add (|step| <= 16).
+      const int32_t sh = sgn(h);
       const uint32_t sum = group_sum<G>((uint32_t)coef * (uint32_t)h) + (1u << 9);
       const int32_t p = (int32_t)sum >> 10;
       e = (int32_t)((uint32_t)v - (uint32_t)p);
-      const uint32_t mag = (uint32_t)max(e, (int32_t)(0u - (uint32_t)e));
+      const int32_t ne = (int32_t)((uint32_t)p - (uint32_t)v);
+      const uint32_t mag = (uint32_t)max(e, ne);
       const int32_t lg = 32 - (int32_t)__clz((int)mag);                    // ceil(log2(|e|+1)); __clz(0) = 32
-      // step in [-16,16] and sign(h) in [-1,1] fit 24 bits: full-rate v_mul_i32_i24 / v_mad_i32_i24 instead of the
-      // quarter-rate 32-bit multiplies (only coef*h needs those)
-      const int32_t step = __mul24(sgn(e), lg >> 1);                        // table src/SLAPredictor.c:123-144
-      coef = mad24(step, sgn(h), coef);
+      const int32_t sign2 = __mul24(sgn(e), sh);                            // sign(e) * sign(h)
+      coef = mad24(sign2, lg >> 1, coef);                                   // step table src/SLAPredictor.c:123-144
       ph = p;
     }
     // history: lane t takes lane t-1; the group's first FIR / IIR lane takes the new input / prediction
-    h = (int32_t)__builtin_amdgcn_update_dpp(h, h, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-    h = is_fir_head ? v : (is_iir_head ? ph : h);
+    if (G == 16) {
+      // a group is exactly one DPP row: row_shr:1 leaves lane 0 of the row with `old`, which is the new input
+      h = (int32_t)__builtin_amdgcn_update_dpp(v, h, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
+      h = is_iir_head ? ph : h;
+    } else {
+      h = (int32_t)__builtin_amdgcn_update_dpp(h, h, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+      h = is_fir_head ? v : (is_iir_head ? ph : h);
+    }
     e_mine = (t == (uint32_t)u) ? e : e_mine;
   }
   return e_mine;
