@@ -157,6 +157,19 @@ int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_stride, uin
                                 const sla_hip_lpc_cand* d_cands, double* d_tile_sums, double* d_out,
                                 double exact_limit, sla_hip_stream_t stream);
 
+/* The scalar tail of the partition search on the device: estimated code length per candidate, adjacency
+ * matrix, shortest path (reference src/SLAPredictor.c:416-468, 1521-1581, 1615-1692).  d_groups: the groups of
+ * sla_hip_launch_search_exact, num_channels consecutive entries per super-frame; d_lpc_out: their (or
+ * sla_hip_launch_lpc's) output.  Per super-frame: d_status 0 = d_num_parts block lengths in d_parts
+ * (SLA_HIP_PLAN_NODES entries per super-frame) are exactly what the reference's host arithmetic decides;
+ * 1 = a comparison came closer than the device logarithm can be trusted (or the input was flagged / not
+ * finite): the caller must redo this super-frame on the host. */
+#define SLA_HIP_PLAN_NODES 17u
+int sla_hip_launch_plan(const sla_hip_lpc_group* d_groups, uint32_t num_superframes, uint32_t num_channels,
+                        uint32_t order, uint32_t bits_per_sample, const sla_hip_lpc_cand* d_cands,
+                        const double* d_lpc_out, uint32_t* d_parts, uint32_t* d_num_parts, uint32_t* d_status,
+                        sla_hip_stream_t stream);
+
 /* Integer pre-emphasis + PARCOR lattice; one wave per chunk. */
 int sla_hip_launch_lattice(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
                            const sla_hip_lattice_chunk* d_chunks, uint32_t num_chunks,
@@ -253,6 +266,10 @@ const char* sla_hip_device_name(void);
 
 /* The 12 floats of the last analysis (sla_hip_analyze_device or SLAEncoder_EncodeWhole/Block). */
 int sla_hip_last_timing(const struct SLAEncoder* encoder, float* timing_ms);
+
+/* 4 counters of the last analysis: search groups rerun as serial chains; super-frames whose partition the host
+ * had to decide (device plan not certified); 1 if the search ran on tile sums; 1 if the device plan is enabled. */
+int sla_hip_last_counters(const struct SLAEncoder* encoder, uint32_t* counters);
 
 #ifdef __cplusplus
 }

@@ -57,8 +57,10 @@ struct SLAEncoder {
   hipEvent_t  ev[2 + 8 * 12];       /* prepass pair + MAX_CHUNKS x EV_PER_CHUNK */
   uint32_t chunks;
   uint32_t split[8], split_count, chunk_cut[9];   /* relative chunk sizes (SLA_HIP_CHUNK_SPLIT="1,3,1"), boundaries of this run */
+  int      device_plan;             /* 1: code lengths + Dijkstra on the device where certified (default), 0: host only */
   int      search_exact;            /* 1: tile-sum search where it is provably bit-exact (default), 0: chains only */
   int      exact_bits;              /* log2 of the energy limit in units^2 (51; lowered by tests to force the fallback) */
+  uint32_t host_planned;            /* last analysis: super-frames whose partition the host had to decide */
   uint32_t fallback_groups;         /* last analysis: search groups that had to take the chain kernel */
   slai_fft_plan* fft;
   uint32_t threads;
@@ -67,11 +69,11 @@ struct SLAEncoder {
   /* device workspace */
   devbuf_t d_pcm, d_res1, d_res2, d_or, d_nz, d_groups, d_cands, d_lpc_out, d_code, d_kint, d_rshift,
            d_winpool, d_chunks, d_jobs, d_fold, d_acf_jobs, d_acf, d_acf_scratch, d_twiddle, d_bgroups, d_bcands, d_blk_out, d_kk, d_pk_jobs, d_pk_blocks, d_pk_hdr, d_image,
-           d_xgroups, d_tile_sums, d_fgroups;
+           d_xgroups, d_tile_sums, d_fgroups, d_parts, d_nparts, d_pstatus;
   int twiddle_ready;
   /* pinned host staging */
   pinbuf_t h_nz, h_groups, h_cands, h_lpc_out, h_code, h_kint, h_rshift, h_chunks, h_jobs, h_fold, h_res, h_pcm, h_acf_jobs, h_acf,
-           h_bgroups, h_bcands, h_blk_out, h_pk_jobs, h_pk_blocks, h_pk_hdr, h_xgroups, h_fgroups;
+           h_bgroups, h_bcands, h_blk_out, h_pk_jobs, h_pk_blocks, h_pk_hdr, h_xgroups, h_fgroups, h_parts, h_nparts, h_pstatus;
   uint32_t* h_or;
   void* nz_ones_ptr; uint64_t nz_ones_words;     /* h_nz words [0, nz_ones_words) are known to be all ones */
   pinbuf_t h_stage[2]; devbuf_t d_stage[2]; hipEvent_t ev_stage[2];
@@ -283,7 +285,9 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
     }
     if (e->split_count > 0) { e->chunks = e->split_count; }
   }
-  e->search_exact = 1; e->exact_bits = 51;
+  e->search_exact = 1; e->exact_bits = 51; e->device_plan = 1;
+  env = getenv("SLA_HIP_PLAN");
+  if (env != NULL && strcmp(env, "host") == 0) { e->device_plan = 0; }
   env = getenv("SLA_HIP_SEARCH");
   if (env != NULL && strcmp(env, "chain") == 0) { e->search_exact = 0; }
   env = getenv("SLA_HIP_EXACT_BITS");
@@ -311,8 +315,8 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
 
 void SLAEncoder_Destroy(struct SLAEncoder* e)
 {
-  devbuf_t* d[30];
-  pinbuf_t* h[22];
+  devbuf_t* d[33];
+  pinbuf_t* h[25];
   int i;
   if (e == NULL) { return; }
   (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3);
@@ -323,12 +327,14 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   d[19] = &e->d_bgroups; d[20] = &e->d_bcands; d[21] = &e->d_blk_out;
   d[22] = &e->d_kk; d[23] = &e->d_pk_jobs; d[24] = &e->d_pk_blocks; d[25] = &e->d_pk_hdr; d[26] = &e->d_image;
   d[27] = &e->d_xgroups; d[28] = &e->d_tile_sums; d[29] = &e->d_fgroups;
-  for (i = 0; i < 30; i++) { if (d[i]->ptr != NULL) { (void)hipFree(d[i]->ptr); } }
+  d[30] = &e->d_parts; d[31] = &e->d_nparts; d[32] = &e->d_pstatus;
+  for (i = 0; i < 33; i++) { if (d[i]->ptr != NULL) { (void)hipFree(d[i]->ptr); } }
   h[0] = &e->h_nz; h[1] = &e->h_groups; h[2] = &e->h_cands; h[3] = &e->h_lpc_out; h[4] = &e->h_code; h[5] = &e->h_kint;
   h[6] = &e->h_rshift; h[7] = &e->h_chunks; h[8] = &e->h_jobs; h[9] = &e->h_fold; h[10] = &e->h_res; h[11] = &e->h_pcm;
   h[12] = &e->h_acf_jobs; h[13] = &e->h_acf; h[14] = &e->h_bgroups; h[15] = &e->h_bcands; h[16] = &e->h_blk_out;
   h[17] = &e->h_pk_jobs; h[18] = &e->h_pk_blocks; h[19] = &e->h_pk_hdr; h[20] = &e->h_xgroups; h[21] = &e->h_fgroups;
-  for (i = 0; i < 22; i++) { if (h[i]->ptr != NULL) { (void)hipHostFree(h[i]->ptr); } }
+  h[22] = &e->h_parts; h[23] = &e->h_nparts; h[24] = &e->h_pstatus;
+  for (i = 0; i < 25; i++) { if (h[i]->ptr != NULL) { (void)hipHostFree(h[i]->ptr); } }
   if (e->h_or != NULL) { (void)hipHostFree(e->h_or); }
   for (i = 0; i < 2; i++) {
     if (e->h_stage[i].ptr != NULL) { (void)hipHostFree(e->h_stage[i].ptr); }
@@ -478,6 +484,15 @@ static void plan_one(void* vctx, uint32_t rel)
   const shape_t* sh;
   a->status[idx] = 0; a->nparts[idx] = 0;
   if (sf->shape == 0xFFFFFFFFu) { return; }
+  if (e->device_plan) {
+    const uint32_t li = sf->xg / C;
+    if (((const uint32_t*)e->h_pstatus.ptr)[li] == 0) {          /* decided on the device, certified */
+      const uint32_t np = ((const uint32_t*)e->h_nparts.ptr)[li];
+      memcpy(a->parts + (size_t)idx * SLAI_MAX_NODES, (const uint32_t*)e->h_parts.ptr + (size_t)li * SLA_HIP_PLAN_NODES, sizeof(uint32_t) * np);
+      a->nparts[idx] = np;
+      return;
+    }
+  }
   sh = &a->shapes[sf->shape];
   for (i = 0; i < sh->nodes; i++) {
     for (j = 0; j < sh->nodes; j++) {
@@ -740,8 +755,17 @@ static int pipeline_reserve(struct SLAEncoder* e, const actx_t* a)
   RCCHK(dev_reserve(&e->d_cands, sizeof(sla_hip_lpc_cand) * (a->ncands + 1)));
   RCCHK(dev_reserve(&e->d_lpc_out, sizeof(double) * ((size_t)a->nslots + 1) * O2));
   RCCHK(pin_reserve(&e->h_lpc_out, sizeof(double) * ((size_t)a->nslots + 1) * O2));
+  RCCHK(dev_reserve(&e->d_xgroups, sizeof(sla_hip_lpc_group) * ((size_t)a->nxg + 1)));
+  {
+    const size_t live = (size_t)a->nxg / C + 1;
+    RCCHK(dev_reserve(&e->d_parts, sizeof(uint32_t) * live * SLA_HIP_PLAN_NODES));
+    RCCHK(dev_reserve(&e->d_nparts, sizeof(uint32_t) * live));
+    RCCHK(dev_reserve(&e->d_pstatus, sizeof(uint32_t) * live));
+    RCCHK(pin_reserve(&e->h_parts, sizeof(uint32_t) * live * SLA_HIP_PLAN_NODES));
+    RCCHK(pin_reserve(&e->h_nparts, sizeof(uint32_t) * live));
+    RCCHK(pin_reserve(&e->h_pstatus, sizeof(uint32_t) * live));
+  }
   if (a->exact) {
-    RCCHK(dev_reserve(&e->d_xgroups, sizeof(sla_hip_lpc_group) * ((size_t)a->nxg + 1)));
     RCCHK(dev_reserve(&e->d_tile_sums, sizeof(double) * ((size_t)a->nxg + 1) * SLA_HIP_XTILES * 2 * sla_hip_search_exact_lags(order)));
     RCCHK(pin_reserve(&e->h_fgroups, sizeof(sla_hip_lpc_group) * ((size_t)a->nsgroups + 1)));
     RCCHK(dev_reserve(&e->d_fgroups, sizeof(sla_hip_lpc_group) * ((size_t)a->nsgroups + 1)));
@@ -817,16 +841,17 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
   const uint32_t ms = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
   hipEvent_t* ev = a->ev + (size_t)c * EV_PER_CHUNK;
   const uint32_t ng = k->grp_hi - k->grp_lo;
+  const uint32_t C = e->wave_format.num_channels;
   HIPCHK(hipEventRecord(ev[EV_SEARCH_S], e->stream));
   if (ng > 0) {
+    const uint32_t nx = k->xg_hi - k->xg_lo;
+    const sla_hip_lpc_group* hx = (const sla_hip_lpc_group*)e->h_xgroups.ptr + k->xg_lo;
+    sla_hip_lpc_group* dx = (sla_hip_lpc_group*)e->d_xgroups.ptr + k->xg_lo;
+    HIPCHK(hipMemcpyAsync(dx, hx, sizeof(sla_hip_lpc_group) * nx, hipMemcpyHostToDevice, e->stream));
     if (a->exact) {
       /* unit of the samples the search sees: 2^(ntz-31), halved by the mid channel's /2 */
       const int ntz = __builtin_ctz(e->h_or[0]);
       const double limit = ldexp(1.0, e->exact_bits + 2 * (ntz - 31 - (int)ms));
-      const uint32_t nx = k->xg_hi - k->xg_lo;
-      const sla_hip_lpc_group* hx = (const sla_hip_lpc_group*)e->h_xgroups.ptr + k->xg_lo;
-      sla_hip_lpc_group* dx = (sla_hip_lpc_group*)e->d_xgroups.ptr + k->xg_lo;
-      HIPCHK(hipMemcpyAsync(dx, hx, sizeof(sla_hip_lpc_group) * nx, hipMemcpyHostToDevice, e->stream));
       HIPCHK(hipEventRecord(ev[EV_SEARCH_S], e->stream));
       RCCHK(sla_hip_launch_search_exact(e->pcm_dev, e->stride, ms, order, dx, nx, a->max_window, a->max_xcands, (const sla_hip_lpc_cand*)e->d_cands.ptr,
                                         (double*)e->d_tile_sums.ptr + (size_t)k->xg_lo * SLA_HIP_XTILES * 2 * sla_hip_search_exact_lags(order),
@@ -840,8 +865,20 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
                                (const sla_hip_lpc_cand*)e->d_cands.ptr, NULL, (double*)e->d_lpc_out.ptr, NULL, NULL, NULL, e->stream));
     }
     HIPCHK(hipEventRecord(ev[EV_SEARCH_E], e->stream));
-    HIPCHK(hipMemcpyAsync((double*)e->h_lpc_out.ptr + (size_t)k->slot_lo * O2, (double*)e->d_lpc_out.ptr + (size_t)k->slot_lo * O2,
-                          sizeof(double) * (size_t)(k->slot_hi - k->slot_lo) * O2, hipMemcpyDeviceToHost, e->stream));
+    if (e->device_plan) {
+      /* plan on the device; only the block lengths come back (the candidates' doubles follow on demand) */
+      const uint32_t live_lo = k->xg_lo / C, live = nx / C;
+      RCCHK(sla_hip_launch_plan(dx, live, C, order, e->wave_format.bit_per_sample, (const sla_hip_lpc_cand*)e->d_cands.ptr,
+                                (const double*)e->d_lpc_out.ptr, (uint32_t*)e->d_parts.ptr + (size_t)live_lo * SLA_HIP_PLAN_NODES,
+                                (uint32_t*)e->d_nparts.ptr + live_lo, (uint32_t*)e->d_pstatus.ptr + live_lo, e->stream));
+      HIPCHK(hipMemcpyAsync((uint32_t*)e->h_parts.ptr + (size_t)live_lo * SLA_HIP_PLAN_NODES, (uint32_t*)e->d_parts.ptr + (size_t)live_lo * SLA_HIP_PLAN_NODES,
+                            sizeof(uint32_t) * (size_t)live * SLA_HIP_PLAN_NODES, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync((uint32_t*)e->h_nparts.ptr + live_lo, (uint32_t*)e->d_nparts.ptr + live_lo, sizeof(uint32_t) * live, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync((uint32_t*)e->h_pstatus.ptr + live_lo, (uint32_t*)e->d_pstatus.ptr + live_lo, sizeof(uint32_t) * live, hipMemcpyDeviceToHost, e->stream));
+    } else {
+      HIPCHK(hipMemcpyAsync((double*)e->h_lpc_out.ptr + (size_t)k->slot_lo * O2, (double*)e->d_lpc_out.ptr + (size_t)k->slot_lo * O2,
+                            sizeof(double) * (size_t)(k->slot_hi - k->slot_lo) * O2, hipMemcpyDeviceToHost, e->stream));
+    }
   } else {
     HIPCHK(hipEventRecord(ev[EV_SEARCH_E], e->stream));
   }
@@ -892,6 +929,24 @@ static int plan_chunk(struct SLAEncoder* e, actx_t* a, uint32_t c)
   uint32_t i;
   ctx.e = e; ctx.a = a; ctx.sf_lo = k->sf_lo;
   ctx.cands = (const sla_hip_lpc_cand*)e->h_cands.ptr; ctx.out = (const double*)e->h_lpc_out.ptr;
+  if (e->device_plan) {
+    /* super-frames the device could not certify (or whose search was flagged) need their candidates' doubles */
+    const uint32_t C = e->wave_format.num_channels, O2 = e->encode_param.parcor_order + 2;
+    const uint32_t* st = (const uint32_t*)e->h_pstatus.ptr;
+    uint32_t open_frames = 0;
+    for (i = k->sf_lo; i < k->sf_hi; i++) {
+      if (a->sf[i].shape != 0xFFFFFFFFu && st[a->sf[i].xg / C] != 0) { open_frames++; }
+    }
+    e->host_planned += open_frames;
+    if (open_frames != 0) {
+      HIPCHK(hipMemcpyAsync((double*)e->h_lpc_out.ptr + (size_t)k->slot_lo * O2, (double*)e->d_lpc_out.ptr + (size_t)k->slot_lo * O2,
+                            sizeof(double) * (size_t)(k->slot_hi - k->slot_lo) * O2, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      if (a->exact) { RCCHK(search_fallback(e, a, c)); }
+    }
+  } else if (a->exact) {
+    RCCHK(search_fallback(e, a, c));
+  }
   parallel_for(e->pool, k->sf_hi - k->sf_lo, plan_one, &ctx);
   k->blk_lo = e->num_blocks;
   for (i = k->sf_lo; i < k->sf_hi; i++) {
@@ -1122,7 +1177,7 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   memset(&a, 0, sizeof(a));
   a.ev = e->ev + 2;
 
-  e->fallback_groups = 0;
+  e->fallback_groups = 0; e->host_planned = 0;
   if (!preset_blocks) {
     e->num_blocks = 0;
     if ((rc = pipeline_prepare(e, &a)) != 0) { actx_free(&a); return rc; }
@@ -1202,7 +1257,6 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
     if (!preset_blocks) {
       if (hipEventSynchronize(ev[EV_SEARCH_DONE]) != hipSuccess) { rc = SLA_APIRESULT_NG; break; }
       TRACE("search done", c);
-      if (a.exact && (rc = search_fallback(e, &a, c)) != 0) { break; }
       t0 = now_ms();
       rc = plan_chunk(e, &a, c);
       t_host += now_ms() - t0;
@@ -1289,6 +1343,14 @@ int sla_hip_analyze_device(struct SLAEncoder* e, const int32_t* d_pcm, uint64_t 
   e->timing[7] = (float)(now_ms() - t_start);
   if (timing_ms != NULL) { memcpy(timing_ms, e->timing, sizeof(e->timing)); }
   e->analysed = 1;
+  return 0;
+}
+
+int sla_hip_last_counters(const struct SLAEncoder* e, uint32_t* counters)
+{
+  if (e == NULL || counters == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  counters[0] = e->fallback_groups; counters[1] = e->host_planned;
+  counters[2] = (uint32_t)e->timing[11]; counters[3] = (uint32_t)e->device_plan;
   return 0;
 }
 

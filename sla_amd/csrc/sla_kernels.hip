@@ -848,6 +848,122 @@ void k_search_finish(uint32_t order, uint32_t lags, uint32_t batch,
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_plan: the partition search's scalar tail on the device -- code-length estimate per candidate
+// (src/SLAPredictor.c:416-468), adjacency matrix, Dijkstra (:1521-1581) -- so that the host does not have to
+// fetch (order+2) doubles per candidate and evaluate 18 logarithms for each.  The reference's decisions hang
+// on glibc's log(); the device's log() may differ from it in the last bits, so a result is only accepted
+// when it provably does not depend on them: every comparison Dijkstra makes (minimum selection, relaxation)
+// and every branch of the estimate must be decided by more than PLAN_MARGIN, which is > 1000x the largest
+// possible discrepancy of a path cost (a few 1e-8 for 8 channels x 16384 samples x 16 edges).  Anything
+// closer, non-finite or out of range is flagged and the host redoes that super-frame exactly as before.
+// One wave per super-frame: lanes = candidates for the costs, lanes = nodes for the relaxation.
+// ---------------------------------------------------------------------------------------------
+#define PLAN_NODES 17            // 16384 / 1024 + 1
+#define PLAN_MARGIN 1e-4
+#define PLAN_BIG 16777216.0      // SLAOPTIMALENCODEESTIMATOR_DIJKSTRA_BIGWEIGHT
+
+__device__ __forceinline__ double plan_code_length(double sumsq, uint32_t n, uint32_t bps, const double* __restrict__ parcor,
+                                                   uint32_t order, bool& sure)
+{
+  const double l2e = 1.4426950408889634;                        // src/SLAUtility.c:442-447
+  double power = sumsq * ldexp(1.0, (int)(2 * (bps - 1)));
+  if (fabs(power) <= (double)FLT_MIN) { return 0.0; }
+  power = log(power) * l2e - log((double)n) * l2e;
+  double gain = 0.0;
+  for (uint32_t ord = 1; ord <= order; ord++) { gain += log(1.0 - parcor[ord] * parcor[ord]) * l2e; }
+  double len = 1.9426950408889634 + 0.5 * (power + gain);
+  len /= 8;
+  if (!(fabs(len) > 1e-9)) { sure = false; }                    // too close to the clamp (or NaN)
+  return (len <= 0) ? 0.125 : len;
+}
+
+__global__ __launch_bounds__(256)
+void k_plan(const sla_hip_lpc_group* __restrict__ groups, uint32_t num_sf, uint32_t nch, uint32_t order, uint32_t bps,
+            const sla_hip_lpc_cand* __restrict__ cands, const double* __restrict__ lpc_out,
+            uint32_t* __restrict__ parts, uint32_t* __restrict__ nparts, uint32_t* __restrict__ status, double margin)
+{
+  __shared__ double s_adj[4][PLAN_NODES * PLAN_NODES];
+  __shared__ uint32_t s_path[4][PLAN_NODES];
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t sf = blockIdx.x * 4 + wv;
+  if (sf >= num_sf) { return; }
+  const sla_hip_lpc_group g = groups[(uint64_t)sf * nch];       // channel 0 of the super-frame: all its candidates
+  const uint32_t window = g.num_samples, O2 = order + 2;
+  const uint32_t nodes = (window + SLA_HIP_XTILE - 1) / SLA_HIP_XTILE + 1;
+  double* adj = s_adj[wv];
+  bool sure = (nodes <= PLAN_NODES);
+  if (!sure) { if (lane == 0) { status[sf] = 1; nparts[sf] = 0; } return; }
+  for (uint32_t q = lane; q < nodes * nodes; q += 64) { adj[q] = PLAN_BIG; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (uint32_t k = lane; k < g.cand_count; k += 64) {
+    const sla_hip_lpc_cand cd = cands[g.cand_first + k];
+    const uint32_t i = cd.start / SLA_HIP_XTILE, j = (cd.start + cd.len + SLA_HIP_XTILE - 1) / SLA_HIP_XTILE;
+    double est = 0.0;
+    for (uint32_t ch = 0; ch < nch; ch++) {
+      const double* o = lpc_out + ((uint64_t)g.slot_first + (uint64_t)ch * g.cand_count + k) * O2;
+      est += cd.len * plan_code_length(o[0], cd.len, bps, o + 1, order, sure);
+    }
+    est += 50.0;                                   // SLAOPTIMALENCODEESTIMATOR_ESTIMATE_BLOCK_SIZE
+    est += 300.0;                                  // ..._LONGPATH_PENALTY
+    if (!(fabs(est) < PLAN_BIG / 2)) { sure = false; }          // NaN (also the "rerun as serial chains" flag), inf, absurd
+    if (i < nodes && j < nodes && j > i) { adj[i * nodes + j] = est; } else { sure = false; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // Dijkstra, lane = node: first-minimum selection, strict-improvement relaxation (as slai_shortest_path)
+  double cost = (lane == 0) ? 0.0 : PLAN_BIG;
+  bool done = false, reached = false;
+  uint32_t pred = 0xFFFFFFFFu;
+  const double inf = __longlong_as_double(0x7FF0000000000000ll);
+  for (uint32_t round = 0; round <= nodes; round++) {
+    const double v = (lane < nodes && !done && cost < PLAN_BIG) ? cost : inf;
+    double best = v;
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(best, off); best = (o < best) ? o : best; }
+    if (!(best < PLAN_BIG)) { break; }                         // the reference would not terminate: the host reports it
+    const unsigned long long at = __ballot(v == best);
+    const uint32_t cur = (uint32_t)__builtin_ctzll(at);
+    double second = (lane == cur) ? inf : v;
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(second, off); second = (o < second) ? o : second; }
+    if (second - best < margin) { sure = false; }
+    if (cur == nodes - 1) { reached = true; break; }
+    if (lane < nodes) {
+      const double a = adj[cur * nodes + lane];
+      if (a < PLAN_BIG) {                                      // BIG + x never improves a cost (all costs <= BIG)
+        const double via = a + best;
+        if (fabs(cost - via) < margin) { sure = false; }
+        if (cost > via) { cost = via; pred = cur; }
+      }
+    }
+    if (lane == cur) { done = true; }
+  }
+  if (lane < nodes) { s_path[wv][lane] = pred; }
+  const bool all_sure = (__ballot(!sure) == 0ull);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane == 0) {
+    uint32_t count = 0, node = nodes - 1;
+    bool ok = reached && all_sure;
+    while (ok && node != 0) {
+      const uint32_t pr = s_path[wv][node];
+      if (pr >= node) { ok = false; break; }
+      count++; node = pr;
+    }
+    if (ok) {
+      node = nodes - 1;
+      for (uint32_t q = 0; q < count; q++) {
+        const uint32_t pr = s_path[wv][node];
+        const uint32_t off = pr * SLA_HIP_XTILE;
+        uint32_t len = (node - pr) * SLA_HIP_XTILE;
+        if (len > window - off) { len = window - off; }
+        parts[(uint64_t)sf * PLAN_NODES + (count - q - 1)] = len;
+        node = pr;
+      }
+    }
+    nparts[sf] = ok ? count : 0;
+    status[sf] = ok ? 0u : 1u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_lattice: one wave per chunk; every lane keeps T consecutive samples of the forward and
 // backward prediction errors in registers, stage m needs b_{m-1}[n-1] of the previous lane
 // (one DPP-able shuffle per stage).  The first H lanes re-compute `order` samples of history
@@ -1448,6 +1564,21 @@ extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_
   if (e != hipSuccess) { return hip_rc(e); }
   hipLaunchKernelGGL(k_search_finish, dim3(num_groups), dim3(64), lds, st, order, lags, batch,
                      d_groups, d_cands, d_tile_sums, d_out, exact_limit);
+  return hip_rc(hipGetLastError());
+}
+
+extern "C" int sla_hip_launch_plan(const sla_hip_lpc_group* d_groups, uint32_t num_superframes, uint32_t num_channels,
+                                   uint32_t order, uint32_t bits_per_sample, const sla_hip_lpc_cand* d_cands,
+                                   const double* d_lpc_out, uint32_t* d_parts, uint32_t* d_num_parts, uint32_t* d_status,
+                                   sla_hip_stream_t stream)
+{
+  if (d_groups == nullptr || d_cands == nullptr || d_lpc_out == nullptr || d_parts == nullptr || d_num_parts == nullptr
+      || d_status == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (num_channels == 0 || num_channels > 8 || order < 1 || bits_per_sample == 0 || bits_per_sample > 32) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (num_superframes == 0) { return 0; }
+  hipLaunchKernelGGL(k_plan, dim3((num_superframes + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_groups, num_superframes, num_channels,
+                     order, bits_per_sample, d_cands, d_lpc_out, d_parts, d_num_parts, d_status,
+                     (getenv("SLA_HIP_PLAN_MARGIN") != nullptr) ? atof(getenv("SLA_HIP_PLAN_MARGIN")) : PLAN_MARGIN);   /* tests raise it to force the host path */
   return hip_rc(hipGetLastError());
 }
 

@@ -432,7 +432,7 @@ def _encode_with_env(hip, monkeypatch, p, pcm, **env):
         enc.set_encode_parameter(p.parcor_order, p.longterm_order, p.lms_order, p.ch_process_method,
                                  p.window_type, p.max_block_samples)
         data = enc.encode_whole(pcm)
-        return data, enc.last_timing()
+        return data, enc.last_timing() + list(enc.last_counters())
     finally:
         enc.close()
 
@@ -454,6 +454,27 @@ def test_search_paths_agree(oracle, hip, monkeypatch, nch, bits, ms, maxb):
     assert tb[10] > 0 and tc[10] == 0
     if bits <= 16:
         assert ta[10] == 0          # 16-bit material can never reach the limit
+
+
+@pytest.mark.parametrize("nch,bits,ms,maxb", [(1, 16, 0, 4096), (2, 24, 1, 16384), (8, 16, 0, 8192)])
+def test_plan_paths_agree(oracle, hip, monkeypatch, nch, bits, ms, maxb):
+    """partition decided on the device (certified), on the host for every super-frame (margin raised so that
+    nothing certifies) and with the device plan switched off: the oracle's bytes each time"""
+    n = 150000
+    pcm = W.music_like(nch, n, bits, seed=91) >> (4 if bits == 24 else 0)
+    if bits == 24:
+        pcm = (pcm >> 8) << 8
+    pcm = np.ascontiguousarray(pcm)
+    p = S.make_params(nch, bits, 48000, parcor=16, ltm=1, lms=8, ms=ms, max_block=maxb)
+    ret, want, _ = oracle.encode_trace(p, pcm)
+    assert ret == 0
+    a, ta = _encode_with_env(hip, monkeypatch, p, pcm)
+    b, tb = _encode_with_env(hip, monkeypatch, p, pcm, SLA_HIP_PLAN_MARGIN="1e30")
+    c, tc = _encode_with_env(hip, monkeypatch, p, pcm, SLA_HIP_PLAN="host")
+    assert a == want and b == want and c == want
+    assert ta[15] == 1 and tb[15] == 1 and tc[15] == 0
+    assert tb[13] > 0 and tb[13] >= ta[13] and tc[13] == 0
+    assert ta[13] <= 2          # music: practically every super-frame certifies
 
 
 def test_search_loud_24bit_takes_the_fallback_where_needed(oracle, hip, monkeypatch):
