@@ -54,7 +54,9 @@ struct SLAEncoder {
   uint32_t status_flag;
   int      device;
   hipStream_t stream, stream2, stream3;
-  hipEvent_t  ev[2 + 8 * 12];       /* prepass pair + MAX_CHUNKS x EV_PER_CHUNK */
+  int own_copy_streams;
+  hipStream_t stream_up, stream_down;            /* descriptor uploads / result downloads: kept off the kernel streams */
+  hipEvent_t  ev[2 + 8 * 15];       /* prepass pair + MAX_CHUNKS x EV_PER_CHUNK */
   uint32_t chunks;
   uint32_t split[8], split_count, chunk_cut[9];   /* relative chunk sizes (SLA_HIP_CHUNK_SPLIT="1,3,1"), boundaries of this run */
   int      device_plan;             /* 1: code lengths + Dijkstra on the device where certified (default), 0: host only */
@@ -75,7 +77,7 @@ struct SLAEncoder {
   pinbuf_t h_nz, h_groups, h_cands, h_lpc_out, h_code, h_kint, h_rshift, h_chunks, h_jobs, h_fold, h_res, h_pcm, h_acf_jobs, h_acf,
            h_bgroups, h_bcands, h_blk_out, h_pk_jobs, h_pk_blocks, h_pk_hdr, h_xgroups, h_fgroups, h_parts, h_nparts, h_pstatus;
   uint32_t* h_or;
-  void* nz_ones_ptr; uint64_t nz_ones_words;     /* h_nz words [0, nz_ones_words) are known to be all ones */
+  size_t nz_ones_cap; uint64_t nz_ones_words;    /* h_nz words [0, nz_ones_words) are known to be all ones (h_nz.cap == nz_ones_cap) */
   pinbuf_t h_stage[2]; devbuf_t d_stage[2]; hipEvent_t ev_stage[2];
 
   /* window pool: tables for every block length seen so far */
@@ -268,7 +270,14 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   }
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess
       || hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess
-      || hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess) { free(e); return NULL; }
+      || hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess
+      || hipStreamCreateWithFlags(&e->stream_up, hipStreamNonBlocking) != hipSuccess
+      || hipStreamCreateWithFlags(&e->stream_down, hipStreamNonBlocking) != hipSuccess) { free(e); return NULL; }
+  e->own_copy_streams = 1;
+  if (getenv("SLA_HIP_COPY_STREAMS") != NULL && atoi(getenv("SLA_HIP_COPY_STREAMS")) == 0) {   /* debugging: copies back on the kernel stream */
+    (void)hipStreamDestroy(e->stream_up); (void)hipStreamDestroy(e->stream_down);
+    e->stream_up = e->stream2; e->stream_down = e->stream2; e->own_copy_streams = 0;
+  }
   for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { if (hipEventCreate(&e->ev[i]) != hipSuccess) { free(e); return NULL; } }
   if (hipEventCreate(&e->ev_stage[0]) != hipSuccess || hipEventCreate(&e->ev_stage[1]) != hipSuccess) { free(e); return NULL; }
   e->chunks = 3;
@@ -320,6 +329,7 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   int i;
   if (e == NULL) { return; }
   (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3);
+  (void)hipStreamSynchronize(e->stream_up); (void)hipStreamSynchronize(e->stream_down);
   d[0] = &e->d_pcm; d[1] = &e->d_res1; d[2] = &e->d_res2; d[3] = &e->d_or; d[4] = &e->d_nz; d[5] = &e->d_groups;
   d[6] = &e->d_cands; d[7] = &e->d_lpc_out; d[8] = &e->d_code; d[9] = &e->d_kint; d[10] = &e->d_rshift;
   d[11] = &e->d_winpool; d[12] = &e->d_chunks; d[13] = &e->d_jobs; d[14] = &e->d_fold;
@@ -343,6 +353,7 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   }
   for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { (void)hipEventDestroy(e->ev[i]); }
   (void)hipStreamDestroy(e->stream); (void)hipStreamDestroy(e->stream2); (void)hipStreamDestroy(e->stream3);
+  if (e->own_copy_streams) { (void)hipStreamDestroy(e->stream_up); (void)hipStreamDestroy(e->stream_down); }
   slai_fft_plan_destroy(e->fft);
   pool_destroy(e->pool);
   free(e->win_host); free(e->win_len); free(e->win_off);
@@ -433,7 +444,7 @@ static int blocks_push(struct SLAEncoder* e, uint32_t start, uint32_t nsmpl, uin
 
 #define MAX_CHUNKS 8
 enum { EV_SEARCH_S, EV_SEARCH_E, EV_SEARCH_DONE, EV_LPCB_S, EV_LPCB_E, EV_LAT_E, EV_ACF_S, EV_ACF_E, EV_BLOCK_DONE,
-       EV_TAIL_S, EV_TAIL_E, EV_TAIL_DONE, EV_PER_CHUNK };
+       EV_TAIL_S, EV_TAIL_E, EV_TAIL_DONE, EV_UPLOADED, EV_PLANNED, EV_PLAN_DOWN, EV_PER_CHUNK };
 
 typedef struct { uint32_t start, window, min_blk, shape, slot_base, grp_lo, grp_hi, xg; } sframe_t;
 typedef struct { uint32_t window, min_blk, nodes, ncand, cand_first; uint32_t pair[SLAI_MAX_NODES * SLAI_MAX_NODES]; } shape_t;
@@ -595,7 +606,7 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
       HIPCHK(hipStreamSynchronize(e->stream));
       e->nz_ones_words = 0;
     } else {
-      if (e->nz_ones_ptr != e->h_nz.ptr) { e->nz_ones_ptr = e->h_nz.ptr; e->nz_ones_words = 0; }
+      if (e->nz_ones_cap != e->h_nz.cap) { e->nz_ones_cap = e->h_nz.cap; e->nz_ones_words = 0; }   /* reallocated since (a new block may reuse the address) */
       if (e->nz_ones_words < head_words) {
         memset((uint64_t*)e->h_nz.ptr + e->nz_ones_words, 0xFF, (size_t)(head_words - e->nz_ones_words) * 8);
       }
@@ -845,9 +856,7 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
   HIPCHK(hipEventRecord(ev[EV_SEARCH_S], e->stream));
   if (ng > 0) {
     const uint32_t nx = k->xg_hi - k->xg_lo;
-    const sla_hip_lpc_group* hx = (const sla_hip_lpc_group*)e->h_xgroups.ptr + k->xg_lo;
     sla_hip_lpc_group* dx = (sla_hip_lpc_group*)e->d_xgroups.ptr + k->xg_lo;
-    HIPCHK(hipMemcpyAsync(dx, hx, sizeof(sla_hip_lpc_group) * nx, hipMemcpyHostToDevice, e->stream));
     if (a->exact) {
       /* unit of the samples the search sees: 2^(ntz-31), halved by the mid channel's /2 */
       const int ntz = __builtin_ctz(e->h_or[0]);
@@ -871,10 +880,14 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
       RCCHK(sla_hip_launch_plan(dx, live, C, order, e->wave_format.bit_per_sample, (const sla_hip_lpc_cand*)e->d_cands.ptr,
                                 (const double*)e->d_lpc_out.ptr, (uint32_t*)e->d_parts.ptr + (size_t)live_lo * SLA_HIP_PLAN_NODES,
                                 (uint32_t*)e->d_nparts.ptr + live_lo, (uint32_t*)e->d_pstatus.ptr + live_lo, e->stream));
+      HIPCHK(hipEventRecord(ev[EV_PLANNED], e->stream));
+      HIPCHK(hipStreamWaitEvent(e->stream_down, ev[EV_PLANNED], 0));
       HIPCHK(hipMemcpyAsync((uint32_t*)e->h_parts.ptr + (size_t)live_lo * SLA_HIP_PLAN_NODES, (uint32_t*)e->d_parts.ptr + (size_t)live_lo * SLA_HIP_PLAN_NODES,
-                            sizeof(uint32_t) * (size_t)live * SLA_HIP_PLAN_NODES, hipMemcpyDeviceToHost, e->stream));
-      HIPCHK(hipMemcpyAsync((uint32_t*)e->h_nparts.ptr + live_lo, (uint32_t*)e->d_nparts.ptr + live_lo, sizeof(uint32_t) * live, hipMemcpyDeviceToHost, e->stream));
-      HIPCHK(hipMemcpyAsync((uint32_t*)e->h_pstatus.ptr + live_lo, (uint32_t*)e->d_pstatus.ptr + live_lo, sizeof(uint32_t) * live, hipMemcpyDeviceToHost, e->stream));
+                            sizeof(uint32_t) * (size_t)live * SLA_HIP_PLAN_NODES, hipMemcpyDeviceToHost, e->stream_down));
+      HIPCHK(hipMemcpyAsync((uint32_t*)e->h_nparts.ptr + live_lo, (uint32_t*)e->d_nparts.ptr + live_lo, sizeof(uint32_t) * live, hipMemcpyDeviceToHost, e->stream_down));
+      HIPCHK(hipMemcpyAsync((uint32_t*)e->h_pstatus.ptr + live_lo, (uint32_t*)e->d_pstatus.ptr + live_lo, sizeof(uint32_t) * live, hipMemcpyDeviceToHost, e->stream_down));
+      HIPCHK(hipEventRecord(ev[EV_SEARCH_DONE], e->stream_down));      /* what the host waits for */
+      return 0;
     } else {
       HIPCHK(hipMemcpyAsync((double*)e->h_lpc_out.ptr + (size_t)k->slot_lo * O2, (double*)e->d_lpc_out.ptr + (size_t)k->slot_lo * O2,
                             sizeof(double) * (size_t)(k->slot_hi - k->slot_lo) * O2, hipMemcpyDeviceToHost, e->stream));
@@ -1023,14 +1036,17 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     sla_hip_lattice_chunk* dl = (sla_hip_lattice_chunk*)e->d_chunks.ptr + k->lc_lo;
     sla_hip_acf_job* da = (sla_hip_acf_job*)e->d_acf_jobs.ptr + k->bg_lo;
     uint32_t slots = 0;
-    HIPCHK(hipMemcpyAsync(dg, groups + k->bg_lo, sizeof(sla_hip_lpc_group) * ng, hipMemcpyHostToDevice, e->stream2));
-    HIPCHK(hipMemcpyAsync((sla_hip_lpc_cand*)e->d_bcands.ptr + k->bg_lo, cands + k->bg_lo, sizeof(sla_hip_lpc_cand) * ng, hipMemcpyHostToDevice, e->stream2));
-    HIPCHK(hipMemcpyAsync(dl, lch + k->lc_lo, sizeof(sla_hip_lattice_chunk) * nl, hipMemcpyHostToDevice, e->stream2));
-    HIPCHK(hipMemcpyAsync(da, acf_jobs + k->bg_lo, sizeof(sla_hip_acf_job) * ng, hipMemcpyHostToDevice, e->stream2));
-    HIPCHK(hipMemsetAsync((int32_t*)e->d_code.ptr + slot_lo * O1, 0, sizeof(int32_t) * nsl * O1, e->stream2));
-    HIPCHK(hipMemsetAsync((int32_t*)e->d_kint.ptr + slot_lo * O1, 0, sizeof(int32_t) * nsl * O1, e->stream2));
-    HIPCHK(hipMemsetAsync((uint32_t*)e->d_rshift.ptr + slot_lo, 0, sizeof(uint32_t) * nsl, e->stream2));
-    HIPCHK(hipMemsetAsync((double*)e->d_blk_out.ptr + slot_lo * O2, 0, sizeof(double) * nsl * O2, e->stream2));
+    HIPCHK(hipMemcpyAsync(dg, groups + k->bg_lo, sizeof(sla_hip_lpc_group) * ng, hipMemcpyHostToDevice, e->stream_up));
+    HIPCHK(hipMemcpyAsync((sla_hip_lpc_cand*)e->d_bcands.ptr + k->bg_lo, cands + k->bg_lo, sizeof(sla_hip_lpc_cand) * ng, hipMemcpyHostToDevice, e->stream_up));
+    HIPCHK(hipMemcpyAsync(dl, lch + k->lc_lo, sizeof(sla_hip_lattice_chunk) * nl, hipMemcpyHostToDevice, e->stream_up));
+    HIPCHK(hipMemcpyAsync(da, acf_jobs + k->bg_lo, sizeof(sla_hip_acf_job) * ng, hipMemcpyHostToDevice, e->stream_up));
+    HIPCHK(hipMemsetAsync((int32_t*)e->d_code.ptr + slot_lo * O1, 0, sizeof(int32_t) * nsl * O1, e->stream_up));
+    HIPCHK(hipMemsetAsync((int32_t*)e->d_kint.ptr + slot_lo * O1, 0, sizeof(int32_t) * nsl * O1, e->stream_up));
+    HIPCHK(hipMemsetAsync((uint32_t*)e->d_rshift.ptr + slot_lo, 0, sizeof(uint32_t) * nsl, e->stream_up));
+    HIPCHK(hipMemsetAsync((double*)e->d_blk_out.ptr + slot_lo * O2, 0, sizeof(double) * nsl * O2, e->stream_up));
+    /* uploads and result downloads travel on their own streams: the kernel stream runs kernel after kernel */
+    HIPCHK(hipEventRecord(ev[EV_UPLOADED], e->stream_up));
+    HIPCHK(hipStreamWaitEvent(e->stream2, ev[EV_UPLOADED], 0));
     HIPCHK(hipEventRecord(ev[EV_LPCB_S], e->stream2));
     RCCHK(sla_hip_launch_lpc(e->pcm_dev, e->stride, ms, order, dg, ng, max_window, 1,
                              (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
@@ -1045,19 +1061,21 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
                                  (double*)e->d_acf_scratch.ptr, slots,
                                  (double*)e->d_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD, SLAI_LTM_ACF_HEAD, e->stream2));
     HIPCHK(hipEventRecord(ev[EV_ACF_E], e->stream2));
-    HIPCHK(hipMemcpyAsync((double*)e->h_blk_out.ptr + slot_lo * O2, (double*)e->d_blk_out.ptr + slot_lo * O2, sizeof(double) * nsl * O2, hipMemcpyDeviceToHost, e->stream2));
-    HIPCHK(hipMemcpyAsync((int32_t*)e->h_code.ptr + slot_lo * O1, (int32_t*)e->d_code.ptr + slot_lo * O1, sizeof(int32_t) * nsl * O1, hipMemcpyDeviceToHost, e->stream2));
-    HIPCHK(hipMemcpyAsync((int32_t*)e->h_kint.ptr + slot_lo * O1, (int32_t*)e->d_kint.ptr + slot_lo * O1, sizeof(int32_t) * nsl * O1, hipMemcpyDeviceToHost, e->stream2));
-    HIPCHK(hipMemcpyAsync((uint32_t*)e->h_rshift.ptr + slot_lo, (uint32_t*)e->d_rshift.ptr + slot_lo, sizeof(uint32_t) * nsl, hipMemcpyDeviceToHost, e->stream2));
+    HIPCHK(hipStreamWaitEvent(e->stream_down, ev[EV_ACF_E], 0));
+    HIPCHK(hipMemcpyAsync((double*)e->h_blk_out.ptr + slot_lo * O2, (double*)e->d_blk_out.ptr + slot_lo * O2, sizeof(double) * nsl * O2, hipMemcpyDeviceToHost, e->stream_down));
+    HIPCHK(hipMemcpyAsync((int32_t*)e->h_code.ptr + slot_lo * O1, (int32_t*)e->d_code.ptr + slot_lo * O1, sizeof(int32_t) * nsl * O1, hipMemcpyDeviceToHost, e->stream_down));
+    HIPCHK(hipMemcpyAsync((int32_t*)e->h_kint.ptr + slot_lo * O1, (int32_t*)e->d_kint.ptr + slot_lo * O1, sizeof(int32_t) * nsl * O1, hipMemcpyDeviceToHost, e->stream_down));
+    HIPCHK(hipMemcpyAsync((uint32_t*)e->h_rshift.ptr + slot_lo, (uint32_t*)e->d_rshift.ptr + slot_lo, sizeof(uint32_t) * nsl, hipMemcpyDeviceToHost, e->stream_down));
     HIPCHK(hipMemcpyAsync((double*)e->h_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD, (double*)e->d_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD,
-                          sizeof(double) * (size_t)ng * SLAI_LTM_ACF_HEAD, hipMemcpyDeviceToHost, e->stream2));
+                          sizeof(double) * (size_t)ng * SLAI_LTM_ACF_HEAD, hipMemcpyDeviceToHost, e->stream_down));
   } else {
     HIPCHK(hipEventRecord(ev[EV_LPCB_E], e->stream2));
     HIPCHK(hipEventRecord(ev[EV_LAT_E], e->stream2));
     HIPCHK(hipEventRecord(ev[EV_ACF_S], e->stream2));
     HIPCHK(hipEventRecord(ev[EV_ACF_E], e->stream2));
   }
-  HIPCHK(hipEventRecord(ev[EV_BLOCK_DONE], e->stream2));
+  HIPCHK(hipStreamWaitEvent(e->stream_down, ev[EV_ACF_E], 0));
+  HIPCHK(hipEventRecord(ev[EV_BLOCK_DONE], e->stream_down));
   return 0;
 }
 
@@ -1246,6 +1264,9 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
     if (a.ncands > 0) {
       HIPCHK(hipMemcpyAsync(e->d_cands.ptr, e->h_cands.ptr, sizeof(sla_hip_lpc_cand) * a.ncands, hipMemcpyHostToDevice, e->stream));
     }
+    if (a.nxg > 0) {
+      HIPCHK(hipMemcpyAsync(e->d_xgroups.ptr, e->h_xgroups.ptr, sizeof(sla_hip_lpc_group) * a.nxg, hipMemcpyHostToDevice, e->stream));
+    }
     for (c = 0; c < a.nchunks && rc == 0; c++) { rc = search_launch(e, &a, c); }
     TRACE("search launched", a.nchunks);
   } else {
@@ -1287,7 +1308,8 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
     }
   }
   if (hipStreamSynchronize(e->stream) != hipSuccess || hipStreamSynchronize(e->stream2) != hipSuccess
-      || hipStreamSynchronize(e->stream3) != hipSuccess) { if (rc == 0) { rc = SLA_APIRESULT_NG; } }
+      || hipStreamSynchronize(e->stream3) != hipSuccess || hipStreamSynchronize(e->stream_up) != hipSuccess
+      || hipStreamSynchronize(e->stream_down) != hipSuccess) { if (rc == 0) { rc = SLA_APIRESULT_NG; } }
   TRACE("all streams idle", 0);
   if (rc == 0) {
     finish_rice(e, &a);
