@@ -1030,7 +1030,7 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
   k->bg_hi = a->nbg; k->lc_hi = a->nlc;
   ng = k->bg_hi - k->bg_lo; nl = k->lc_hi - k->lc_lo;
 
-  HIPCHK(hipEventRecord(ev[EV_LPCB_S], e->stream2));
+  if (ng == 0) { HIPCHK(hipEventRecord(ev[EV_LPCB_S], e->stream2)); }
   if (ng > 0) {
     sla_hip_lpc_group* dg = (sla_hip_lpc_group*)e->d_bgroups.ptr + k->bg_lo;
     sla_hip_lattice_chunk* dl = (sla_hip_lattice_chunk*)e->d_chunks.ptr + k->lc_lo;
@@ -1040,10 +1040,7 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     HIPCHK(hipMemcpyAsync((sla_hip_lpc_cand*)e->d_bcands.ptr + k->bg_lo, cands + k->bg_lo, sizeof(sla_hip_lpc_cand) * ng, hipMemcpyHostToDevice, e->stream_up));
     HIPCHK(hipMemcpyAsync(dl, lch + k->lc_lo, sizeof(sla_hip_lattice_chunk) * nl, hipMemcpyHostToDevice, e->stream_up));
     HIPCHK(hipMemcpyAsync(da, acf_jobs + k->bg_lo, sizeof(sla_hip_acf_job) * ng, hipMemcpyHostToDevice, e->stream_up));
-    HIPCHK(hipMemsetAsync((int32_t*)e->d_code.ptr + slot_lo * O1, 0, sizeof(int32_t) * nsl * O1, e->stream_up));
-    HIPCHK(hipMemsetAsync((int32_t*)e->d_kint.ptr + slot_lo * O1, 0, sizeof(int32_t) * nsl * O1, e->stream_up));
-    HIPCHK(hipMemsetAsync((uint32_t*)e->d_rshift.ptr + slot_lo, 0, sizeof(uint32_t) * nsl, e->stream_up));
-    HIPCHK(hipMemsetAsync((double*)e->d_blk_out.ptr + slot_lo * O2, 0, sizeof(double) * nsl * O2, e->stream_up));
+    /* (k_lpc_blocks writes every output slot of its groups; slots of silent blocks are never read) */
     /* uploads and result downloads travel on their own streams: the kernel stream runs kernel after kernel */
     HIPCHK(hipEventRecord(ev[EV_UPLOADED], e->stream_up));
     HIPCHK(hipStreamWaitEvent(e->stream2, ev[EV_UPLOADED], 0));
