@@ -137,6 +137,14 @@ int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid
                        double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
                        sla_hip_stream_t stream);
 
+/* sla_hip_launch_lpc restricted to the groups that sla_hip_launch_search_exact flagged (NaN in r[0] of the group's
+ * first slot): everything else returns at once and keeps its result.  *d_rerun_counter (may be NULL) is
+ * incremented by the number of groups that were analysed. */
+int sla_hip_launch_lpc_rerun(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                             const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                             uint32_t max_cands_per_group, const sla_hip_lpc_cand* d_cands,
+                             double* d_out, uint32_t* d_rerun_counter, sla_hip_stream_t stream);
+
 /* Partition search without serial chains (reference src/SLAPredictor.c:1615-1649 + :331-388).
  * The search analyses the un-windowed samples: integers times a power of two.  As long as the energy of
  * a group's window stays below `exact_limit` (= 2^51 units^2, unit = the common power-of-two factor of
@@ -147,7 +155,7 @@ int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid
  * candidates; candidates must start on a tile boundary and end on one or at the end of the window.
  * d_tile_sums: num_groups * SLA_HIP_XTILES * 2 * sla_hip_search_exact_lags(order) doubles of scratch.
  * A group whose energy reaches the limit gets NaN in r[0] of every candidate: the caller reruns those
- * groups through sla_hip_launch_lpc. */
+ * groups through sla_hip_launch_lpc_rerun. */
 #define SLA_HIP_XTILE  1024u
 #define SLA_HIP_XTILES 16u
 uint32_t sla_hip_search_exact_lags(uint32_t order);      /* padded lag count, 0: order not supported */

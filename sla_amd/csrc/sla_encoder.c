@@ -314,7 +314,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
     if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0 && (uint32_t)CPU_COUNT(&set) < e->threads) { e->threads = (uint32_t)CPU_COUNT(&set); }
   }
   if (e->threads < 1) { e->threads = 1; }
-  if (e->threads > 16) { e->threads = 16; }       /* the loops are short: more workers only add wake-up and join time */
+  if (e->threads > 10) { e->threads = 10; }       /* the loops are short: more workers only add wake-up and join time */
   env = getenv("SLA_HIP_THREADS");
   if (env != NULL && atoi(env) > 0) { e->threads = (uint32_t)atoi(env); }
   e->pool = pool_create(e->threads);
@@ -778,8 +778,6 @@ static int pipeline_reserve(struct SLAEncoder* e, const actx_t* a)
   }
   if (a->exact) {
     RCCHK(dev_reserve(&e->d_tile_sums, sizeof(double) * ((size_t)a->nxg + 1) * SLA_HIP_XTILES * 2 * sla_hip_search_exact_lags(order)));
-    RCCHK(pin_reserve(&e->h_fgroups, sizeof(sla_hip_lpc_group) * ((size_t)a->nsgroups + 1)));
-    RCCHK(dev_reserve(&e->d_fgroups, sizeof(sla_hip_lpc_group) * ((size_t)a->nsgroups + 1)));
   }
   /* blocks */
   RCCHK(pin_reserve(&e->h_bgroups, sizeof(sla_hip_lpc_group) * nslots));
@@ -865,10 +863,13 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
       RCCHK(sla_hip_launch_search_exact(e->pcm_dev, e->stride, ms, order, dx, nx, a->max_window, a->max_xcands, (const sla_hip_lpc_cand*)e->d_cands.ptr,
                                         (double*)e->d_tile_sums.ptr + (size_t)k->xg_lo * SLA_HIP_XTILES * 2 * sla_hip_search_exact_lags(order),
                                         (double*)e->d_lpc_out.ptr, limit, e->stream));
+      /* windows over the exactness limit (loud material wider than 16 bits) were flagged: their groups take the
+       * serial chains now, on the device, without a host round trip; the others return at once */
+      RCCHK(sla_hip_launch_lpc_rerun(e->pcm_dev, e->stride, ms, order, (const sla_hip_lpc_group*)e->d_groups.ptr + k->grp_lo, ng,
+                                     a->max_window, a->max_cpg, (const sla_hip_lpc_cand*)e->d_cands.ptr, (double*)e->d_lpc_out.ptr,
+                                     (uint32_t*)e->d_or.ptr + 2, e->stream));
     } else {
-      const sla_hip_lpc_group* hg = (const sla_hip_lpc_group*)e->h_groups.ptr + k->grp_lo;
       sla_hip_lpc_group* dg = (sla_hip_lpc_group*)e->d_groups.ptr + k->grp_lo;
-      HIPCHK(hipMemcpyAsync(dg, hg, sizeof(sla_hip_lpc_group) * ng, hipMemcpyHostToDevice, e->stream));
       HIPCHK(hipEventRecord(ev[EV_SEARCH_S], e->stream));
       RCCHK(sla_hip_launch_lpc(e->pcm_dev, e->stride, ms, order, dg, ng, a->max_window, a->max_cpg,
                                (const sla_hip_lpc_cand*)e->d_cands.ptr, NULL, (double*)e->d_lpc_out.ptr, NULL, NULL, NULL, e->stream));
@@ -899,40 +900,6 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
   return 0;
 }
 
-/* exact search only: super-frames whose window energy reached the exactness limit come back with NaN in
- * r[0]; their groups take the serial-chain kernel now (rare: loud material wider than 16 bits) */
-static int search_fallback(struct SLAEncoder* e, actx_t* a, uint32_t c)
-{
-  const chunk_t* k = &a->ck[c];
-  const uint32_t C = e->wave_format.num_channels, order = e->encode_param.parcor_order, O2 = order + 2;
-  const uint32_t ms = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
-  const double* out = (const double*)e->h_lpc_out.ptr;
-  sla_hip_lpc_group* fg = (sla_hip_lpc_group*)e->h_fgroups.ptr;
-  uint32_t i, ch, n = 0;
-  for (i = k->sf_lo; i < k->sf_hi; i++) {
-    const sframe_t* f = &a->sf[i];
-    int flagged = 0;
-    if (f->shape == 0xFFFFFFFFu) { continue; }
-    for (ch = 0; ch < C; ch++) {
-      const double r0 = out[(size_t)(f->slot_base + ch * a->shapes[f->shape].ncand) * O2];
-      if (r0 != r0) { flagged = 1; }
-    }
-    if (flagged) {
-      memcpy(fg + n, (const sla_hip_lpc_group*)e->h_groups.ptr + f->grp_lo, sizeof(sla_hip_lpc_group) * (f->grp_hi - f->grp_lo));
-      n += f->grp_hi - f->grp_lo;
-    }
-  }
-  if (n == 0) { return 0; }
-  e->fallback_groups += n;
-  HIPCHK(hipMemcpyAsync(e->d_fgroups.ptr, fg, sizeof(sla_hip_lpc_group) * n, hipMemcpyHostToDevice, e->stream));
-  RCCHK(sla_hip_launch_lpc(e->pcm_dev, e->stride, ms, order, (const sla_hip_lpc_group*)e->d_fgroups.ptr, n, a->max_window, a->max_cpg,
-                           (const sla_hip_lpc_cand*)e->d_cands.ptr, NULL, (double*)e->d_lpc_out.ptr, NULL, NULL, NULL, e->stream));
-  HIPCHK(hipMemcpyAsync((double*)e->h_lpc_out.ptr + (size_t)k->slot_lo * O2, (double*)e->d_lpc_out.ptr + (size_t)k->slot_lo * O2,
-                        sizeof(double) * (size_t)(k->slot_hi - k->slot_lo) * O2, hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipStreamSynchronize(e->stream));
-  return 0;
-}
-
 /* host: plan of chunk c -> block table entries [blk_lo, blk_hi) */
 static int plan_chunk(struct SLAEncoder* e, actx_t* a, uint32_t c)
 {
@@ -955,10 +922,7 @@ static int plan_chunk(struct SLAEncoder* e, actx_t* a, uint32_t c)
       HIPCHK(hipMemcpyAsync((double*)e->h_lpc_out.ptr + (size_t)k->slot_lo * O2, (double*)e->d_lpc_out.ptr + (size_t)k->slot_lo * O2,
                             sizeof(double) * (size_t)(k->slot_hi - k->slot_lo) * O2, hipMemcpyDeviceToHost, e->stream));
       HIPCHK(hipStreamSynchronize(e->stream));
-      if (a->exact) { RCCHK(search_fallback(e, a, c)); }
     }
-  } else if (a->exact) {
-    RCCHK(search_fallback(e, a, c));
   }
   parallel_for(e->pool, k->sf_hi - k->sf_lo, plan_one, &ctx);
   k->blk_lo = e->num_blocks;
@@ -1264,6 +1228,10 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
     if (a.nxg > 0) {
       HIPCHK(hipMemcpyAsync(e->d_xgroups.ptr, e->h_xgroups.ptr, sizeof(sla_hip_lpc_group) * a.nxg, hipMemcpyHostToDevice, e->stream));
     }
+    if (a.nsgroups > 0) {
+      HIPCHK(hipMemcpyAsync(e->d_groups.ptr, e->h_groups.ptr, sizeof(sla_hip_lpc_group) * a.nsgroups, hipMemcpyHostToDevice, e->stream));
+    }
+    HIPCHK(hipMemsetAsync((uint32_t*)e->d_or.ptr + 2, 0, sizeof(uint32_t), e->stream));      /* groups rerun as serial chains */
     for (c = 0; c < a.nchunks && rc == 0; c++) { rc = search_launch(e, &a, c); }
     TRACE("search launched", a.nchunks);
   } else {
@@ -1307,6 +1275,9 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   if (hipStreamSynchronize(e->stream) != hipSuccess || hipStreamSynchronize(e->stream2) != hipSuccess
       || hipStreamSynchronize(e->stream3) != hipSuccess || hipStreamSynchronize(e->stream_up) != hipSuccess
       || hipStreamSynchronize(e->stream_down) != hipSuccess) { if (rc == 0) { rc = SLA_APIRESULT_NG; } }
+  if (rc == 0 && !preset_blocks) {
+    if (hipMemcpy(&e->fallback_groups, (uint32_t*)e->d_or.ptr + 2, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) { rc = SLA_APIRESULT_NG; }
+  }
   TRACE("all streams idle", 0);
   if (rc == 0) {
     finish_rice(e, &a);

@@ -248,7 +248,7 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
            const sla_hip_lpc_cand* __restrict__ cands,
            const double* __restrict__ window_pool, double* __restrict__ out,
            int32_t* __restrict__ out_code, int32_t* __restrict__ out_kint, uint32_t* __restrict__ out_rshift,
-           uint32_t x_region, uint32_t dbg_skip)
+           uint32_t x_region, uint32_t dbg_skip, uint32_t* __restrict__ rerun_counter)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ sla_hip_lpc_group s_g[LPC_MAX_PACK];
@@ -262,6 +262,14 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
     s_maxabs[threadIdx.x] = 0;
   }
   __syncthreads();
+  if (dbg_skip & 128u) {
+    // rerun mode (after k_search_finish): only groups whose window was over the exactness limit -- their first
+    // output slot carries the NaN flag -- are analysed, everything else keeps its tile-sum result
+    uint32_t flagged = 0;
+    for (uint32_t k = 0; k < ng; k++) { const double r0 = out[(uint64_t)s_g[k].slot_first * (order + 2)]; flagged += (r0 != r0) ? 1u : 0u; }
+    if (flagged == 0) { return; }
+    if (threadIdx.x == 0 && rerun_counter != nullptr) { atomicAdd(rerun_counter, flagged); }
+  }
   if (threadIdx.x == 0) {
     uint32_t acc = 0;
     for (uint32_t k = 0; k < ng; k++) { s_coff[k] = acc; acc += s_g[k].cand_count; }
@@ -1444,12 +1452,39 @@ extern "C" int sla_hip_launch_prepass(const int32_t* d_pcm, uint64_t plane_strid
   return hip_rc(hipGetLastError());
 }
 
+static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                           const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                           uint32_t max_cands_per_group,
+                           const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
+                           double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
+                           sla_hip_stream_t stream, uint32_t mode_flags, uint32_t* d_rerun_counter);
+
 extern "C" int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
                                   const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
                                   uint32_t max_cands_per_group,
                                   const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
                                   double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
                                   sla_hip_stream_t stream)
+{
+  return launch_lpc_impl(d_pcm, plane_stride, mid_side, order, d_groups, num_groups, max_window, max_cands_per_group, d_cands,
+                         d_window_pool, d_out, d_code, d_kint, d_rshift, stream, 0u, nullptr);
+}
+
+extern "C" int sla_hip_launch_lpc_rerun(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                                        const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                                        uint32_t max_cands_per_group, const sla_hip_lpc_cand* d_cands,
+                                        double* d_out, uint32_t* d_rerun_counter, sla_hip_stream_t stream)
+{
+  return launch_lpc_impl(d_pcm, plane_stride, mid_side, order, d_groups, num_groups, max_window, max_cands_per_group, d_cands,
+                         nullptr, d_out, nullptr, nullptr, nullptr, stream, 128u, d_rerun_counter);
+}
+
+static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                           const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                           uint32_t max_cands_per_group,
+                           const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
+                           double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
+                           sla_hip_stream_t stream, uint32_t mode_flags, uint32_t* d_rerun_counter)
 {
   if (d_pcm == nullptr || d_groups == nullptr || d_cands == nullptr || d_out == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (order < 1 || order > 255 || max_window == 0 || max_cands_per_group == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
@@ -1522,7 +1557,7 @@ extern "C" int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, u
   if (e != hipSuccess) { return hip_rc(e); }
   hipLaunchKernelGGL(k_lpc, dim3((num_groups + pack - 1) / pack), dim3(256), lds, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
                      d_groups, num_groups, pack, d_cands, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)x_region,
-                     (uint32_t)(getenv("SLA_HIP_LPC_SKIP") ? atoi(getenv("SLA_HIP_LPC_SKIP")) : 0));
+                     (uint32_t)(getenv("SLA_HIP_LPC_SKIP") ? (atoi(getenv("SLA_HIP_LPC_SKIP")) & 127) : 0) | mode_flags, d_rerun_counter);
   return hip_rc(hipGetLastError());
 }
 
