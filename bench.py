@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=None, help="override the audio duration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--sync-gather", action="store_true", help="N > 1: wait for each step's all-gather before the next step starts")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
@@ -81,29 +82,50 @@ def main():
     stride = (n + 63) // 64 * 64
     d_pcm = torch.zeros((nch, stride), dtype=torch.int32, device="cuda")
     d_pcm[:, :n] = torch.from_numpy(pcm).cuda()
-    d_lat = torch.zeros((nch, stride), dtype=torch.int32, device="cuda")
-    d_fin = torch.zeros((nch, stride), dtype=torch.int32, device="cuda")
-    gathered = torch.empty((world, nch, stride), dtype=torch.int32, device="cuda") if world > 1 else None
+    # N > 1 over RCCL: the all-gather of one step's residual planes travels while the next step is analysed into
+    # a second set of planes (two sets take turns), so the collective over xGMI and the kernels overlap
+    overlap = (world > 1 and args.backend == "nccl" and not args.sync_gather)
+    nbuf = 2 if overlap else 1
+    d_lat = [torch.zeros((nch, stride), dtype=torch.int32, device="cuda") for _ in range(nbuf)]
+    d_fin = [torch.zeros((nch, stride), dtype=torch.int32, device="cuda") for _ in range(nbuf)]
+    gathered = [torch.empty((world, nch, stride), dtype=torch.int32, device="cuda") for _ in range(nbuf)] if world > 1 else None
+    works = [None] * nbuf
 
     enc = sla_amd.Encoder(*cap)
     enc.set_wave_format(nch, bits, rate)
     enc.set_encode_parameter(order, ltm, lms, ms, win, maxb)
-    enc.bind_residual_planes(d_lat.data_ptr(), d_fin.data_ptr(), stride)
+    enc.bind_residual_planes(d_lat[0].data_ptr(), d_fin[0].data_ptr(), stride)
     torch.cuda.synchronize()
 
     from sla_amd import dist as sdist
+    step_no = [0]
+
+    def settle(b):
+        if works[b] is not None:
+            works[b].wait()
+            torch.cuda.current_stream().synchronize()
+            works[b] = None
 
     def step():
+        b = step_no[0] % nbuf
+        step_no[0] += 1
+        settle(b)                                             # the planes of two steps ago have been gathered
+        if nbuf > 1:
+            enc.bind_residual_planes(d_lat[b].data_ptr(), d_fin[b].data_ptr(), stride)
         t = enc.analyze_device(d_pcm.data_ptr(), stride, n)
         if world > 1:
-            if args.backend == "nccl":
-                sdist.all_gather_planes(d_fin, gathered)      # RCCL over xGMI: re-assemble the residual stream
+            if overlap:
+                works[b] = sdist.all_gather_planes(d_fin[b], gathered[b], async_op=True)[1]
+            elif args.backend == "nccl":
+                sdist.all_gather_planes(d_fin[b], gathered[b])   # RCCL over xGMI: re-assemble the residual stream
             else:                                             # rehearsal backend: stage through the host
-                gathered.copy_(sdist.all_gather_planes(d_fin.cpu()))
+                gathered[b].copy_(sdist.all_gather_planes(d_fin[b].cpu()))
         return t
 
     for _ in range(args.warmup):
         step()
+    for b in range(nbuf):
+        settle(b)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -111,6 +133,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         kernel_ms += np.array(step())
+    for b in range(nbuf):
+        settle(b)                                             # every collective of the timed steps has landed
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -132,7 +156,7 @@ def main():
                    "name": args.config, "channels": nch, "bits": bits, "rate": rate, "seconds": seconds,
                    "parcor_order": order, "longterm_order": ltm, "lms_order": lms,
                    "max_block_samples": maxb, "samples_per_step_per_gpu": n * nch,
-                   "parallelism": "frames sharded over %d GPU(s), RCCL all-gather of residuals" % world},
+                   "parallelism": "frames sharded over %d GPU(s), RCCL all-gather of residuals%s" % (world, " overlapped with the next step" if overlap else "")},
     }
 
     if rank == 0:

@@ -15,16 +15,18 @@ def shard_units(num_units, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def all_gather_planes(planes, out=None):
+def all_gather_planes(planes, out=None, async_op=False):
     """planes: int32 tensor [C, stride] holding this rank's residual planes.  Returns [world, C, stride]
-    with every rank's planes (one collective; RCCL ring over xGMI when the backend is nccl)."""
+    with every rank's planes (one collective; RCCL ring over xGMI when the backend is nccl).
+    async_op=True returns (out, work): the collective travels while the caller analyses its next shard
+    into OTHER planes; work.wait() before `out` is read or `planes` are written again."""
     world = dist.get_world_size()
     shape = tuple(planes.shape)
     if out is None:
         out = torch.empty((world,) + shape, dtype=planes.dtype, device=planes.device)
     # concatenated form (world*C, stride): accepted by both RCCL and gloo
-    dist.all_gather_into_tensor(out.view((world * shape[0],) + shape[1:]), planes.contiguous())
-    return out
+    work = dist.all_gather_into_tensor(out.view((world * shape[0],) + shape[1:]), planes.contiguous(), async_op=async_op)
+    return (out, work) if async_op else out
 
 
 def max_over_ranks(seconds, device):

@@ -43,6 +43,14 @@ def _worker(rank, world, port, clips, n, q):
         planes = np.zeros((per_rank, 2, n), np.int32)  # padded to equal size for the collective
         planes[:len(mine)] = np.stack(mine) if mine else planes[:0]
         gathered = sdist.all_gather_planes(torch.from_numpy(planes.reshape(per_rank * 2, n)))
+        # the overlapped form bench.py uses at N > 1: two plane sets in flight, settled before reuse
+        outs, works = [], []
+        for k in range(2):
+            o2, w2 = sdist.all_gather_planes(torch.from_numpy(planes.reshape(per_rank * 2, n)) + k, async_op=True)
+            outs.append(o2); works.append(w2)
+        for k in range(2):
+            works[k].wait()
+            assert torch.equal(outs[k], gathered + k)
         t = sdist.max_over_ranks(float(rank + 1), "cpu")
         assert t == float(world)
         q.put((rank, gathered.numpy().reshape(world, per_rank, 2, n).copy()))
