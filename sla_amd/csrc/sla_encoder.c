@@ -56,7 +56,7 @@ struct SLAEncoder {
   hipStream_t stream, stream2, stream3;
   int own_copy_streams;
   hipStream_t stream_up, stream_down;            /* descriptor uploads / result downloads: kept off the kernel streams */
-  hipEvent_t  ev[2 + 8 * 15];       /* prepass pair + MAX_CHUNKS x EV_PER_CHUNK */
+  hipEvent_t  ev[2 + 8 * 16];       /* prepass pair + MAX_CHUNKS x EV_PER_CHUNK */
   uint32_t chunks;
   uint32_t split[8], split_count, chunk_cut[9];   /* relative chunk sizes (SLA_HIP_CHUNK_SPLIT="1,3,1"), boundaries of this run */
   int      device_plan;             /* 1: code lengths + Dijkstra on the device where certified (default), 0: host only */
@@ -444,7 +444,7 @@ static int blocks_push(struct SLAEncoder* e, uint32_t start, uint32_t nsmpl, uin
 
 #define MAX_CHUNKS 8
 enum { EV_SEARCH_S, EV_SEARCH_E, EV_SEARCH_DONE, EV_LPCB_S, EV_LPCB_E, EV_LAT_E, EV_ACF_S, EV_ACF_E, EV_BLOCK_DONE,
-       EV_TAIL_S, EV_TAIL_E, EV_TAIL_DONE, EV_UPLOADED, EV_PLANNED, EV_PLAN_DOWN, EV_PER_CHUNK };
+       EV_TAIL_S, EV_TAIL_E, EV_TAIL_DONE, EV_UPLOADED, EV_PLANNED, EV_PLAN_DOWN, EV_LPC_DOWN, EV_PER_CHUNK };
 
 typedef struct { uint32_t start, window, min_blk, shape, slot_base, grp_lo, grp_hi, xg; } sframe_t;
 typedef struct { uint32_t window, min_blk, nodes, ncand, cand_first; uint32_t pair[SLAI_MAX_NODES * SLAI_MAX_NODES]; } shape_t;
@@ -572,6 +572,9 @@ static void actx_free(actx_t* a)
 }
 
 /* prepass + whole-file tables: offset_lshift, super-frames, candidate shapes, search groups */
+static double g_trace_t0;
+#define PTRACE(label) do { if (getenv("SLA_HIP_TRACE") != NULL) { fprintf(stderr, "[sla_hip]   prepare +%7.3f ms  %s\n", now_ms() - g_trace_t0, (label)); } } while (0)
+
 static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
 {
   const uint32_t C = e->wave_format.num_channels, bps = e->wave_format.bit_per_sample;
@@ -585,6 +588,7 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
   uint32_t sf_cap = 0, shapes_cap = 8, pos, i;
   const uint64_t* nz;
 
+  g_trace_t0 = now_ms();
   RCCHK(dev_reserve(&e->d_or, 64));
   RCCHK(dev_reserve(&e->d_nz, (size_t)(nwords + 2) * 8));
   RCCHK(pin_reserve(&e->h_nz, (size_t)(nwords + 2) * 8));
@@ -615,6 +619,7 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
   }
   nz = (const uint64_t*)e->h_nz.ptr;
   ((uint64_t*)e->h_nz.ptr)[nwords] = 0; ((uint64_t*)e->h_nz.ptr)[nwords + 1] = 0;
+  PTRACE("prepass + mask on the host");
 
   /* offset_lshift = bps - (32 - ntz(OR of all words))          src/SLAEncoder.c:425-455 */
   {
@@ -670,6 +675,7 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
     }
   }
 
+  PTRACE("super-frame table");
   /* candidate table per shape: every (i,j) whose clipped length is allowed   src/SLAPredictor.c:1615-1630 */
   {
     uint32_t total = 1;
@@ -696,6 +702,7 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
     }
   }
 
+  PTRACE("candidate + window tables");
   /* search groups: (super-frame, channel), candidates sliced so that window + r[] fits the LDS budget */
   {
     uint32_t total_groups = 1;
@@ -1014,6 +1021,13 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
                              (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
                              (uint32_t*)e->d_rshift.ptr, e->stream2));
     HIPCHK(hipEventRecord(ev[EV_LPCB_E], e->stream2));
+    /* the LPC results go home while lattice and FFT run: the host decides RAW blocks in the meantime */
+    HIPCHK(hipStreamWaitEvent(e->stream_down, ev[EV_LPCB_E], 0));
+    HIPCHK(hipMemcpyAsync((double*)e->h_blk_out.ptr + slot_lo * O2, (double*)e->d_blk_out.ptr + slot_lo * O2, sizeof(double) * nsl * O2, hipMemcpyDeviceToHost, e->stream_down));
+    HIPCHK(hipMemcpyAsync((int32_t*)e->h_code.ptr + slot_lo * O1, (int32_t*)e->d_code.ptr + slot_lo * O1, sizeof(int32_t) * nsl * O1, hipMemcpyDeviceToHost, e->stream_down));
+    HIPCHK(hipMemcpyAsync((int32_t*)e->h_kint.ptr + slot_lo * O1, (int32_t*)e->d_kint.ptr + slot_lo * O1, sizeof(int32_t) * nsl * O1, hipMemcpyDeviceToHost, e->stream_down));
+    HIPCHK(hipMemcpyAsync((uint32_t*)e->h_rshift.ptr + slot_lo, (uint32_t*)e->d_rshift.ptr + slot_lo, sizeof(uint32_t) * nsl, hipMemcpyDeviceToHost, e->stream_down));
+    HIPCHK(hipEventRecord(ev[EV_LPC_DOWN], e->stream_down));
     RCCHK(sla_hip_launch_lattice(e->pcm_dev, e->stride, ms, order, dl, nl, (const int32_t*)e->d_kint.ptr, RES1(e), e->stream2));
     HIPCHK(hipEventRecord(ev[EV_LAT_E], e->stream2));
     if (sizeof(double) * (size_t)fft_size > SLA_HIP_LDS_BUDGET) { slots = (ng < 512) ? ng : 512; }
@@ -1023,14 +1037,11 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
                                  (double*)e->d_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD, SLAI_LTM_ACF_HEAD, e->stream2));
     HIPCHK(hipEventRecord(ev[EV_ACF_E], e->stream2));
     HIPCHK(hipStreamWaitEvent(e->stream_down, ev[EV_ACF_E], 0));
-    HIPCHK(hipMemcpyAsync((double*)e->h_blk_out.ptr + slot_lo * O2, (double*)e->d_blk_out.ptr + slot_lo * O2, sizeof(double) * nsl * O2, hipMemcpyDeviceToHost, e->stream_down));
-    HIPCHK(hipMemcpyAsync((int32_t*)e->h_code.ptr + slot_lo * O1, (int32_t*)e->d_code.ptr + slot_lo * O1, sizeof(int32_t) * nsl * O1, hipMemcpyDeviceToHost, e->stream_down));
-    HIPCHK(hipMemcpyAsync((int32_t*)e->h_kint.ptr + slot_lo * O1, (int32_t*)e->d_kint.ptr + slot_lo * O1, sizeof(int32_t) * nsl * O1, hipMemcpyDeviceToHost, e->stream_down));
-    HIPCHK(hipMemcpyAsync((uint32_t*)e->h_rshift.ptr + slot_lo, (uint32_t*)e->d_rshift.ptr + slot_lo, sizeof(uint32_t) * nsl, hipMemcpyDeviceToHost, e->stream_down));
     HIPCHK(hipMemcpyAsync((double*)e->h_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD, (double*)e->d_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD,
                           sizeof(double) * (size_t)ng * SLAI_LTM_ACF_HEAD, hipMemcpyDeviceToHost, e->stream_down));
   } else {
     HIPCHK(hipEventRecord(ev[EV_LPCB_E], e->stream2));
+    HIPCHK(hipEventRecord(ev[EV_LPC_DOWN], e->stream_down));
     HIPCHK(hipEventRecord(ev[EV_LAT_E], e->stream2));
     HIPCHK(hipEventRecord(ev[EV_ACF_S], e->stream2));
     HIPCHK(hipEventRecord(ev[EV_ACF_E], e->stream2));
@@ -1067,22 +1078,20 @@ static void raw_one(void* vctx, uint32_t rel)
   }
 }
 
-/* host + stage 3 of chunk c: RAW decision, long-term solve, then k_tail */
-static int tail_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
+/* host part 1 of stage 3 (needs only the LPC results): RAW decision per block, list of tail jobs */
+static int raw_phase(struct SLAEncoder* e, actx_t* a, uint32_t c)
 {
   chunk_t* k = &a->ck[c];
   const uint32_t C = e->wave_format.num_channels;
-  const uint32_t ntaps = e->encode_param.longterm_order, lms = e->encode_param.lms_order_per_filter;
-  sla_hip_tail_job* jobs = (sla_hip_tail_job*)e->h_jobs.ptr;
-  hipEvent_t* ev = a->ev + (size_t)c * EV_PER_CHUNK;
-  uint32_t b, ch, j, t, nj;
-
+  uint32_t b, ch;
   k->job_lo = a->njobs;
   /* RAW decision per block (any channel's estimate >= 0.95, src/SLAEncoder.c:553-565) on the host threads */
   {
     raw_ctx_t rc;
     rc.e = e; rc.blk_lo = k->blk_lo;
+    g_trace_t0 = now_ms();
     parallel_for(e->pool, k->blk_hi - k->blk_lo, raw_one, &rc);
+    PTRACE("tail: RAW decision");
   }
   for (b = k->blk_lo; b < k->blk_hi; b++) {
     if (e->blk[b].type != SLAI_BLK_COMPRESS) { continue; }
@@ -1092,12 +1101,25 @@ static int tail_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     }
   }
   k->job_hi = a->njobs;
+  return 0;
+}
+
+/* host part 2 + stage 3 of chunk c: long-term solve from the FFT records, then k_tail */
+static int tail_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
+{
+  chunk_t* k = &a->ck[c];
+  const uint32_t C = e->wave_format.num_channels;
+  const uint32_t ntaps = e->encode_param.longterm_order, lms = e->encode_param.lms_order_per_filter;
+  sla_hip_tail_job* jobs = (sla_hip_tail_job*)e->h_jobs.ptr;
+  hipEvent_t* ev = a->ev + (size_t)c * EV_PER_CHUNK;
+  uint32_t j, t, nj;
   nj = k->job_hi - k->job_lo;
   {
     ltm_ctx_t lc;
     lc.e = e; lc.acf = (const double*)e->h_acf.ptr; lc.job_blk = a->job_blk; lc.job_ch = a->job_ch; lc.job_grp = a->job_grp;
     lc.job_lo = k->job_lo;
     parallel_for(e->pool, nj, ltm_one, &lc);
+    PTRACE("tail: long-term solve");
   }
   HIPCHK(hipEventRecord(ev[EV_TAIL_S], e->stream3));
   if (nj > 0) {
@@ -1109,6 +1131,7 @@ static int tail_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
       for (t = 0; t < SLAI_MAX_TAPS; t++) { jobs[j].ltm_coef[t] = bc->ltm_q[t]; }
       jobs[j].pad_[0] = jobs[j].pad_[1] = 0;
     }
+    PTRACE("tail: jobs built");
     HIPCHK(hipMemcpyAsync(dj, jobs + k->job_lo, sizeof(sla_hip_tail_job) * nj, hipMemcpyHostToDevice, e->stream3));
     HIPCHK(hipEventRecord(ev[EV_TAIL_S], e->stream3));
     RCCHK(sla_hip_launch_tail(RES1(e), RES2(e), e->stride, dj, nj, ntaps, lms, (uint64_t*)e->d_fold.ptr + k->job_lo, e->stream3));
@@ -1253,6 +1276,8 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
     TRACE("blocks launched", c);
     if (c >= 1) {
       hipEvent_t* pv = a.ev + (size_t)(c - 1) * EV_PER_CHUNK;
+      if (hipEventSynchronize(pv[EV_LPC_DOWN]) != hipSuccess) { rc = SLA_APIRESULT_NG; break; }
+      if ((rc = raw_phase(e, &a, c - 1)) != 0) { break; }
       if (hipEventSynchronize(pv[EV_BLOCK_DONE]) != hipSuccess) { rc = SLA_APIRESULT_NG; break; }
       TRACE("blocks done", c - 1);
       t0 = now_ms();
@@ -1263,7 +1288,8 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   }
   if (rc == 0) {
     hipEvent_t* pv = a.ev + (size_t)(a.nchunks - 1) * EV_PER_CHUNK;
-    if (hipEventSynchronize(pv[EV_BLOCK_DONE]) != hipSuccess) { rc = SLA_APIRESULT_NG; }
+    if (hipEventSynchronize(pv[EV_LPC_DOWN]) != hipSuccess || (rc = raw_phase(e, &a, a.nchunks - 1)) != 0
+        || hipEventSynchronize(pv[EV_BLOCK_DONE]) != hipSuccess) { if (rc == 0) { rc = SLA_APIRESULT_NG; } }
     else {
       TRACE("blocks done", a.nchunks - 1);
       t0 = now_ms();

@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <float.h>
 #include <stdlib.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -1426,6 +1427,27 @@ void k_ltm_acf(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_a
 // ---------------------------------------------------------------------------------------------
 // launchers (C-ABI, see include/sla_hip.h)
 // ---------------------------------------------------------------------------------------------
+// hipFuncSetAttribute costs a driver call; the limit only ever has to grow (per kernel and device)
+static hipError_t ensure_dynamic_lds(const void* fn, size_t bytes)
+{
+  static struct { const void* fn; int dev; size_t bytes; } seen[64];
+  static int nseen = 0;
+  static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  pthread_mutex_lock(&mu);
+  int slot = -1;
+  for (int i = 0; i < nseen; i++) { if (seen[i].fn == fn && seen[i].dev == dev) { slot = i; break; } }
+  if (slot >= 0 && seen[slot].bytes >= bytes) { pthread_mutex_unlock(&mu); return hipSuccess; }
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) {
+    if (slot < 0 && nseen < 64) { slot = nseen++; seen[slot].fn = fn; seen[slot].dev = dev; seen[slot].bytes = 0; }
+    if (slot >= 0) { seen[slot].bytes = bytes; }
+  }
+  pthread_mutex_unlock(&mu);
+  return e;
+}
+
 static inline int hip_rc(hipError_t e) { return (e == hipSuccess) ? 0 : -(int)e; }
 
 extern "C" int sla_hip_launch_prepass(const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_channels,
@@ -1509,7 +1531,7 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
       if (bytes > SLA_HIP_LDS_BUDGET) { continue; }
       const uint32_t spl = (nch <= 32) ? 12 : 6;                    // producer lanes per chain: nch * spl <= LB_PRODUCERS
       const void* fn = (spl == 12) ? (const void*)k_lpc_blocks<12> : (const void*)k_lpc_blocks<6>;
-      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      hipError_t e = ensure_dynamic_lds(fn, bytes);
       if (e != hipSuccess) { return hip_rc(e); }
       const dim3 grid((num_groups + p - 1) / p), block(LB_THREADS);
       const uint32_t clk = (uint32_t)(getenv("SLA_HIP_LPC_CLK") != nullptr);
@@ -1553,7 +1575,7 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
   if (x_region * pack < 2 * (size_t)pack * max_cands_per_group * (order + 2)) { x_region = 2 * (size_t)max_cands_per_group * (order + 2); }
   size_t lds = sizeof(double) * ((size_t)pack * x_region + (size_t)pack * per_group_r);
   if (lds > SLA_HIP_LDS_BUDGET) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
-  hipError_t e = hipFuncSetAttribute((const void*)k_lpc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = ensure_dynamic_lds((const void*)k_lpc, lds);
   if (e != hipSuccess) { return hip_rc(e); }
   hipLaunchKernelGGL(k_lpc, dim3((num_groups + pack - 1) / pack), dim3(256), lds, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
                      d_groups, num_groups, pack, d_cands, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)x_region,
@@ -1595,7 +1617,7 @@ extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_
   if (dbg & 8) { return 0; }
   const uint32_t batch = (max_cands_per_group < XF_BATCH) ? max_cands_per_group : XF_BATCH;
   const size_t lds = sizeof(double) * (size_t)batch * ((order + 1) + 2 * (size_t)(order + 2));
-  e = hipFuncSetAttribute((const void*)k_search_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  e = ensure_dynamic_lds((const void*)k_search_finish, lds);
   if (e != hipSuccess) { return hip_rc(e); }
   hipLaunchKernelGGL(k_search_finish, dim3(num_groups), dim3(64), lds, st, order, lags, batch,
                      d_groups, d_cands, d_tile_sums, d_out, exact_limit);
@@ -1669,7 +1691,7 @@ extern "C" int sla_hip_launch_ltm_acf(const int32_t* d_residual, uint64_t plane_
   const uint32_t dbg = (uint32_t)(getenv("SLA_HIP_ACF_SKIP") ? atoi(getenv("SLA_HIP_ACF_SKIP")) : 0);
   const size_t lds = sizeof(double) * (size_t)fft_size;
   if (lds <= SLA_HIP_LDS_BUDGET) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_ltm_acf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds((const void*)k_ltm_acf<true>, lds);
     if (e != hipSuccess) { return hip_rc(e); }
     hipLaunchKernelGGL(k_ltm_acf<true>, dim3(num_jobs), dim3(ACF_THREADS), lds, st, d_residual, plane_stride, d_jobs, num_jobs,
                        log2F, d_twiddles, (double*)nullptr, d_acf_head, head, dbg);
