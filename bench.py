@@ -36,7 +36,6 @@ WORKLOAD_NAME = {
     "C4": "48 kHz 16-bit stereo clip, order-16 LPC, 4096-sample frames (MS)",
     "C5": "96 kHz 24-bit 8-channel, 30 min, order-48 LPC, 8192-sample frames",
 }
-KERNEL_NAMES = ["k_prepass", "k_lpc (partition search)", "k_lpc (chosen blocks)", "k_lattice", "k_tail", "k_ltm_acf"]
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 ALGO_BYTES_PER_SAMPLE = 8      # 4 B int32 PCM read + 4 B int32 final residual written
 

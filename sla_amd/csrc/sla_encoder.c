@@ -575,63 +575,17 @@ static void actx_free(actx_t* a)
 static double g_trace_t0;
 #define PTRACE(label) do { if (getenv("SLA_HIP_TRACE") != NULL) { fprintf(stderr, "[sla_hip]   prepare +%7.3f ms  %s\n", now_ms() - g_trace_t0, (label)); } } while (0)
 
-static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
+/* whole-file tables: super-frames (hop over silence runs), candidate shapes, search groups.  nz == NULL: no
+ * sample is silent (the speculative pass that runs while the prepass is still on the device) */
+static int build_tables(struct SLAEncoder* e, actx_t* a, const uint64_t* nz)
 {
   const uint32_t C = e->wave_format.num_channels, bps = e->wave_format.bit_per_sample;
   const uint32_t order = e->encode_param.parcor_order, O1 = order + 1;
-  const uint32_t ms = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
   const uint32_t n = e->num_samples, maxb = e->encode_param.max_num_block_samples;
-  const uint64_t nwords = ((uint64_t)n + 63) / 64;
   extern uint32_t sla_hip_lattice_chunk_samples(uint32_t order);
   const uint32_t chunk_samples = sla_hip_lattice_chunk_samples(order);
   sla_hip_lpc_cand* cands; sla_hip_lpc_group* groups;
   uint32_t sf_cap = 0, shapes_cap = 8, pos, i;
-  const uint64_t* nz;
-
-  g_trace_t0 = now_ms();
-  RCCHK(dev_reserve(&e->d_or, 64));
-  RCCHK(dev_reserve(&e->d_nz, (size_t)(nwords + 2) * 8));
-  RCCHK(pin_reserve(&e->h_nz, (size_t)(nwords + 2) * 8));
-  HIPCHK(hipEventRecord(e->ev[0], e->stream));
-  RCCHK(sla_hip_launch_prepass(e->pcm_dev, e->stride, C, n, bps, ms, (uint32_t*)e->d_or.ptr, (uint64_t*)e->d_nz.ptr, e->stream));
-  HIPCHK(hipEventRecord(e->ev[1], e->stream));
-  {
-    /* Without an all-zero mask word there is no silence to find, except at the very end of the file where the
-     * minimum block length shrinks with what is left (src/SLAEncoder.c:846-869): only the last words of the mask
-     * are fetched then, everything before them counts as "not silent" (a run of zeros shorter than the minimum
-     * block length never changes a decision). */
-    const uint64_t tail_words = (nwords < SLAI_MIN_BLOCK / 64 + 2) ? nwords : (SLAI_MIN_BLOCK / 64 + 2);
-    const uint64_t head_words = nwords - tail_words;
-    HIPCHK(hipMemcpyAsync(e->h_or, e->d_or.ptr, 8, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync((uint64_t*)e->h_nz.ptr + head_words, (uint64_t*)e->d_nz.ptr + head_words, (size_t)tail_words * 8, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    if (e->h_or[1] != 0) {
-      HIPCHK(hipMemcpyAsync(e->h_nz.ptr, e->d_nz.ptr, (size_t)head_words * 8, hipMemcpyDeviceToHost, e->stream));
-      HIPCHK(hipStreamSynchronize(e->stream));
-      e->nz_ones_words = 0;
-    } else {
-      if (e->nz_ones_cap != e->h_nz.cap) { e->nz_ones_cap = e->h_nz.cap; e->nz_ones_words = 0; }   /* reallocated since (a new block may reuse the address) */
-      if (e->nz_ones_words < head_words) {
-        memset((uint64_t*)e->h_nz.ptr + e->nz_ones_words, 0xFF, (size_t)(head_words - e->nz_ones_words) * 8);
-      }
-      e->nz_ones_words = head_words;       /* the words behind it were just overwritten by the tail copy */
-    }
-  }
-  nz = (const uint64_t*)e->h_nz.ptr;
-  ((uint64_t*)e->h_nz.ptr)[nwords] = 0; ((uint64_t*)e->h_nz.ptr)[nwords + 1] = 0;
-  PTRACE("prepass + mask on the host");
-
-  /* offset_lshift = bps - (32 - ntz(OR of all words))          src/SLAEncoder.c:425-455 */
-  {
-    const uint32_t mask = e->h_or[0];
-    e->lshift = 0;
-    if (mask != 0) {
-      const uint32_t ntz = (uint32_t)__builtin_ctz(mask);
-      if (bps < 32 - ntz) { return SLA_APIRESULT_INVALID_ARGUMENT; }   /* samples wider than declared */
-      e->lshift = bps - (32 - ntz);
-      if (e->lshift >= bps) { return SLA_APIRESULT_INVALID_ARGUMENT; }
-    }
-  }
 
   /* super-frame table (sequential hop over silence runs)        src/SLAEncoder.c:846-869, 392-408 */
   a->shapes = (shape_t*)malloc(sizeof(shape_t) * shapes_cap);
@@ -759,6 +713,84 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
     a->nslots += C * sh->ncand;
     if (sh->window > a->max_window) { a->max_window = sh->window; }
   }
+  return 0;
+}
+
+static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
+{
+  const uint32_t C = e->wave_format.num_channels, bps = e->wave_format.bit_per_sample;
+  const uint32_t order = e->encode_param.parcor_order;
+  const uint32_t ms = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
+  const uint32_t n = e->num_samples, maxb = e->encode_param.max_num_block_samples;
+  const uint64_t nwords = ((uint64_t)n + 63) / 64;
+  const uint64_t* nz;
+  int rebuild = 0;
+
+  g_trace_t0 = now_ms();
+  RCCHK(dev_reserve(&e->d_or, 64));
+  RCCHK(dev_reserve(&e->d_nz, (size_t)(nwords + 2) * 8));
+  RCCHK(pin_reserve(&e->h_nz, (size_t)(nwords + 2) * 8));
+  HIPCHK(hipEventRecord(e->ev[0], e->stream));
+  RCCHK(sla_hip_launch_prepass(e->pcm_dev, e->stride, C, n, bps, ms, (uint32_t*)e->d_or.ptr, (uint64_t*)e->d_nz.ptr, e->stream));
+  HIPCHK(hipEventRecord(e->ev[1], e->stream));
+  {
+    /* Without an all-zero mask word there is no silence to find, except at the very end of the file where the
+     * minimum block length shrinks with what is left (src/SLAEncoder.c:846-869): only the last words of the mask
+     * are fetched then, everything before them counts as "not silent" (a run of zeros shorter than the minimum
+     * block length never changes a decision). */
+    const uint64_t tail_words = (nwords < SLAI_MIN_BLOCK / 64 + 2) ? nwords : (SLAI_MIN_BLOCK / 64 + 2);
+    const uint64_t head_words = nwords - tail_words;
+    HIPCHK(hipMemcpyAsync(e->h_or, e->d_or.ptr, 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync((uint64_t*)e->h_nz.ptr + head_words, (uint64_t*)e->d_nz.ptr + head_words, (size_t)tail_words * 8, hipMemcpyDeviceToHost, e->stream));
+    /* while the prepass runs: the tables of a file without silence (the usual case; checked below) */
+    RCCHK(build_tables(e, a, NULL));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->h_or[1] != 0) {
+      HIPCHK(hipMemcpyAsync(e->h_nz.ptr, e->d_nz.ptr, (size_t)head_words * 8, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipStreamSynchronize(e->stream));
+      e->nz_ones_words = 0;
+      rebuild = 1;
+    } else {
+      if (e->nz_ones_cap != e->h_nz.cap) { e->nz_ones_cap = e->h_nz.cap; e->nz_ones_words = 0; }   /* reallocated since (a new block may reuse the address) */
+      if (e->nz_ones_words < head_words) {
+        memset((uint64_t*)e->h_nz.ptr + e->nz_ones_words, 0xFF, (size_t)(head_words - e->nz_ones_words) * 8);
+      }
+      e->nz_ones_words = head_words;       /* the words behind it were just overwritten by the tail copy */
+    }
+  }
+  nz = (const uint64_t*)e->h_nz.ptr;
+  ((uint64_t*)e->h_nz.ptr)[nwords] = 0; ((uint64_t*)e->h_nz.ptr)[nwords + 1] = 0;
+  PTRACE("prepass + mask on the host");
+
+  /* offset_lshift = bps - (32 - ntz(OR of all words))          src/SLAEncoder.c:425-455 */
+  {
+    const uint32_t mask = e->h_or[0];
+    e->lshift = 0;
+    if (mask != 0) {
+      const uint32_t ntz = (uint32_t)__builtin_ctz(mask);
+      if (bps < 32 - ntz) { return SLA_APIRESULT_INVALID_ARGUMENT; }   /* samples wider than declared */
+      e->lshift = bps - (32 - ntz);
+      if (e->lshift >= bps) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+    }
+  }
+
+  /* without all-zero mask words only the last super-frame can still be silent (its minimum block length is what
+   * is left of the file) */
+  if (!rebuild && a->nsf > 0) {
+    const sframe_t* f = &a->sf[a->nsf - 1];
+    const uint32_t remain = n - f->start;
+    const uint32_t window = (maxb < remain) ? maxb : remain;
+    const uint32_t min_blk = (SLAI_MIN_BLOCK < remain) ? SLAI_MIN_BLOCK : remain;
+    if (slai_zero_run(nz, f->start, window) >= min_blk) { rebuild = 1; }
+  }
+  if (rebuild) {
+    free(a->sf); free(a->shapes); a->sf = NULL; a->shapes = NULL;
+    a->nsf = 0; a->nshapes = 0; a->ncands = 0; a->nsgroups = 0; a->nslots = 0; a->nxg = 0;
+    a->blocks_bound = 0; a->lchunks_bound = 0;
+    RCCHK(build_tables(e, a, nz));
+  }
+  a->exact = (e->search_exact && SLAI_SEARCH_DELTA == SLA_HIP_XTILE && maxb <= SLA_HIP_XTILE * SLA_HIP_XTILES
+              && sla_hip_search_exact_lags(order) != 0 && e->h_or[0] != 0);
   return 0;
 }
 
@@ -914,6 +946,7 @@ static int plan_chunk(struct SLAEncoder* e, actx_t* a, uint32_t c)
   const uint64_t* nz = (const uint64_t*)e->h_nz.ptr;
   plan_ctx_t ctx;
   uint32_t i;
+  int certified_only = 0;
   ctx.e = e; ctx.a = a; ctx.sf_lo = k->sf_lo;
   ctx.cands = (const sla_hip_lpc_cand*)e->h_cands.ptr; ctx.out = (const double*)e->h_lpc_out.ptr;
   if (e->device_plan) {
@@ -925,13 +958,18 @@ static int plan_chunk(struct SLAEncoder* e, actx_t* a, uint32_t c)
       if (a->sf[i].shape != 0xFFFFFFFFu && st[a->sf[i].xg / C] != 0) { open_frames++; }
     }
     e->host_planned += open_frames;
+    certified_only = (open_frames == 0);
     if (open_frames != 0) {
       HIPCHK(hipMemcpyAsync((double*)e->h_lpc_out.ptr + (size_t)k->slot_lo * O2, (double*)e->d_lpc_out.ptr + (size_t)k->slot_lo * O2,
                             sizeof(double) * (size_t)(k->slot_hi - k->slot_lo) * O2, hipMemcpyDeviceToHost, e->stream));
       HIPCHK(hipStreamSynchronize(e->stream));
     }
   }
-  parallel_for(e->pool, k->sf_hi - k->sf_lo, plan_one, &ctx);
+  if (e->device_plan && certified_only) {
+    for (i = 0; i < k->sf_hi - k->sf_lo; i++) { plan_one(&ctx, i); }        /* a copy per super-frame: not worth waking the pool */
+  } else {
+    parallel_for(e->pool, k->sf_hi - k->sf_lo, plan_one, &ctx);
+  }
   k->blk_lo = e->num_blocks;
   for (i = k->sf_lo; i < k->sf_hi; i++) {
     const sframe_t* f = &a->sf[i];

@@ -79,6 +79,7 @@ int slai_shortest_path(const double* adj, uint32_t nodes, uint32_t* path)
 uint32_t slai_zero_run(const uint64_t* nz, uint64_t from, uint64_t limit)
 {
   uint64_t pos = from, end = from + limit;
+  if (nz == NULL) { return 0; }                 /* no mask: nothing is silent */
   while (pos < end) {
     uint64_t word = nz[pos >> 6] >> (pos & 63);
     if (word != 0) {
