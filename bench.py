@@ -98,6 +98,7 @@ def main():
 
     from sla_amd import dist as sdist
     step_no = [0]
+    span_ms = np.zeros(4)       # on-device execution time of k_lpc_blocks, k_lattice, k_ltm_acf, k_tail (summed over steps)
 
     def settle(b):
         if works[b] is not None:
@@ -112,6 +113,7 @@ def main():
         if nbuf > 1:
             enc.bind_residual_planes(d_lat[b].data_ptr(), d_fin[b].data_ptr(), stride)
         t = enc.analyze_device(d_pcm.data_ptr(), stride, n)
+        span_ms[:] += np.array(enc.last_kernel_ms())
         if world > 1:
             if overlap:
                 works[b] = sdist.all_gather_planes(d_fin[b], gathered[b], async_op=True)[1]
@@ -129,6 +131,7 @@ def main():
     if world > 1:
         dist.barrier()
     kernel_ms = np.zeros(12)
+    span_ms[:] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         kernel_ms += np.array(step())
@@ -141,6 +144,7 @@ def main():
     if world > 1:
         elapsed = sdist.max_over_ranks(elapsed, "cuda" if args.backend == "nccl" else "cpu")
     kernel_ms /= max(args.steps, 1)
+    span_ms /= max(args.steps, 1)
 
     total_samples = float(n) * nch * world * args.steps
     value = total_samples / elapsed / 1e6
@@ -165,12 +169,18 @@ def main():
         # over the file: partition search and chosen blocks; chunked stages launch once per chunk)
         nchunks = max(int(round(kernel_ms[9])), 1)
         exact_search = kernel_ms[11] > 0.5      # partition search ran on tile sums, k_lpc only on the chosen blocks
-        kernels = {"k_prepass": (kernel_ms[0], 1, 1),
-                   "k_lpc_blocks": (kernel_ms[2], nchunks, 1),
-                   "k_lattice": (kernel_ms[3], nchunks, 1), "k_ltm_acf": (kernel_ms[8], nchunks, 1),
-                   "k_tail": (kernel_ms[4], nchunks, 1)}
-        if exact_search:
-            kernels["k_acf_tiles"] = (kernel_ms[1], nchunks, 1)      # the event pair also spans k_search_finish
+        # the four big kernels report their own execution time (first wave in to last wave out, constant-rate device
+        # clock = what rocprofv3 --kernel-trace shows); stream-event pairs also count the time a launch waits behind
+        # kernels of the other streams, so they are kept for the stages that have nothing else
+        ev = {"k_lpc_blocks": kernel_ms[2], "k_lattice": kernel_ms[3], "k_ltm_acf": kernel_ms[8], "k_tail": kernel_ms[4]}
+        dev = dict(zip(("k_lpc_blocks", "k_lattice", "k_ltm_acf", "k_tail"), span_ms))
+        kernels = {"k_prepass": (kernel_ms[0], 1, 1)}
+        for name in ev:
+            kernels[name] = (dev[name] if dev[name] > 0 else ev[name], nchunks, 1)
+        if exact_search and kernel_ms[10] > 0:
+            kernels["k_lpc"] = (kernel_ms[1], nchunks, 1)            # tile sums + rerun of the flagged windows as serial chains: the chains dominate
+        elif exact_search:
+            kernels["k_acf_tiles"] = (kernel_ms[1], nchunks, 1)      # the event pair also spans k_search_finish and k_plan
         else:
             kernels["k_lpc"] = (kernel_ms[1], nchunks, 1)            # serial-chain partition search
         dom = max(kernels, key=lambda k: kernels[k][0])
@@ -182,7 +192,11 @@ def main():
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                            "traffic": None, "kernel_ms": round(float(launch_ms), 4), "launches_per_step": launches,
                            "algorithmic_bytes_per_launch": algo_bytes,
-                           "note": "kernel_ms = average HIP-event duration of one launch of this kernel inside the timed region"}
+                           "kernel_ms_stream_events": round(float(ev.get(dom, kernels[dom][0]) / launches), 4),
+                           "note": "kernel_ms = average duration of one launch of this kernel inside the timed region, measured on the "
+                                   "device (first wave in to last wave out, 100 MHz device clock) as rocprofv3 --kernel-trace does; "
+                                   "kernel_ms_stream_events = the same launches between HIP events on their stream (includes queueing "
+                                   "behind kernels of the other streams)"}
         # HBM traffic per launch of that kernel from the committed rocprofv3 --pmc passes (same config only)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.config.lower())))
@@ -191,6 +205,7 @@ def main():
                 out["roofline"]["traffic_source"] = pmc["source"]
         except (OSError, KeyError, ValueError):
             pass
+        out["kernel_ms_on_device"] = {k: round(float(v), 4) for k, v in dev.items()}
         out["stage_ms"] = {"k_prepass": round(float(kernel_ms[0]), 4),
                            ("search_tile_sums" if exact_search else "k_lpc_search"): round(float(kernel_ms[1]), 4),
                            "search_fallback_groups": round(float(kernel_ms[10]), 2),

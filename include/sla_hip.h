@@ -279,6 +279,12 @@ int sla_hip_last_timing(const struct SLAEncoder* encoder, float* timing_ms);
  * had to decide (device plan not certified); 1 if the search ran on tile sums; 1 if the device plan is enabled. */
 int sla_hip_last_counters(const struct SLAEncoder* encoder, uint32_t* counters);
 
+/* 4 floats [ms]: execution time of k_lpc_blocks, k_lattice, k_ltm_acf, k_tail in the last analysis, summed over
+ * its launches and measured ON the device (first wave in to last wave out, constant 100 MHz clock) -- what
+ * rocprofv3 --kernel-trace reports, without the time a launch spends queued behind kernels of other streams
+ * that a pair of stream events includes. */
+int sla_hip_last_kernel_ms(const struct SLAEncoder* encoder, float* kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,6 +114,7 @@ def lib():
         L.sla_hip_device_name.restype = C.c_char_p
         L.sla_hip_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.sla_hip_last_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.sla_hip_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.sla_hip_search_exact_lags.restype = C.c_uint32
         _lib = L
     return _lib
@@ -128,7 +129,7 @@ EXPORTED_SYMBOLS = [
     "sla_hip_launch_ltm_acf", "sla_hip_launch_rice_len", "sla_hip_launch_rice_write", "sla_hip_pack_device", "sla_hip_launch_unpack16",
     "sla_hip_analyze_device", "sla_hip_pack", "sla_hip_final_residual", "sla_hip_lattice_residual",
     "sla_hip_get_trace", "sla_hip_device_name", "sla_hip_last_timing", "sla_hip_launch_search_exact",
-    "sla_hip_search_exact_lags", "sla_hip_launch_plan", "sla_hip_last_counters", "sla_hip_launch_lpc_rerun", "sla_hip_bind_residual_planes",
+    "sla_hip_search_exact_lags", "sla_hip_launch_plan", "sla_hip_last_counters", "sla_hip_launch_lpc_rerun", "sla_hip_last_kernel_ms", "sla_hip_bind_residual_planes",
 ]
 
 
@@ -261,6 +262,12 @@ class Encoder:
         timing = (C.c_float * 12)()
         self._check(self._lib.sla_hip_last_timing(self._h, timing), "sla_hip_last_timing")
         return list(timing)
+
+    def last_kernel_ms(self):
+        """on-device execution time [ms] of (k_lpc_blocks, k_lattice, k_ltm_acf, k_tail) in the last analysis"""
+        k = (C.c_float * 4)()
+        self._check(self._lib.sla_hip_last_kernel_ms(self._h, k), "sla_hip_last_kernel_ms")
+        return list(k)
 
     def last_counters(self):
         """(search groups rerun as chains, super-frames planned on the host, exact search used, device plan enabled)"""

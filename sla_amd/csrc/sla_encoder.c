@@ -71,7 +71,7 @@ struct SLAEncoder {
   /* device workspace */
   devbuf_t d_pcm, d_res1, d_res2, d_or, d_nz, d_groups, d_cands, d_lpc_out, d_code, d_kint, d_rshift,
            d_winpool, d_chunks, d_jobs, d_fold, d_acf_jobs, d_acf, d_acf_scratch, d_twiddle, d_bgroups, d_bcands, d_blk_out, d_kk, d_pk_jobs, d_pk_blocks, d_pk_hdr, d_image,
-           d_xgroups, d_tile_sums, d_fgroups, d_parts, d_nparts, d_pstatus;
+           d_xgroups, d_tile_sums, d_fgroups, d_parts, d_nparts, d_pstatus, d_spans;
   int twiddle_ready;
   /* pinned host staging */
   pinbuf_t h_nz, h_groups, h_cands, h_lpc_out, h_code, h_kint, h_rshift, h_chunks, h_jobs, h_fold, h_res, h_pcm, h_acf_jobs, h_acf,
@@ -99,8 +99,10 @@ struct SLAEncoder {
   size_t   coef_cap;
   int      analysed;
   float    timing[12];
+  float    kernel_ms[4];            /* last analysis: on-device execution spans of k_lpc_blocks, k_lattice, k_ltm_acf, k_tail, summed over chunks */
 };
 
+#define SPAN_SLOT(e, chunk, kernel) ((unsigned long long*)(e)->d_spans.ptr + ((size_t)(chunk) * 4 + (kernel)) * 2)
 #define RES1(e) ((e)->user_res1 != NULL ? (e)->user_res1 : (int32_t*)(e)->d_res1.ptr)
 #define RES2(e) ((e)->user_res2 != NULL ? (e)->user_res2 : (int32_t*)(e)->d_res2.ptr)
 
@@ -324,7 +326,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
 
 void SLAEncoder_Destroy(struct SLAEncoder* e)
 {
-  devbuf_t* d[33];
+  devbuf_t* d[34];
   pinbuf_t* h[25];
   int i;
   if (e == NULL) { return; }
@@ -337,8 +339,8 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   d[19] = &e->d_bgroups; d[20] = &e->d_bcands; d[21] = &e->d_blk_out;
   d[22] = &e->d_kk; d[23] = &e->d_pk_jobs; d[24] = &e->d_pk_blocks; d[25] = &e->d_pk_hdr; d[26] = &e->d_image;
   d[27] = &e->d_xgroups; d[28] = &e->d_tile_sums; d[29] = &e->d_fgroups;
-  d[30] = &e->d_parts; d[31] = &e->d_nparts; d[32] = &e->d_pstatus;
-  for (i = 0; i < 33; i++) { if (d[i]->ptr != NULL) { (void)hipFree(d[i]->ptr); } }
+  d[30] = &e->d_parts; d[31] = &e->d_nparts; d[32] = &e->d_pstatus; d[33] = &e->d_spans;
+  for (i = 0; i < 34; i++) { if (d[i]->ptr != NULL) { (void)hipFree(d[i]->ptr); } }
   h[0] = &e->h_nz; h[1] = &e->h_groups; h[2] = &e->h_cands; h[3] = &e->h_lpc_out; h[4] = &e->h_code; h[5] = &e->h_kint;
   h[6] = &e->h_rshift; h[7] = &e->h_chunks; h[8] = &e->h_jobs; h[9] = &e->h_fold; h[10] = &e->h_res; h[11] = &e->h_pcm;
   h[12] = &e->h_acf_jobs; h[13] = &e->h_acf; h[14] = &e->h_bgroups; h[15] = &e->h_bcands; h[16] = &e->h_blk_out;
@@ -1054,6 +1056,7 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     HIPCHK(hipEventRecord(ev[EV_UPLOADED], e->stream_up));
     HIPCHK(hipStreamWaitEvent(e->stream2, ev[EV_UPLOADED], 0));
     HIPCHK(hipEventRecord(ev[EV_LPCB_S], e->stream2));
+    slai_next_launch_span(SPAN_SLOT(e, c, 0));
     RCCHK(sla_hip_launch_lpc(e->pcm_dev, e->stride, ms, order, dg, ng, max_window, 1,
                              (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
                              (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
@@ -1066,10 +1069,12 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     HIPCHK(hipMemcpyAsync((int32_t*)e->h_kint.ptr + slot_lo * O1, (int32_t*)e->d_kint.ptr + slot_lo * O1, sizeof(int32_t) * nsl * O1, hipMemcpyDeviceToHost, e->stream_down));
     HIPCHK(hipMemcpyAsync((uint32_t*)e->h_rshift.ptr + slot_lo, (uint32_t*)e->d_rshift.ptr + slot_lo, sizeof(uint32_t) * nsl, hipMemcpyDeviceToHost, e->stream_down));
     HIPCHK(hipEventRecord(ev[EV_LPC_DOWN], e->stream_down));
+    slai_next_launch_span(SPAN_SLOT(e, c, 1));
     RCCHK(sla_hip_launch_lattice(e->pcm_dev, e->stride, ms, order, dl, nl, (const int32_t*)e->d_kint.ptr, RES1(e), e->stream2));
     HIPCHK(hipEventRecord(ev[EV_LAT_E], e->stream2));
     if (sizeof(double) * (size_t)fft_size > SLA_HIP_LDS_BUDGET) { slots = (ng < 512) ? ng : 512; }
     HIPCHK(hipEventRecord(ev[EV_ACF_S], e->stream2));
+    slai_next_launch_span(SPAN_SLOT(e, c, 2));
     RCCHK(sla_hip_launch_ltm_acf(RES1(e), e->stride, da, ng, fft_size, (const double*)e->d_twiddle.ptr,
                                  (double*)e->d_acf_scratch.ptr, slots,
                                  (double*)e->d_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD, SLAI_LTM_ACF_HEAD, e->stream2));
@@ -1172,6 +1177,7 @@ static int tail_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     PTRACE("tail: jobs built");
     HIPCHK(hipMemcpyAsync(dj, jobs + k->job_lo, sizeof(sla_hip_tail_job) * nj, hipMemcpyHostToDevice, e->stream3));
     HIPCHK(hipEventRecord(ev[EV_TAIL_S], e->stream3));
+    slai_next_launch_span(SPAN_SLOT(e, c, 3));
     RCCHK(sla_hip_launch_tail(RES1(e), RES2(e), e->stride, dj, nj, ntaps, lms, (uint64_t*)e->d_fold.ptr + k->job_lo, e->stream3));
     HIPCHK(hipEventRecord(ev[EV_TAIL_E], e->stream3));
     HIPCHK(hipMemcpyAsync((uint64_t*)e->h_fold.ptr + k->job_lo, (uint64_t*)e->d_fold.ptr + k->job_lo, sizeof(uint64_t) * nj, hipMemcpyDeviceToHost, e->stream3));
@@ -1245,6 +1251,9 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   }
   TRACE("prepared (prepass + tables)", a.nsf);
   if ((rc = pipeline_reserve(e, &a)) != 0) { actx_free(&a); return rc; }
+  if (dev_reserve(&e->d_spans, sizeof(unsigned long long) * MAX_CHUNKS * 4 * 2) != 0
+      || hipMemsetAsync(e->d_spans.ptr, 0, sizeof(unsigned long long) * MAX_CHUNKS * 4 * 2, e->stream) != hipSuccess
+      || hipStreamSynchronize(e->stream) != hipSuccess) { actx_free(&a); return SLA_APIRESULT_NG; }
   TRACE("reserved", 0);
 
   /* chunking: equal runs of super-frames */
@@ -1342,6 +1351,21 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   if (rc == 0 && !preset_blocks) {
     if (hipMemcpy(&e->fallback_groups, (uint32_t*)e->d_or.ptr + 2, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) { rc = SLA_APIRESULT_NG; }
   }
+  memset(e->kernel_ms, 0, sizeof(e->kernel_ms));
+  if (rc == 0) {
+    unsigned long long sp[MAX_CHUNKS * 4 * 2];
+    int rate_khz = 100000;
+    (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, e->device);
+    if (rate_khz <= 0) { rate_khz = 100000; }
+    if (hipMemcpy(sp, e->d_spans.ptr, sizeof(sp), hipMemcpyDeviceToHost) == hipSuccess) {
+      for (c = 0; c < a.nchunks; c++) {
+        for (i = 0; i < 4; i++) {
+          const unsigned long long st = ~sp[(c * 4 + i) * 2], en = sp[(c * 4 + i) * 2 + 1];
+          if (en != 0 && en > st) { e->kernel_ms[i] += (float)((double)(en - st) / (double)rate_khz); }
+        }
+      }
+    }
+  }
   TRACE("all streams idle", 0);
   if (rc == 0) {
     finish_rice(e, &a);
@@ -1397,6 +1421,13 @@ int sla_hip_analyze_device(struct SLAEncoder* e, const int32_t* d_pcm, uint64_t 
   e->timing[7] = (float)(now_ms() - t_start);
   if (timing_ms != NULL) { memcpy(timing_ms, e->timing, sizeof(e->timing)); }
   e->analysed = 1;
+  return 0;
+}
+
+int sla_hip_last_kernel_ms(const struct SLAEncoder* e, float* kernel_ms)
+{
+  if (e == NULL || kernel_ms == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  memcpy(kernel_ms, e->kernel_ms, sizeof(e->kernel_ms));
   return 0;
 }
 

@@ -51,6 +51,23 @@ __device__ __forceinline__ double load_f64(const int32_t* __restrict__ pcm, uint
   return (ch == 0) ? ((l + r) / 2) : (l - r);
 }
 
+// execution span of a launch, measured on the device: span[0] = max(~start), span[1] = max(end) in ticks of the
+// constant 100 MHz clock (zero-initialised by the host; NULL = not wanted).  Unlike a pair of stream events this
+// does not include the time a launch waits for resources behind kernels of other streams.  Only the first
+// workgroup reports a start and only the first and the last one an end: workgroups are dispatched in order, the
+// last one out is (within one workgroup's run time) the last one in -- and one atomic per WAVE on one address
+// would serialise a 60k-wave launch.
+__device__ __forceinline__ void span_begin(unsigned long long* span)
+{
+  if (span != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { atomicMax(&span[0], ~(unsigned long long)wall_clock64()); }
+}
+__device__ __forceinline__ void span_end(unsigned long long* span)
+{
+  if (span != nullptr && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && (threadIdx.x & 63) == 0) {
+    atomicMax(&span[1], (unsigned long long)wall_clock64());
+  }
+}
+
 __device__ __forceinline__ uint32_t umax_wave(uint32_t v)
 {
   for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(v, off); v = (o > v) ? o : v; }
@@ -461,10 +478,11 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
                   const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, uint32_t pack,
                   const double* __restrict__ window_pool, double* __restrict__ out,
                   int32_t* __restrict__ out_code, int32_t* __restrict__ out_kint, uint32_t* __restrict__ out_rshift,
-                  uint32_t x_region, uint32_t nch, uint32_t clk)
+                  uint32_t x_region, uint32_t nch, uint32_t clk, unsigned long long* exec_span)
 {
   constexpr uint32_t Q = LB_K / S;              // consecutive terms a producer lane makes per tile
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  span_begin(exec_span);
   const unsigned long long t_start = clk ? clock64() : 0;
   __shared__ sla_hip_lpc_group s_g[LPC_MAX_PACK];
   __shared__ uint32_t s_maxabs[LPC_MAX_PACK];
@@ -654,6 +672,7 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
       out_kint[slot * O1 + lane] = (int32_t)((uint32_t)code << (16u - qb)) >> rshift;
     }
   }
+  span_end(exec_span);
   if (clk && lane == 0) {
     const unsigned long long t_end = clock64();
     if (wv == 0) {
@@ -988,11 +1007,12 @@ __device__ __forceinline__ int32_t lat_term(int32_t k, int32_t v)
 __global__ __launch_bounds__(256)
 void k_lattice(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
                const sla_hip_lattice_chunk* __restrict__ chunks, uint32_t num_chunks,
-               const int32_t* __restrict__ kint, int32_t* __restrict__ residual)
+               const int32_t* __restrict__ kint, int32_t* __restrict__ residual, unsigned long long* span)
 {
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t cid = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (cid >= num_chunks) { return; }
+  span_begin(span);
   const sla_hip_lattice_chunk ck = chunks[cid];
   const uint32_t halo_lanes = (order + LAT_T - 1) / LAT_T;
   // sample index (relative to block) of this lane's first element; negative = before the block
@@ -1038,6 +1058,7 @@ void k_lattice(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, ui
       if (p >= (int64_t)ck.chunk_start && p < (int64_t)ck.chunk_start + ck.count) { dst[p] = f[i]; }
     }
   }
+  span_end(span);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1137,8 +1158,9 @@ template <int ORDER>
 __global__ __launch_bounds__(256)
 void k_tail(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, uint64_t stride,
             const sla_hip_tail_job* __restrict__ jobs, uint32_t num_jobs, uint32_t ntaps,
-            uint64_t* __restrict__ fold_sum)
+            uint64_t* __restrict__ fold_sum, unsigned long long* span)
 {
+  span_begin(span);
   constexpr int G = 2 * ORDER;                 // lanes per job
   constexpr int JPW = 64 / G;                  // jobs per wave
   const uint32_t lane = threadIdx.x & 63;
@@ -1194,6 +1216,7 @@ void k_tail(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, u
     fsum += ((uint64_t)hi << 32) | lo;
   }
   if (have && t == 0) { fold_sum[j] = fsum; }
+  span_end(span);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1337,9 +1360,10 @@ template <bool IN_LDS>
 __global__ __launch_bounds__(ACF_THREADS)
 void k_ltm_acf(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_acf_job* __restrict__ jobs,
                uint32_t njobs, uint32_t log2F, const double* __restrict__ tw, double* __restrict__ scratch,
-               double* __restrict__ out, uint32_t head, uint32_t dbg_skip)
+               double* __restrict__ out, uint32_t head, uint32_t dbg_skip, unsigned long long* span)
 {
   extern __shared__ double2 lds2[];
+  span_begin(span);
   __shared__ double s_acf[ACF_PICK_LAGS];
   __shared__ unsigned long long s_mask[3][ACF_PICK_LAGS / 64];
   const uint32_t F = 1u << log2F, npts = F >> 1, log2npts = log2F - 1;
@@ -1422,11 +1446,18 @@ void k_ltm_acf(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_a
     }
     __syncthreads();
   }
+  span_end(span);
 }
 
 // ---------------------------------------------------------------------------------------------
 // launchers (C-ABI, see include/sla_hip.h)
 // ---------------------------------------------------------------------------------------------
+// The driver may ask for the on-device execution span of its next launch of k_lpc_blocks / k_lattice / k_ltm_acf /
+// k_tail (see span_begin): it names the two-word slot right before the launcher call, on the same host thread.
+static thread_local unsigned long long* t_next_span = nullptr;
+extern "C" void slai_next_launch_span(unsigned long long* d_span) { t_next_span = d_span; }
+static inline unsigned long long* take_span() { unsigned long long* p = t_next_span; t_next_span = nullptr; return p; }
+
 // hipFuncSetAttribute costs a driver call; the limit only ever has to grow (per kernel and device)
 static hipError_t ensure_dynamic_lds(const void* fn, size_t bytes)
 {
@@ -1534,13 +1565,14 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
       hipError_t e = ensure_dynamic_lds(fn, bytes);
       if (e != hipSuccess) { return hip_rc(e); }
       const dim3 grid((num_groups + p - 1) / p), block(LB_THREADS);
+      unsigned long long* span = take_span();
       const uint32_t clk = (uint32_t)(getenv("SLA_HIP_LPC_CLK") != nullptr);
       if (spl == 12) {
         hipLaunchKernelGGL(k_lpc_blocks<12>, grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
-                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk);
+                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span);
       } else {
         hipLaunchKernelGGL(k_lpc_blocks<6>, grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
-                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk);
+                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span);
       }
       if (getenv("SLA_HIP_LPC_CLK") != nullptr) {
         unsigned long long h[8] = {0}, z[8] = {0};
@@ -1647,7 +1679,7 @@ extern "C" int sla_hip_launch_lattice(const int32_t* d_pcm, uint64_t plane_strid
   if (order < 1 || order > 255 || (order + LAT_T - 1) / LAT_T >= 32) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (num_chunks == 0) { return 0; }
   hipLaunchKernelGGL(k_lattice, dim3((num_chunks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_pcm, plane_stride,
-                     mid_side, order, d_chunks, num_chunks, d_kint, d_residual);
+                     mid_side, order, d_chunks, num_chunks, d_kint, d_residual, take_span());
   return hip_rc(hipGetLastError());
 }
 
@@ -1667,11 +1699,12 @@ extern "C" int sla_hip_launch_tail(const int32_t* d_res_in, int32_t* d_res_out, 
   const uint32_t jobs_per_block = 4 * (64 / (2 * lms_order));     // 4 waves, 64/(2*order) jobs per wave
   dim3 grid((num_jobs + jobs_per_block - 1) / (jobs_per_block ? jobs_per_block : 1)), block(256);
   hipStream_t st = (hipStream_t)stream;
+  unsigned long long* span = take_span();
   switch (lms_order) {
-    case 4:  hipLaunchKernelGGL(k_tail<4>,  grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum); break;
-    case 8:  hipLaunchKernelGGL(k_tail<8>,  grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum); break;
-    case 16: hipLaunchKernelGGL(k_tail<16>, grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum); break;
-    case 32: hipLaunchKernelGGL(k_tail<32>, grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum); break;
+    case 4:  hipLaunchKernelGGL(k_tail<4>,  grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span); break;
+    case 8:  hipLaunchKernelGGL(k_tail<8>,  grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span); break;
+    case 16: hipLaunchKernelGGL(k_tail<16>, grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span); break;
+    case 32: hipLaunchKernelGGL(k_tail<32>, grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span); break;
     default: return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY;
   }
   return hip_rc(hipGetLastError());
@@ -1690,16 +1723,17 @@ extern "C" int sla_hip_launch_ltm_acf(const int32_t* d_residual, uint64_t plane_
   hipStream_t st = (hipStream_t)stream;
   const uint32_t dbg = (uint32_t)(getenv("SLA_HIP_ACF_SKIP") ? atoi(getenv("SLA_HIP_ACF_SKIP")) : 0);
   const size_t lds = sizeof(double) * (size_t)fft_size;
+  unsigned long long* span = take_span();
   if (lds <= SLA_HIP_LDS_BUDGET) {
     hipError_t e = ensure_dynamic_lds((const void*)k_ltm_acf<true>, lds);
     if (e != hipSuccess) { return hip_rc(e); }
     hipLaunchKernelGGL(k_ltm_acf<true>, dim3(num_jobs), dim3(ACF_THREADS), lds, st, d_residual, plane_stride, d_jobs, num_jobs,
-                       log2F, d_twiddles, (double*)nullptr, d_acf_head, head, dbg);
+                       log2F, d_twiddles, (double*)nullptr, d_acf_head, head, dbg, span);
   } else {
     if (d_scratch == nullptr || scratch_slots == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
     uint32_t grid = (num_jobs < scratch_slots) ? num_jobs : scratch_slots;
     hipLaunchKernelGGL(k_ltm_acf<false>, dim3(grid), dim3(ACF_THREADS), 0, st, d_residual, plane_stride, d_jobs, num_jobs,
-                       log2F, d_twiddles, d_scratch, d_acf_head, head, dbg);
+                       log2F, d_twiddles, d_scratch, d_acf_head, head, dbg, span);
   }
   return hip_rc(hipGetLastError());
 }
