@@ -7,6 +7,7 @@ fallback, leading-silence frame shifts) and, at BASELINE.json's full sizes, thro
 prefix consistency.  Nothing here reads /root/reference."""
 import ctypes as C
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -490,6 +491,73 @@ def test_search_loud_24bit_takes_the_fallback_where_needed(oracle, hip, monkeypa
     got, t = _encode_with_env(hip, monkeypatch, p, pcm)
     assert got == want
     assert t[11] == 1.0 and t[10] > 0
+
+
+# ------------------------------------------------------------------ seeded random walk over the parameter space
+
+def _fuzz_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    nch = int(rng.choice([1, 1, 2, 2, 3, 6, 8]))
+    bits = int(rng.choice([8, 16, 16, 24, 24]))
+    order = int(rng.choice([1, 2, 5, 8, 16, 24, 32, 48]))
+    ltm = int(rng.choice([1, 3, 5]))
+    lms = int(rng.choice([4, 8, 16, 32]))
+    ms = int(nch == 2 and rng.integers(0, 2))
+    win = int(rng.integers(0, 5))
+    maxb = int(rng.choice([1024, 2048, 3000, 4096, 8192, 12288, 16384]))
+    n = int(rng.choice([1, 63, 700, 2047, 2048, 4097, 9999, 20000, 33333, 50000]))
+    kind = rng.choice(["music", "loud", "quiet", "gaps", "tail_zero", "wave"])
+    if kind == "wave":
+        pcm = W.gen(str(rng.choice(W.NAMES)), nch, n, bits, seed=seed)
+    else:
+        pcm = W.music_like(nch, n, bits, seed=seed, level=1.0 if kind == "loud" else (0.01 if kind == "quiet" else 0.5))
+        if kind == "gaps" and n > 5000:
+            a = int(rng.integers(0, n // 2)); b = a + int(rng.integers(1, n // 2))
+            pcm[:, a:b] = 0
+        if kind == "tail_zero":
+            pcm[:, n - int(rng.integers(1, max(2, min(n, 3000)))):] = 0
+    p = S.make_params(nch, bits, int(rng.choice([44100, 48000, 96000])), parcor=order, ltm=ltm, lms=lms, ms=ms, window=win,
+                      max_block=maxb)
+    return p, np.ascontiguousarray(pcm)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SLA_FUZZ_CASES", "48"))))
+def test_random_parameter_walk(oracle, hip, seed):
+    """random (seeded) combinations of channels, widths, orders, windows, block limits, lengths and content
+    -- silence gaps, silent tails, full-scale and very quiet material -- through every fast path and its fallback"""
+    p, pcm = _fuzz_case(seed)
+    ret = oracle.encode_trace(p, pcm)[0]
+    if ret == 6 and pcm.shape[1] % p.max_block_samples == p.parcor_order:
+        # DESIGN.md section 5: a tail of exactly `order` samples sends the reference into a loop that never ends (the
+        # oracle gives up with FAILED_TO_CALCULATE_COEF); the HIP path terminates -- nothing to compare
+        pytest.skip("reference does not terminate on this input")
+    if ret != 0:
+        # the reference refuses the combination (e.g. max block below the minimum block of the search): same code
+        with pytest.raises(hip.SlaError) as err:
+            hip_encode(hip, p, pcm)
+        assert err.value.code == ret
+        return
+    # bytes, tables and residuals against the oracle; the PCM round trip is the reference's own property and does not hold
+    # for every corner the walk reaches (full-scale mid/side overflows in the reference too)
+    assert_same_as_oracle(oracle, hip, p, pcm, roundtrip=False)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SLA_FUZZ_LONG_CASES", "10"))))
+def test_random_parameter_walk_chunked(oracle, hip, seed):
+    """the same walk on files long enough for the three-chunk pipeline (>= 64 super-frames), with silence in them"""
+    rng = np.random.default_rng(5000 + seed)
+    nch = int(rng.choice([1, 2, 2, 4]))
+    bits = int(rng.choice([16, 16, 24]))
+    order = int(rng.choice([4, 16, 32]))
+    maxb = int(rng.choice([2048, 4096, 8192]))
+    n = int(maxb * rng.integers(70, 130) + rng.integers(0, maxb))
+    pcm = W.music_like(nch, n, bits, seed=seed, level=float(rng.choice([0.02, 0.5, 1.0])))
+    for _ in range(int(rng.integers(0, 4))):
+        a = int(rng.integers(0, n - 1)); b = min(n, a + int(rng.integers(1, 6 * maxb)))
+        pcm[:, a:b] = 0
+    p = S.make_params(nch, bits, 48000, parcor=order, ltm=int(rng.choice([1, 3])), lms=int(rng.choice([8, 16])),
+                      ms=int(nch == 2 and rng.integers(0, 2)), window=int(rng.integers(0, 5)), max_block=maxb)
+    assert_same_as_oracle(oracle, hip, p, np.ascontiguousarray(pcm), roundtrip=False)
 
 
 # ------------------------------------------------------------------ BASELINE sizes: size-independent properties
