@@ -9,12 +9,22 @@
 //
 // Kernel                      replaces (reference file:line)
 //   k_prepass                 src/SLAEncoder.c:425-455 (OR of all words), :392-408 / :520-528 (silence)
-//   k_lpc                     src/SLAPredictor.c:331-388 (autocorrelation, paired-product order),
-//                             :253-328 (Levinson-Durbin), src/SLAEncoder.c:505-515,540-543 (staging),
-//                             src/SLAUtility.c:370-412 (mid/side), src/SLAEncoder.c:567-589 (quantiser)
+//   k_acf_tiles,              src/SLAPredictor.c:1615-1649 (partition search) over :331-388 (autocorrelation): exact
+//   k_search_finish           tile sums where the order of summation provably cannot matter, :253-328 (Levinson-Durbin)
+//   k_lpc                     src/SLAPredictor.c:331-388 in the reference's serial order + :253-328: the rerun of windows
+//                             the tile-sum search flagged, and the original path of every stage (debug switches)
+//   k_plan                    src/SLAPredictor.c:416-468 (code length), :1521-1581 (Dijkstra), :1652-1692 (partition),
+//                             certified against libm's last bits
+//   k_lpc_blocks              src/SLAEncoder.c:505-515,540-543 (staging), src/SLAUtility.c:370-412 (mid/side),
+//                             src/SLAPredictor.c:331-388 (autocorrelation, term tiles), :253-328 (Levinson-Durbin),
+//                             src/SLAEncoder.c:567-589 (quantiser) for the chosen blocks
 //   k_lattice                 src/SLAPredictor.c:1741-1765 (pre-emphasis), :557-607 (PARCOR lattice)
+//   k_ltm_acf                 src/SLAPredictor.c:827-924 (long-term analysis: FFT autocorrelation, pitch candidates),
+//                             src/SLAUtility.c:219-319 (four1 / realft)
 //   k_tail                    src/SLAPredictor.c:1031-1119 (long-term filter), :1202-1331 (sign-log LMS),
 //                             src/SLACoder.c:361-385 (mean of folded residual)
+//   k_rice_len, k_rice_write, src/SLACoder.c:45-83,120-139,165-271,388-467 (Golomb, gamma, recursive Rice, PutDataArray),
+//   k_block_crc               src/SLAEncoder.c:682-798 (block assembly), src/SLAUtility.c:321-339 (CRC16)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <float.h>
