@@ -137,6 +137,15 @@ int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid
                        double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
                        sla_hip_stream_t stream);
 
+/* Chosen blocks in one launch: sla_hip_launch_lpc in its quantiser form (one candidate per group = the whole
+ * block) followed, inside the same workgroups, by the PARCOR lattice of sla_hip_launch_lattice with the
+ * coefficients just quantised -> d_lattice_residual (plane layout of d_pcm). */
+int sla_hip_launch_lpc_blocks(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                              const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                              const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
+                              double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
+                              int32_t* d_lattice_residual, sla_hip_stream_t stream);
+
 /* sla_hip_launch_lpc restricted to the groups that sla_hip_launch_search_exact flagged (NaN in r[0] of the group's
  * first slot): everything else returns at once and keeps its result.  *d_rerun_counter (may be NULL) is
  * incremented by the number of groups that were analysed. */

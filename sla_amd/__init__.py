@@ -129,7 +129,7 @@ EXPORTED_SYMBOLS = [
     "sla_hip_launch_ltm_acf", "sla_hip_launch_rice_len", "sla_hip_launch_rice_write", "sla_hip_pack_device", "sla_hip_launch_unpack16",
     "sla_hip_analyze_device", "sla_hip_pack", "sla_hip_final_residual", "sla_hip_lattice_residual",
     "sla_hip_get_trace", "sla_hip_device_name", "sla_hip_last_timing", "sla_hip_launch_search_exact",
-    "sla_hip_search_exact_lags", "sla_hip_launch_plan", "sla_hip_last_counters", "sla_hip_launch_lpc_rerun", "sla_hip_last_kernel_ms", "sla_hip_bind_residual_planes",
+    "sla_hip_search_exact_lags", "sla_hip_launch_plan", "sla_hip_last_counters", "sla_hip_launch_lpc_rerun", "sla_hip_last_kernel_ms", "sla_hip_launch_lpc_blocks", "sla_hip_bind_residual_planes",
 ]
 
 

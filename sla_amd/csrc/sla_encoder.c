@@ -59,6 +59,7 @@ struct SLAEncoder {
   hipEvent_t  ev[2 + 8 * 16];       /* prepass pair + MAX_CHUNKS x EV_PER_CHUNK */
   uint32_t chunks;
   uint32_t split[8], split_count, chunk_cut[9];   /* relative chunk sizes (SLA_HIP_CHUNK_SPLIT="1,3,1"), boundaries of this run */
+  int      fuse_lattice;            /* 1: the lattice runs inside k_lpc_blocks (SLA_HIP_LATTICE=fused), 0: separate k_lattice launch */
   int      device_plan;             /* 1: code lengths + Dijkstra on the device where certified (default), 0: host only */
   int      search_exact;            /* 1: tile-sum search where it is provably bit-exact (default), 0: chains only */
   int      exact_bits;              /* log2 of the energy limit in units^2 (51; lowered by tests to force the fallback) */
@@ -297,6 +298,13 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
     if (e->split_count > 0) { e->chunks = e->split_count; }
   }
   e->search_exact = 1; e->exact_bits = 51; e->device_plan = 1;
+  /* measured on C2: the lattice inside k_lpc_blocks costs 0.6 ms per step (9 wave-chunks on the 8 waves of a workgroup
+   * that has nothing else left to overlap them with), its own launch 0.27 ms: separate by default */
+  e->fuse_lattice = 0;
+  env = getenv("SLA_HIP_LATTICE");
+  if (env != NULL && strcmp(env, "fused") == 0) { e->fuse_lattice = 1; }
+  env = getenv("SLA_HIP_LPC_BLOCKS");
+  if (env != NULL && strcmp(env, "chains") == 0) { e->fuse_lattice = 0; }
   env = getenv("SLA_HIP_PLAN");
   if (env != NULL && strcmp(env, "host") == 0) { e->device_plan = 0; }
   env = getenv("SLA_HIP_SEARCH");
@@ -1009,6 +1017,7 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
   sla_hip_acf_job* acf_jobs = (sla_hip_acf_job*)e->h_acf_jobs.ptr;
   hipEvent_t* ev = a->ev + (size_t)c * EV_PER_CHUNK;
   uint32_t b, ch, max_window = 1, ng, nl;
+  const int fused = (e->fuse_lattice && order <= 64);
   const size_t slot_lo = (size_t)k->blk_lo * C, nsl = (size_t)(k->blk_hi - k->blk_lo) * C;
 
   k->bg_lo = a->nbg; k->lc_lo = a->nlc;
@@ -1027,7 +1036,7 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
       cands[g].start = 0; cands[g].len = blk->nsmpl;
       acf_jobs[g].blk_off = blk->start; acf_jobs[g].blk_len = blk->nsmpl; acf_jobs[g].channel = ch;
       a->grp_of_slot[(size_t)b * C + ch] = g;
-      for (at = 0; at < blk->nsmpl; at += chunk_samples) {
+      for (at = 0; !fused && at < blk->nsmpl; at += chunk_samples) {
         sla_hip_lattice_chunk* lc;
         if (a->nlc >= a->lchunks_bound) { return SLA_APIRESULT_NG; }
         lc = &lch[a->nlc++];
@@ -1049,7 +1058,7 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     uint32_t slots = 0;
     HIPCHK(hipMemcpyAsync(dg, groups + k->bg_lo, sizeof(sla_hip_lpc_group) * ng, hipMemcpyHostToDevice, e->stream_up));
     HIPCHK(hipMemcpyAsync((sla_hip_lpc_cand*)e->d_bcands.ptr + k->bg_lo, cands + k->bg_lo, sizeof(sla_hip_lpc_cand) * ng, hipMemcpyHostToDevice, e->stream_up));
-    HIPCHK(hipMemcpyAsync(dl, lch + k->lc_lo, sizeof(sla_hip_lattice_chunk) * nl, hipMemcpyHostToDevice, e->stream_up));
+    if (nl > 0) { HIPCHK(hipMemcpyAsync(dl, lch + k->lc_lo, sizeof(sla_hip_lattice_chunk) * nl, hipMemcpyHostToDevice, e->stream_up)); }
     HIPCHK(hipMemcpyAsync(da, acf_jobs + k->bg_lo, sizeof(sla_hip_acf_job) * ng, hipMemcpyHostToDevice, e->stream_up));
     /* (k_lpc_blocks writes every output slot of its groups; slots of silent blocks are never read) */
     /* uploads and result downloads travel on their own streams: the kernel stream runs kernel after kernel */
@@ -1057,10 +1066,17 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     HIPCHK(hipStreamWaitEvent(e->stream2, ev[EV_UPLOADED], 0));
     HIPCHK(hipEventRecord(ev[EV_LPCB_S], e->stream2));
     slai_next_launch_span(SPAN_SLOT(e, c, 0));
-    RCCHK(sla_hip_launch_lpc(e->pcm_dev, e->stride, ms, order, dg, ng, max_window, 1,
-                             (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
-                             (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
-                             (uint32_t*)e->d_rshift.ptr, e->stream2));
+    if (fused) {
+      RCCHK(sla_hip_launch_lpc_blocks(e->pcm_dev, e->stride, ms, order, dg, ng, max_window,
+                                      (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
+                                      (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
+                                      (uint32_t*)e->d_rshift.ptr, RES1(e), e->stream2));
+    } else {
+      RCCHK(sla_hip_launch_lpc(e->pcm_dev, e->stride, ms, order, dg, ng, max_window, 1,
+                               (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
+                               (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
+                               (uint32_t*)e->d_rshift.ptr, e->stream2));
+    }
     HIPCHK(hipEventRecord(ev[EV_LPCB_E], e->stream2));
     /* the LPC results go home while lattice and FFT run: the host decides RAW blocks in the meantime */
     HIPCHK(hipStreamWaitEvent(e->stream_down, ev[EV_LPCB_E], 0));
@@ -1069,8 +1085,10 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     HIPCHK(hipMemcpyAsync((int32_t*)e->h_kint.ptr + slot_lo * O1, (int32_t*)e->d_kint.ptr + slot_lo * O1, sizeof(int32_t) * nsl * O1, hipMemcpyDeviceToHost, e->stream_down));
     HIPCHK(hipMemcpyAsync((uint32_t*)e->h_rshift.ptr + slot_lo, (uint32_t*)e->d_rshift.ptr + slot_lo, sizeof(uint32_t) * nsl, hipMemcpyDeviceToHost, e->stream_down));
     HIPCHK(hipEventRecord(ev[EV_LPC_DOWN], e->stream_down));
-    slai_next_launch_span(SPAN_SLOT(e, c, 1));
-    RCCHK(sla_hip_launch_lattice(e->pcm_dev, e->stride, ms, order, dl, nl, (const int32_t*)e->d_kint.ptr, RES1(e), e->stream2));
+    if (!fused) {
+      slai_next_launch_span(SPAN_SLOT(e, c, 1));
+      RCCHK(sla_hip_launch_lattice(e->pcm_dev, e->stride, ms, order, dl, nl, (const int32_t*)e->d_kint.ptr, RES1(e), e->stream2));
+    }
     HIPCHK(hipEventRecord(ev[EV_LAT_E], e->stream2));
     if (sizeof(double) * (size_t)fft_size > SLA_HIP_LDS_BUDGET) { slots = (ng < 512) ? ng : 512; }
     HIPCHK(hipEventRecord(ev[EV_ACF_S], e->stream2));

@@ -402,6 +402,64 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
   }
 }
 
+#define LAT_T 16
+__device__ __forceinline__ int32_t lat_term(int32_t k, int32_t v)
+{
+  return (int32_t)((uint32_t)k * (uint32_t)v + 16384u) >> 15;
+}
+
+// One wave, `count` output samples of one (block, channel) starting at chunk_start (see k_lattice).  kc[1..order]:
+// the block's lattice coefficients (wave-uniform reads).
+__device__ __forceinline__ void lattice_chunk_wave(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
+                                                   uint64_t blk_off, uint32_t blk_len, uint32_t chunk_start, uint32_t count,
+                                                   uint32_t channel, uint32_t int_shift, const int32_t* __restrict__ kc,
+                                                   int32_t* __restrict__ residual, uint32_t lane)
+{
+  const uint32_t halo_lanes = (order + LAT_T - 1) / LAT_T;
+  // sample index (relative to block) of this lane's first element; negative = before the block
+  const int64_t first = (int64_t)chunk_start + ((int64_t)lane - (int64_t)halo_lanes) * LAT_T;
+  int32_t f[LAT_T], b[LAT_T];
+  // pre-emphasised input: y[n] = x[n] - ((x[n-1]*31)>>5), x[-1] = 0, zero outside the block
+  int32_t prev = 0;
+  {
+    int64_t p = first - 1;
+    if (p >= 0 && p < (int64_t)blk_len) { prev = load_int(pcm, stride, ms, channel, blk_off + p, int_shift); }
+  }
+#pragma unroll
+  for (int i = 0; i < LAT_T; i++) {
+    int64_t p = first + i;
+    int32_t cur = 0;
+    if (p >= 0 && p < (int64_t)blk_len) { cur = load_int(pcm, stride, ms, channel, blk_off + p, int_shift); }
+    int32_t y = (int32_t)((uint32_t)cur - (uint32_t)((int32_t)((uint32_t)prev * 31u) >> 5));
+    f[i] = y; b[i] = y;
+    prev = cur;
+  }
+  for (uint32_t m = 1; m <= order; m++) {
+    const int32_t k = kc[m];                       // wave-uniform -> scalar load
+    int32_t carry = __shfl_up(b[LAT_T - 1], 1);    // b_{m-1} of the sample just before this lane's run
+    if (lane == 0) { carry = 0; }
+#pragma unroll
+    for (int i = LAT_T - 1; i >= 1; i--) {
+      int32_t nf = (int32_t)((uint32_t)f[i] - (uint32_t)lat_term(k, b[i - 1]));
+      int32_t nb = (int32_t)((uint32_t)b[i - 1] - (uint32_t)lat_term(k, f[i]));
+      f[i] = nf; b[i] = nb;
+    }
+    {
+      int32_t nf = (int32_t)((uint32_t)f[0] - (uint32_t)lat_term(k, carry));
+      int32_t nb = (int32_t)((uint32_t)carry - (uint32_t)lat_term(k, f[0]));
+      f[0] = nf; b[0] = nb;
+    }
+  }
+  if (lane >= halo_lanes) {
+    int32_t* dst = residual + (uint64_t)channel * stride + blk_off;
+#pragma unroll
+    for (int i = 0; i < LAT_T; i++) {
+      int64_t p = first + i;
+      if (p >= (int64_t)chunk_start && p < (int64_t)chunk_start + count) { dst[p] = f[i]; }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_lpc_blocks: the chosen blocks (one candidate per group = the whole windowed block).
 //
@@ -488,7 +546,8 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
                   const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, uint32_t pack,
                   const double* __restrict__ window_pool, double* __restrict__ out,
                   int32_t* __restrict__ out_code, int32_t* __restrict__ out_kint, uint32_t* __restrict__ out_rshift,
-                  uint32_t x_region, uint32_t nch, uint32_t clk, unsigned long long* exec_span)
+                  uint32_t x_region, uint32_t nch, uint32_t clk, unsigned long long* exec_span,
+                  int32_t* __restrict__ lat_residual)
 {
   constexpr uint32_t Q = LB_K / S;              // consecutive terms a producer lane makes per tile
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -680,6 +739,24 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
       code = (code > lim - 1) ? (lim - 1) : code;
       out_code[slot * O1 + lane] = code;
       out_kint[slot * O1 + lane] = (int32_t)((uint32_t)code << (16u - qb)) >> rshift;
+    }
+  }
+  // ---- PARCOR lattice of the same blocks (k_lattice's wave-chunks), while their samples are still hot in L2 ----
+  if (lat_residual != nullptr) {
+    __threadfence();                                  // out_kint of this workgroup's slots: visible to its other waves
+    __syncthreads();
+    const uint32_t per = (SLA_WAVE - (order + LAT_T - 1) / LAT_T) * LAT_T;
+    uint32_t first_chunk = 0;
+    for (uint32_t k = 0; k < ng; k++) {
+      const sla_hip_lpc_group g = s_g[k];
+      const uint32_t nchunks = (g.num_samples + per - 1) / per;
+      for (uint32_t cid = wv; cid < first_chunk + nchunks; cid += LB_THREADS / 64) {
+        if (cid < first_chunk) { continue; }
+        const uint32_t at = (cid - first_chunk) * per;
+        lattice_chunk_wave(pcm, stride, ms, order, g.pcm_off, g.num_samples, at, (g.num_samples - at < per) ? (g.num_samples - at) : per,
+                           g.channel, g.int_shift, out_kint + (uint64_t)g.slot_first * O1, lat_residual, lane);
+      }
+      first_chunk += nchunks;
     }
   }
   span_end(exec_span);
@@ -1008,12 +1085,6 @@ void k_plan(const sla_hip_lpc_group* __restrict__ groups, uint32_t num_sf, uint3
 // (the lattice is feed-forward: output n depends on inputs n-order..n only), so chunks are
 // independent and need no LDS and no barrier.
 // ---------------------------------------------------------------------------------------------
-#define LAT_T 16
-__device__ __forceinline__ int32_t lat_term(int32_t k, int32_t v)
-{
-  return (int32_t)((uint32_t)k * (uint32_t)v + 16384u) >> 15;
-}
-
 __global__ __launch_bounds__(256)
 void k_lattice(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
                const sla_hip_lattice_chunk* __restrict__ chunks, uint32_t num_chunks,
@@ -1024,50 +1095,8 @@ void k_lattice(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, ui
   if (cid >= num_chunks) { return; }
   span_begin(span);
   const sla_hip_lattice_chunk ck = chunks[cid];
-  const uint32_t halo_lanes = (order + LAT_T - 1) / LAT_T;
-  // sample index (relative to block) of this lane's first element; negative = before the block
-  const int64_t first = (int64_t)ck.chunk_start + ((int64_t)lane - (int64_t)halo_lanes) * LAT_T;
-  int32_t f[LAT_T], b[LAT_T];
-  // pre-emphasised input: y[n] = x[n] - ((x[n-1]*31)>>5), x[-1] = 0, zero outside the block
-  int32_t prev = 0;
-  {
-    int64_t p = first - 1;
-    if (p >= 0 && p < (int64_t)ck.blk_len) { prev = load_int(pcm, stride, ms, ck.channel, ck.blk_off + p, ck.int_shift); }
-  }
-#pragma unroll
-  for (int i = 0; i < LAT_T; i++) {
-    int64_t p = first + i;
-    int32_t cur = 0;
-    if (p >= 0 && p < (int64_t)ck.blk_len) { cur = load_int(pcm, stride, ms, ck.channel, ck.blk_off + p, ck.int_shift); }
-    int32_t y = (int32_t)((uint32_t)cur - (uint32_t)((int32_t)((uint32_t)prev * 31u) >> 5));
-    f[i] = y; b[i] = y;
-    prev = cur;
-  }
-  const int32_t* kc = kint + (uint64_t)ck.slot * (order + 1);
-  for (uint32_t m = 1; m <= order; m++) {
-    const int32_t k = kc[m];                       // wave-uniform -> scalar load
-    int32_t carry = __shfl_up(b[LAT_T - 1], 1);    // b_{m-1} of the sample just before this lane's run
-    if (lane == 0) { carry = 0; }
-#pragma unroll
-    for (int i = LAT_T - 1; i >= 1; i--) {
-      int32_t nf = (int32_t)((uint32_t)f[i] - (uint32_t)lat_term(k, b[i - 1]));
-      int32_t nb = (int32_t)((uint32_t)b[i - 1] - (uint32_t)lat_term(k, f[i]));
-      f[i] = nf; b[i] = nb;
-    }
-    {
-      int32_t nf = (int32_t)((uint32_t)f[0] - (uint32_t)lat_term(k, carry));
-      int32_t nb = (int32_t)((uint32_t)carry - (uint32_t)lat_term(k, f[0]));
-      f[0] = nf; b[0] = nb;
-    }
-  }
-  if (lane >= halo_lanes) {
-    int32_t* dst = residual + (uint64_t)ck.channel * stride + ck.blk_off;
-#pragma unroll
-    for (int i = 0; i < LAT_T; i++) {
-      int64_t p = first + i;
-      if (p >= (int64_t)ck.chunk_start && p < (int64_t)ck.chunk_start + ck.count) { dst[p] = f[i]; }
-    }
-  }
+  lattice_chunk_wave(pcm, stride, ms, order, ck.blk_off, ck.blk_len, ck.chunk_start, ck.count, ck.channel, ck.int_shift,
+                     kint + (uint64_t)ck.slot * (order + 1), residual, lane);
   span_end(span);
 }
 
@@ -1520,7 +1549,7 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
                            uint32_t max_cands_per_group,
                            const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
                            double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
-                           sla_hip_stream_t stream, uint32_t mode_flags, uint32_t* d_rerun_counter);
+                           sla_hip_stream_t stream, uint32_t mode_flags, uint32_t* d_rerun_counter, int32_t* d_lat_residual);
 
 extern "C" int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
                                   const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
@@ -1530,7 +1559,18 @@ extern "C" int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, u
                                   sla_hip_stream_t stream)
 {
   return launch_lpc_impl(d_pcm, plane_stride, mid_side, order, d_groups, num_groups, max_window, max_cands_per_group, d_cands,
-                         d_window_pool, d_out, d_code, d_kint, d_rshift, stream, 0u, nullptr);
+                         d_window_pool, d_out, d_code, d_kint, d_rshift, stream, 0u, nullptr, nullptr);
+}
+
+extern "C" int sla_hip_launch_lpc_blocks(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                                         const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                                         const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
+                                         double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
+                                         int32_t* d_lattice_residual, sla_hip_stream_t stream)
+{
+  if (d_code == nullptr || d_lattice_residual == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  return launch_lpc_impl(d_pcm, plane_stride, mid_side, order, d_groups, num_groups, max_window, 1, d_cands,
+                         d_window_pool, d_out, d_code, d_kint, d_rshift, stream, 0u, nullptr, d_lattice_residual);
 }
 
 extern "C" int sla_hip_launch_lpc_rerun(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
@@ -1539,7 +1579,7 @@ extern "C" int sla_hip_launch_lpc_rerun(const int32_t* d_pcm, uint64_t plane_str
                                         double* d_out, uint32_t* d_rerun_counter, sla_hip_stream_t stream)
 {
   return launch_lpc_impl(d_pcm, plane_stride, mid_side, order, d_groups, num_groups, max_window, max_cands_per_group, d_cands,
-                         nullptr, d_out, nullptr, nullptr, nullptr, stream, 128u, d_rerun_counter);
+                         nullptr, d_out, nullptr, nullptr, nullptr, stream, 128u, d_rerun_counter, nullptr);
 }
 
 static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
@@ -1547,7 +1587,7 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
                            uint32_t max_cands_per_group,
                            const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
                            double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
-                           sla_hip_stream_t stream, uint32_t mode_flags, uint32_t* d_rerun_counter)
+                           sla_hip_stream_t stream, uint32_t mode_flags, uint32_t* d_rerun_counter, int32_t* d_lat_residual)
 {
   if (d_pcm == nullptr || d_groups == nullptr || d_cands == nullptr || d_out == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (order < 1 || order > 255 || max_window == 0 || max_cands_per_group == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
@@ -1579,10 +1619,10 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
       const uint32_t clk = (uint32_t)(getenv("SLA_HIP_LPC_CLK") != nullptr);
       if (spl == 12) {
         hipLaunchKernelGGL(k_lpc_blocks<12>, grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
-                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span);
+                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span, d_lat_residual);
       } else {
         hipLaunchKernelGGL(k_lpc_blocks<6>, grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
-                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span);
+                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span, d_lat_residual);
       }
       if (getenv("SLA_HIP_LPC_CLK") != nullptr) {
         unsigned long long h[8] = {0}, z[8] = {0};
@@ -1600,6 +1640,7 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
     }
     return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY;
   }
+  if (d_lat_residual != nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }      /* only k_lpc_blocks carries the lattice */
   // windows per workgroup: as many as the LDS budget takes, at most what fills the three chain waves
   size_t x_region = (size_t)max_window;
   const size_t per_group_r = (size_t)max_cands_per_group * (order + 1);

@@ -478,6 +478,17 @@ def test_plan_paths_agree(oracle, hip, monkeypatch, nch, bits, ms, maxb):
     assert ta[13] <= 2          # music: practically every super-frame certifies
 
 
+@pytest.mark.parametrize("nch,bits,order,maxb", [(1, 16, 16, 4096), (2, 24, 32, 8192), (3, 16, 48, 16384), (2, 8, 5, 2048)])
+def test_lattice_fused_into_the_block_kernel(oracle, hip, monkeypatch, nch, bits, order, maxb):
+    """SLA_HIP_LATTICE=fused: sla_hip_launch_lpc_blocks runs the PARCOR lattice inside k_lpc_blocks"""
+    pcm = W.music_like(nch, 90000, bits, seed=order)
+    p = S.make_params(nch, bits, 48000, parcor=order, ltm=3, lms=8, ms=int(nch == 2), max_block=maxb)
+    ret, want, _ = oracle.encode_trace(p, pcm)
+    assert ret == 0
+    got, _ = _encode_with_env(hip, monkeypatch, p, pcm, SLA_HIP_LATTICE="fused")
+    assert got == want
+
+
 def test_search_loud_24bit_takes_the_fallback_where_needed(oracle, hip, monkeypatch):
     """full-scale 24-bit noise has > 2^51 units^2 per window: flagged groups rerun as serial chains"""
     rng = np.random.default_rng(5)
