@@ -298,6 +298,31 @@ def test_encoder_handle_is_reusable(oracle, hip):
     enc.close()
 
 
+def test_distinct_handles_on_distinct_threads(oracle, hip):
+    """handles are not re-entrant, but distinct handles may run on distinct host threads"""
+    import threading
+    cases = [(1, 16, 16, 4096, 120000), (2, 24, 32, 8192, 90000), (2, 16, 8, 2048, 70000), (4, 16, 16, 4096, 60000)]
+    want, pcms, bad = [], [], []
+    for i, (nch, bits, order, mb, n) in enumerate(cases):
+        pcm = W.music_like(nch, n, bits, seed=40 + i)
+        p = S.make_params(nch, bits, 48000, parcor=order, ltm=3, lms=8, ms=int(nch == 2), max_block=mb)
+        ret, data, _ = oracle.encode_trace(p, pcm)
+        assert ret == 0
+        want.append(data); pcms.append((p, pcm))
+
+    def work(i):
+        p, pcm = pcms[i]
+        for _ in range(6):
+            if hip_encode(hip, p, pcm, want_residuals=False)[0] != want[i]:
+                bad.append(i)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(cases))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not bad
+
+
 # ------------------------------------------------------------------ kernel launchers (C-ABI, torch = device memory)
 
 def test_lattice_launcher_wraps_like_int32(oracle, hip):
