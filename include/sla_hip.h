@@ -187,6 +187,29 @@ int sla_hip_launch_plan(const sla_hip_lpc_group* d_groups, uint32_t num_superfra
                         const double* d_lpc_out, uint32_t* d_parts, uint32_t* d_num_parts, uint32_t* d_status,
                         sla_hip_stream_t stream);
 
+/* Building blocks of the per-call predictor API (include/SLAPredictor.h), also usable on their own:
+ *   sla_hip_launch_lpc_f64      sla_hip_launch_lpc in its search form on samples that already are doubles
+ *                               (group.pcm_off indexes d_samples; no conversion, window or pre-emphasis)
+ *   sla_hip_launch_lattice_raw  sla_hip_launch_lattice on samples that already are the lattice input (no shift,
+ *                               no mid/side, no pre-emphasis)
+ *   sla_hip_launch_tail_stages  sla_hip_launch_tail with the LMS stage optional (job.pitch = 0 switches the
+ *                               long-term stage off as always); d_fold_sum still receives the zig-zag sums
+ *   sla_hip_launch_emphasis_*   pre-emphasis as a pass of its own, out[n] = in[n] - ((in[n-1] * (2^s - 1)) >> s) */
+int sla_hip_launch_lpc_f64(const double* d_samples, uint32_t order,
+                           const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                           uint32_t max_cands_per_group, const sla_hip_lpc_cand* d_cands,
+                           double* d_out, sla_hip_stream_t stream);
+int sla_hip_launch_lattice_raw(const int32_t* d_samples, uint64_t plane_stride, uint32_t order,
+                               const sla_hip_lattice_chunk* d_chunks, uint32_t num_chunks,
+                               const int32_t* d_kint, int32_t* d_residual, sla_hip_stream_t stream);
+int sla_hip_launch_tail_stages(const int32_t* d_res_in, int32_t* d_res_out, uint64_t plane_stride,
+                               const sla_hip_tail_job* d_jobs, uint32_t num_jobs, uint32_t longterm_order,
+                               uint32_t lms_order, uint32_t skip_lms, uint64_t* d_fold_sum, sla_hip_stream_t stream);
+int sla_hip_launch_emphasis_i32(const int32_t* d_in, int32_t* d_out, uint32_t num_samples, int32_t previous,
+                                uint32_t coef_shift, sla_hip_stream_t stream);
+int sla_hip_launch_emphasis_f64(const double* d_in, double* d_out, uint32_t num_samples, uint32_t coef_shift,
+                                sla_hip_stream_t stream);
+
 /* Integer pre-emphasis + PARCOR lattice; one wave per chunk. */
 int sla_hip_launch_lattice(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
                            const sla_hip_lattice_chunk* d_chunks, uint32_t num_chunks,

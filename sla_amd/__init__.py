@@ -129,7 +129,20 @@ EXPORTED_SYMBOLS = [
     "sla_hip_launch_ltm_acf", "sla_hip_launch_rice_len", "sla_hip_launch_rice_write", "sla_hip_pack_device", "sla_hip_launch_unpack16",
     "sla_hip_analyze_device", "sla_hip_pack", "sla_hip_final_residual", "sla_hip_lattice_residual",
     "sla_hip_get_trace", "sla_hip_device_name", "sla_hip_last_timing", "sla_hip_launch_search_exact",
-    "sla_hip_search_exact_lags", "sla_hip_launch_plan", "sla_hip_last_counters", "sla_hip_launch_lpc_rerun", "sla_hip_last_kernel_ms", "sla_hip_launch_lpc_blocks", "sla_hip_bind_residual_planes",
+    "sla_hip_search_exact_lags", "sla_hip_launch_plan", "sla_hip_last_counters", "sla_hip_launch_lpc_rerun", "sla_hip_last_kernel_ms", "sla_hip_launch_lpc_blocks",
+    "sla_hip_launch_lpc_f64", "sla_hip_launch_lattice_raw", "sla_hip_launch_tail_stages", "sla_hip_launch_emphasis_i32",
+    "sla_hip_launch_emphasis_f64",
+    # include/SLAPredictor.h, include/SLACoder.h (per-call API of the reference, encode side)
+    "SLALPCCalculator_Create", "SLALPCCalculator_Destroy", "SLALPCCalculator_CalculatePARCORCoefDouble",
+    "SLALPCCalculator_EstimateCodeLength", "SLALPCSynthesizer_Create", "SLALPCSynthesizer_Destroy", "SLALPCSynthesizer_Reset",
+    "SLALPCSynthesizer_PredictByParcorCoefInt32", "SLALongTermCalculator_Create", "SLALongTermCalculator_Destroy",
+    "SLALongTermCalculator_CalculateCoef", "SLALongTermSynthesizer_Create", "SLALongTermSynthesizer_Destroy",
+    "SLALongTermSynthesizer_Reset", "SLALongTermSynthesizer_PredictInt32", "SLALMSFilter_Create", "SLALMSFilter_Destroy",
+    "SLALMSFilter_Reset", "SLALMSFilter_PredictInt32", "SLAOptimalEncodeEstimator_Create", "SLAOptimalEncodeEstimator_Destroy",
+    "SLAOptimalEncodeEstimator_SearchOptimalBlockPartitions", "SLAOptimalEncodeEstimator_CalculateMaxNumPartitions",
+    "SLAEmphasisFilter_Create", "SLAEmphasisFilter_Reset", "SLAEmphasisFilter_Destroy", "SLAEmphasisFilter_PreEmphasisInt32",
+    "SLAEmphasisFilter_PreEmphasisDouble", "SLACoder_Create", "SLACoder_Destroy",
+    "SLACoder_CalculateInitialRecursiveRiceParameter", "sla_hip_coder_initial_parameter", "sla_hip_bind_residual_planes",
 ]
 
 

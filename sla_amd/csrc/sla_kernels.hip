@@ -317,7 +317,9 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
     const double* win = window_pool + (windowed ? g.win_off : 0);
     uint32_t maxabs = 0;
     for (uint32_t s = threadIdx.x; s < g.num_samples; s += blockDim.x) {
-      double cur = load_f64(pcm, stride, ms, g.channel, g.pcm_off + s);
+      // mode bit 512 (per-call SLAPredictor API): `pcm` is an array of doubles the caller has already prepared
+      double cur = (dbg_skip & 512u) ? reinterpret_cast<const double*>(pcm)[g.pcm_off + s]
+                                     : load_f64(pcm, stride, ms, g.channel, g.pcm_off + s);
       if (windowed) {
         cur *= win[s];
         double prev = (s > 0) ? load_f64(pcm, stride, ms, g.channel, g.pcm_off + s - 1) * win[s - 1] : 0.0;
@@ -413,7 +415,7 @@ __device__ __forceinline__ int32_t lat_term(int32_t k, int32_t v)
 __device__ __forceinline__ void lattice_chunk_wave(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
                                                    uint64_t blk_off, uint32_t blk_len, uint32_t chunk_start, uint32_t count,
                                                    uint32_t channel, uint32_t int_shift, const int32_t* __restrict__ kc,
-                                                   int32_t* __restrict__ residual, uint32_t lane)
+                                                   int32_t* __restrict__ residual, uint32_t lane, bool raw = false)
 {
   const uint32_t halo_lanes = (order + LAT_T - 1) / LAT_T;
   // sample index (relative to block) of this lane's first element; negative = before the block
@@ -430,7 +432,8 @@ __device__ __forceinline__ void lattice_chunk_wave(const int32_t* __restrict__ p
     int64_t p = first + i;
     int32_t cur = 0;
     if (p >= 0 && p < (int64_t)blk_len) { cur = load_int(pcm, stride, ms, channel, blk_off + p, int_shift); }
-    int32_t y = (int32_t)((uint32_t)cur - (uint32_t)((int32_t)((uint32_t)prev * 31u) >> 5));
+    // raw: the caller's samples are the lattice input as they are (per-call SLALPCSynthesizer API)
+    int32_t y = raw ? cur : (int32_t)((uint32_t)cur - (uint32_t)((int32_t)((uint32_t)prev * 31u) >> 5));
     f[i] = y; b[i] = y;
     prev = cur;
   }
@@ -1088,7 +1091,7 @@ void k_plan(const sla_hip_lpc_group* __restrict__ groups, uint32_t num_sf, uint3
 __global__ __launch_bounds__(256)
 void k_lattice(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
                const sla_hip_lattice_chunk* __restrict__ chunks, uint32_t num_chunks,
-               const int32_t* __restrict__ kint, int32_t* __restrict__ residual, unsigned long long* span)
+               const int32_t* __restrict__ kint, int32_t* __restrict__ residual, unsigned long long* span, uint32_t raw)
 {
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t cid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1096,8 +1099,32 @@ void k_lattice(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, ui
   span_begin(span);
   const sla_hip_lattice_chunk ck = chunks[cid];
   lattice_chunk_wave(pcm, stride, ms, order, ck.blk_off, ck.blk_len, ck.chunk_start, ck.count, ck.channel, ck.int_shift,
-                     kint + (uint64_t)ck.slot * (order + 1), residual, lane);
+                     kint + (uint64_t)ck.slot * (order + 1), residual, lane, raw != 0);
   span_end(span);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pre-emphasis as its own pass (per-call SLAEmphasisFilter API; the pipeline fuses it into k_lpc_blocks / k_lattice):
+// y[n] = x[n] - ((x[n-1] * (2^s - 1)) >> s) with x[-1] = prev      src/SLAPredictor.c:1741-1765, 1794-1813
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_emphasis_i32(const int32_t* __restrict__ in, int32_t* __restrict__ out, uint32_t n, int32_t prev, uint32_t shift)
+{
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) { return; }
+  const int32_t p = (i == 0) ? prev : in[i - 1];
+  const int32_t coef = (int32_t)((1u << shift) - 1u);
+  out[i] = (int32_t)((uint32_t)in[i] - (uint32_t)((int32_t)((uint32_t)p * (uint32_t)coef) >> shift));
+}
+
+__global__ __launch_bounds__(256)
+void k_emphasis_f64(const double* __restrict__ in, double* __restrict__ out, uint32_t n, uint32_t shift)
+{
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) { return; }
+  const double coef = (ldexp(1.0, (int)shift) - 1.0) * ldexp(1.0, -(int)shift);
+  const double p = (i == 0) ? 0.0 : in[i - 1];
+  out[i] = in[i] - p * coef;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1197,7 +1224,7 @@ template <int ORDER>
 __global__ __launch_bounds__(256)
 void k_tail(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, uint64_t stride,
             const sla_hip_tail_job* __restrict__ jobs, uint32_t num_jobs, uint32_t ntaps,
-            uint64_t* __restrict__ fold_sum, unsigned long long* span)
+            uint64_t* __restrict__ fold_sum, unsigned long long* span, uint32_t stage_flags)
 {
   span_begin(span);
   constexpr int G = 2 * ORDER;                 // lanes per job
@@ -1240,7 +1267,7 @@ void k_tail(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, u
     v_next = fetch(s0 + G + t);                      // next block's samples travel while this one computes
     int32_t e_mine = (s0 == 0) ? tail_block<ORDER, true>(v_mine, grp_base, is_fir_head, is_iir_head, t, coef, h)
                                : tail_block<ORDER, false>(v_mine, grp_base, is_fir_head, is_iir_head, t, coef, h);
-    e_mine = short_job ? v_mine : e_mine;
+    e_mine = (short_job || (stage_flags & 1u)) ? v_mine : e_mine;      // stage_flags bit 0: no LMS stage (per-call API)
     const uint32_t s = s0 + t;
     if (s < n) {
       out[s] = e_mine;
@@ -1730,7 +1757,7 @@ extern "C" int sla_hip_launch_lattice(const int32_t* d_pcm, uint64_t plane_strid
   if (order < 1 || order > 255 || (order + LAT_T - 1) / LAT_T >= 32) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (num_chunks == 0) { return 0; }
   hipLaunchKernelGGL(k_lattice, dim3((num_chunks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_pcm, plane_stride,
-                     mid_side, order, d_chunks, num_chunks, d_kint, d_residual, take_span());
+                     mid_side, order, d_chunks, num_chunks, d_kint, d_residual, take_span(), 0u);
   return hip_rc(hipGetLastError());
 }
 
@@ -1739,9 +1766,67 @@ extern "C" uint32_t sla_hip_lattice_chunk_samples(uint32_t order)
   return (SLA_WAVE - (order + LAT_T - 1) / LAT_T) * LAT_T;
 }
 
+extern "C" int sla_hip_launch_lattice_raw(const int32_t* d_samples, uint64_t plane_stride, uint32_t order,
+                                          const sla_hip_lattice_chunk* d_chunks, uint32_t num_chunks,
+                                          const int32_t* d_kint, int32_t* d_residual, sla_hip_stream_t stream)
+{
+  if (d_samples == nullptr || d_chunks == nullptr || d_kint == nullptr || d_residual == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (order < 1 || order > 255 || (order + LAT_T - 1) / LAT_T >= 32) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (num_chunks == 0) { return 0; }
+  hipLaunchKernelGGL(k_lattice, dim3((num_chunks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_samples, plane_stride,
+                     0u, order, d_chunks, num_chunks, d_kint, d_residual, take_span(), 1u);
+  return hip_rc(hipGetLastError());
+}
+
+extern "C" int sla_hip_launch_lpc_f64(const double* d_samples, uint32_t order,
+                                      const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                                      uint32_t max_cands_per_group, const sla_hip_lpc_cand* d_cands,
+                                      double* d_out, sla_hip_stream_t stream)
+{
+  return launch_lpc_impl(reinterpret_cast<const int32_t*>(d_samples), 0, 0, order, d_groups, num_groups, max_window, max_cands_per_group,
+                         d_cands, nullptr, d_out, nullptr, nullptr, nullptr, stream, 512u, nullptr, nullptr);
+}
+
+extern "C" int sla_hip_launch_emphasis_i32(const int32_t* d_in, int32_t* d_out, uint32_t num_samples, int32_t previous,
+                                           uint32_t coef_shift, sla_hip_stream_t stream)
+{
+  if (d_in == nullptr || d_out == nullptr || coef_shift == 0 || coef_shift > 30) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (num_samples == 0) { return 0; }
+  hipLaunchKernelGGL(k_emphasis_i32, dim3((num_samples + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_in, d_out, num_samples, previous, coef_shift);
+  return hip_rc(hipGetLastError());
+}
+
+extern "C" int sla_hip_launch_emphasis_f64(const double* d_in, double* d_out, uint32_t num_samples, uint32_t coef_shift,
+                                           sla_hip_stream_t stream)
+{
+  if (d_in == nullptr || d_out == nullptr || coef_shift == 0 || coef_shift > 30) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (num_samples == 0) { return 0; }
+  hipLaunchKernelGGL(k_emphasis_f64, dim3((num_samples + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_in, d_out, num_samples, coef_shift);
+  return hip_rc(hipGetLastError());
+}
+
+static int launch_tail_impl(const int32_t* d_res_in, int32_t* d_res_out, uint64_t plane_stride,
+                            const sla_hip_tail_job* d_jobs, uint32_t num_jobs, uint32_t longterm_order,
+                            uint32_t lms_order, uint64_t* d_fold_sum, sla_hip_stream_t stream, uint32_t stage_flags);
+
 extern "C" int sla_hip_launch_tail(const int32_t* d_res_in, int32_t* d_res_out, uint64_t plane_stride,
                                    const sla_hip_tail_job* d_jobs, uint32_t num_jobs, uint32_t longterm_order,
                                    uint32_t lms_order, uint64_t* d_fold_sum, sla_hip_stream_t stream)
+{
+  return launch_tail_impl(d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, lms_order, d_fold_sum, stream, 0u);
+}
+
+extern "C" int sla_hip_launch_tail_stages(const int32_t* d_res_in, int32_t* d_res_out, uint64_t plane_stride,
+                                          const sla_hip_tail_job* d_jobs, uint32_t num_jobs, uint32_t longterm_order,
+                                          uint32_t lms_order, uint32_t skip_lms, uint64_t* d_fold_sum, sla_hip_stream_t stream)
+{
+  return launch_tail_impl(d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, lms_order, d_fold_sum, stream,
+                          skip_lms ? 1u : 0u);
+}
+
+static int launch_tail_impl(const int32_t* d_res_in, int32_t* d_res_out, uint64_t plane_stride,
+                            const sla_hip_tail_job* d_jobs, uint32_t num_jobs, uint32_t longterm_order,
+                            uint32_t lms_order, uint64_t* d_fold_sum, sla_hip_stream_t stream, uint32_t stage_flags)
 {
   if (d_res_in == nullptr || d_res_out == nullptr || d_jobs == nullptr || d_fold_sum == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (longterm_order > 5 || !(longterm_order & 1)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
@@ -1752,10 +1837,10 @@ extern "C" int sla_hip_launch_tail(const int32_t* d_res_in, int32_t* d_res_out, 
   hipStream_t st = (hipStream_t)stream;
   unsigned long long* span = take_span();
   switch (lms_order) {
-    case 4:  hipLaunchKernelGGL(k_tail<4>,  grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span); break;
-    case 8:  hipLaunchKernelGGL(k_tail<8>,  grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span); break;
-    case 16: hipLaunchKernelGGL(k_tail<16>, grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span); break;
-    case 32: hipLaunchKernelGGL(k_tail<32>, grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span); break;
+    case 4:  hipLaunchKernelGGL(k_tail<4>,  grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
+    case 8:  hipLaunchKernelGGL(k_tail<8>,  grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
+    case 16: hipLaunchKernelGGL(k_tail<16>, grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
+    case 32: hipLaunchKernelGGL(k_tail<32>, grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
     default: return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY;
   }
   return hip_rc(hipGetLastError());
