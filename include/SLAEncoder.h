@@ -21,39 +21,64 @@
 
 #define SLA_ENCODER_VERSION_STRING   "0.0.1(beta)"
 
-struct SLAEncoder;
+struct SLAEncoder;                     /* opaque: device workspace, streams, host tables */
 
+/* Capacity of a handle (layout = reference src/include/public/SLAEncoder.h:14-21). */
 struct SLAEncoderConfig {
-  uint32_t max_num_channels;
-  uint32_t max_num_block_samples;
-  uint32_t max_parcor_order;
-  uint32_t max_longterm_order;
-  uint32_t max_lms_order_per_filter;
-  uint8_t  verpose_flag;               /* (sic) */
+  uint32_t max_num_channels;           /* 1..8 planes                                                   */
+  uint32_t max_num_block_samples;      /* <= 16384 here: the analysis window lives in LDS               */
+  uint32_t max_parcor_order;           /* PARCOR coefficients per channel                               */
+  uint32_t max_longterm_order;         /* long-term taps, 1 / 3 / 5                                     */
+  uint32_t max_lms_order_per_filter;   /* LMS coefficients per cascade stage                            */
+  uint8_t  verpose_flag;               /* (sic) unused by the encoder                                   */
 };
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-/* replaces reference src/SLAEncoder.c:56-128 */
-struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config);
-/* replaces reference src/SLAEncoder.c:131-173 */
-void SLAEncoder_Destroy(struct SLAEncoder* encoder);
-/* replaces reference src/SLAEncoder.c:176-197 */
-SLAApiResult SLAEncoder_SetWaveFormat(struct SLAEncoder* encoder, const struct SLAWaveFormat* wave_format);
-/* replaces reference src/SLAEncoder.c:200-224 */
-SLAApiResult SLAEncoder_SetEncodeParameter(struct SLAEncoder* encoder, const struct SLAEncodeParameter* encode_param);
-/* replaces reference src/SLAEncoder.c:227-292 */
-SLAApiResult SLAEncoder_EncodeHeader(const struct SLAHeaderInfo* header, uint8_t* data, uint32_t data_size);
-/* replaces reference src/SLAEncoder.c:458-801 (one block; host PCM in, bytes out) */
-SLAApiResult SLAEncoder_EncodeBlock(struct SLAEncoder* encoder,
-    const int32_t* const* input, uint32_t num_samples,
-    uint8_t* data, uint32_t data_size, uint32_t* output_size);
-/* replaces reference src/SLAEncoder.c:804-932 (header + every block of a file) */
-SLAApiResult SLAEncoder_EncodeWhole(struct SLAEncoder* encoder,
-    const int32_t* const* input, uint32_t num_samples,
-    uint8_t* data, uint32_t data_size, uint32_t* output_size);
+/* Life cycle.  Create: reference src/SLAEncoder.c:56-128 (here it also brings up the HIP device: streams,
+ * events, twiddle tables, the host thread pool).  Destroy: :131-173. */
+struct SLAEncoder*
+SLAEncoder_Create(const struct SLAEncoderConfig* config);
+
+void
+SLAEncoder_Destroy(struct SLAEncoder* encoder);
+
+/* Stream format and coding parameters; both must be set before any encode call.
+ * reference src/SLAEncoder.c:176-197 and :200-224 */
+SLAApiResult
+SLAEncoder_SetWaveFormat(struct SLAEncoder*          encoder,
+                         const struct SLAWaveFormat* wave_format);
+
+SLAApiResult
+SLAEncoder_SetEncodeParameter(struct SLAEncoder*               encoder,
+                              const struct SLAEncodeParameter* encode_param);
+
+/* The 43-byte file header, host only.  reference src/SLAEncoder.c:227-292 */
+SLAApiResult
+SLAEncoder_EncodeHeader(const struct SLAHeaderInfo* header,
+                        uint8_t*                    data,
+                        uint32_t                    data_size);
+
+/* Everything of a file in one call -- header, partition search, every block: the batched device pipeline.
+ * input[ch][n]: planar PCM, left-justified in 32 bits.  reference src/SLAEncoder.c:804-932 */
+SLAApiResult
+SLAEncoder_EncodeWhole(struct SLAEncoder*    encoder,
+                       const int32_t* const* input,
+                       uint32_t              num_samples,
+                       uint8_t*              data,
+                       uint32_t              data_size,
+                       uint32_t*             output_size);
+
+/* One block (host PCM in, block bytes out; a PCIe round trip per call).  reference src/SLAEncoder.c:458-801 */
+SLAApiResult
+SLAEncoder_EncodeBlock(struct SLAEncoder*    encoder,
+                       const int32_t* const* input,
+                       uint32_t              num_samples,
+                       uint8_t*              data,
+                       uint32_t              data_size,
+                       uint32_t*             output_size);
 
 #ifdef __cplusplus
 }
