@@ -252,6 +252,61 @@ int sla_hip_launch_rice_write(const int32_t* d_residual, const int32_t* d_pcm, u
  * SLAEncoder_EncodeWhole to halve the PCIe bytes of <= 16-bit input. */
 int sla_hip_launch_unpack16(const int16_t* d_in, int32_t* d_out, uint64_t count, sla_hip_stream_t stream);
 
+/* ---- decode side (kernels in sla_decode.hip, driver: SLADecoder.h) -----------------
+ * The stream image is the .sla file's bytes in device memory (hipMalloc alignment, viewed as 32-bit words).
+ * The host walks the block chain (sync code, size field, sample count: 10 bytes per block) into a table of
+ * sla_hip_dec_block; everything behind those fields is parsed on the device.  All stages work in place on
+ * one set of channel planes [C][plane_stride] int32:
+ *   dec_bits    : block header fields + entropy decode (src/SLADecoder.c:355-412, 440-481; src/SLACoder.c:84-163,
+ *                 272-318, 406-427, 469-506) -> right-justified residual / raw samples / zeros; per block
+ *                 sla_hip_dec_info, per (block, channel) sla_hip_dec_chan and the PARCOR coefficients
+ *                 d_kint[(block * C + ch) * (order + 1) + m]; with want_crc also the CRC16 of every block
+ *   dec_lms     : SLALMSFilter_SynthesizeInt32              src/SLAPredictor.c:1334-1463
+ *   dec_ltm     : SLALongTermSynthesizer_SynthesizeInt32    src/SLAPredictor.c:1034-1119
+ *   dec_lattice : SLALPCSynthesizer_SynthesizeByParcorCoefInt32 src/SLAPredictor.c:610-740
+ *                 + SLAEmphasisFilter_DeEmphasisInt32       src/SLAPredictor.c:1768-1791
+ *   dec_finish  : SLAUtility_MStoLRInt32 src/SLAUtility.c:415-433 + left-justification src/SLADecoder.c:540-547
+ * The synthesis kernels skip blocks whose decoded type is not "compressed". */
+#define SLA_HIP_DEC_HEADER_ONLY 1u       /* sla_hip_dec_block.flags: parse the header (and CRC), decode no samples */
+typedef struct sla_hip_dec_block {
+  uint64_t byte_off;        /* offset of the block's sync code in the image */
+  uint32_t byte_len;        /* size field + 6, clipped to the end of the stream (CRC16 covers [8, byte_len)) */
+  uint32_t smp_off;         /* first sample of the block in the planes */
+  uint32_t num_samples;     /* samples per channel, from the block header */
+  uint32_t flags;
+} sla_hip_dec_block;
+typedef struct sla_hip_dec_info {
+  uint32_t type;            /* 0 compressed, 1 silent, 2 raw, 3 not a block type */
+  uint32_t used_bytes;      /* bytes from the sync code to the byte-aligned end of what the reader consumed */
+  uint32_t crc;             /* CRC16-IBM of [8, byte_len) when requested */
+  uint32_t overrun;         /* 1: the reader ran off the end of the stream */
+} sla_hip_dec_info;
+typedef struct sla_hip_dec_chan {
+  uint32_t pitch;           /* 0: no long-term stage */
+  int32_t  ltm_coef[5];     /* Q31 */
+  uint32_t rice_init;
+  uint32_t reserved;
+} sla_hip_dec_chan;
+int sla_hip_launch_dec_bits(const uint32_t* d_image, uint64_t image_bytes,
+                            const sla_hip_dec_block* d_blocks, uint32_t num_blocks,
+                            uint32_t num_channels, uint32_t bits_per_sample, uint32_t offset_lshift,
+                            uint32_t mid_side, uint32_t parcor_order, uint32_t longterm_order,
+                            uint32_t want_crc, int32_t* d_planes, uint64_t plane_stride,
+                            sla_hip_dec_info* d_info, sla_hip_dec_chan* d_chan, int32_t* d_kint,
+                            sla_hip_stream_t stream);
+int sla_hip_launch_dec_lms(int32_t* d_planes, uint64_t plane_stride, const sla_hip_dec_block* d_blocks,
+                           const sla_hip_dec_info* d_info, uint32_t num_blocks, uint32_t num_channels,
+                           uint32_t lms_order, sla_hip_stream_t stream);
+int sla_hip_launch_dec_ltm(int32_t* d_planes, uint64_t plane_stride, const sla_hip_dec_block* d_blocks,
+                           const sla_hip_dec_info* d_info, const sla_hip_dec_chan* d_chan,
+                           uint32_t num_blocks, uint32_t num_channels, uint32_t longterm_order,
+                           uint32_t max_block_samples, sla_hip_stream_t stream);
+int sla_hip_launch_dec_lattice(int32_t* d_planes, uint64_t plane_stride, const sla_hip_dec_block* d_blocks,
+                               const sla_hip_dec_info* d_info, uint32_t num_blocks, uint32_t num_channels,
+                               const int32_t* d_kint, uint32_t parcor_order, sla_hip_stream_t stream);
+int sla_hip_launch_dec_finish(int32_t* d_planes, uint64_t plane_stride, uint32_t num_channels,
+                              uint32_t num_samples, uint32_t mid_side, uint32_t shift, sla_hip_stream_t stream);
+
 /* ---- (2) whole-file driver ---------------------------------------------- */
 
 /* Per-block results of the last analyze call, copied into caller arrays

@@ -4,7 +4,8 @@ The product is the C-ABI shared library ``sla_amd/libsla_hip.so`` (hand-written 
 plain-C host, see include/*.h).  This package is only the thin ctypes face used by the tests,
 bench.py and __graft_entry__: it mirrors the reference's encoder interface
 (SLAEncoder_Create / SetWaveFormat / SetEncodeParameter / EncodeWhole / EncodeBlock, reference
-src/include/public/SLAEncoder.h:28-53) one to one.
+src/include/public/SLAEncoder.h:28-53) and decoder interface (SLADecoder_Create / DecodeHeader /
+DecodeWhole, src/include/public/SLADecoder.h:38-60) one to one.
 
 There is no CPU fallback: loading fails loudly when the library has not been built, and
 ``Encoder()`` raises when no HIP device is usable.
@@ -38,6 +39,13 @@ class SLAEncoderConfig(C.Structure):
     _fields_ = [("max_num_channels", C.c_uint32), ("max_num_block_samples", C.c_uint32),
                 ("max_parcor_order", C.c_uint32), ("max_longterm_order", C.c_uint32),
                 ("max_lms_order_per_filter", C.c_uint32), ("verpose_flag", C.c_uint8)]
+
+
+class SLADecoderConfig(C.Structure):
+    _fields_ = [("max_num_channels", C.c_uint32), ("max_num_block_samples", C.c_uint32),
+                ("max_parcor_order", C.c_uint32), ("max_longterm_order", C.c_uint32),
+                ("max_lms_order_per_filter", C.c_uint32), ("enable_crc_check", C.c_uint8),
+                ("verpose_flag", C.c_uint8)]
 
 
 class SLAWaveFormat(C.Structure):
@@ -116,6 +124,16 @@ def lib():
         L.sla_hip_last_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.sla_hip_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.sla_hip_search_exact_lags.restype = C.c_uint32
+        L.SLADecoder_Create.restype = C.c_void_p
+        L.SLADecoder_Create.argtypes = [C.POINTER(SLADecoderConfig)]
+        L.SLADecoder_Destroy.argtypes = [C.c_void_p]
+        L.SLADecoder_Destroy.restype = None
+        L.SLADecoder_DecodeHeader.argtypes = [u8p, C.c_uint32, C.POINTER(SLAHeaderInfo)]
+        L.SLADecoder_SetWaveFormat.argtypes = [C.c_void_p, C.POINTER(SLAWaveFormat)]
+        L.SLADecoder_SetEncodeParameter.argtypes = [C.c_void_p, C.POINTER(SLAEncodeParameter)]
+        L.SLADecoder_DecodeWhole.argtypes = [C.c_void_p, u8p, C.c_uint32, C.POINTER(i32p), C.c_uint32, u32p]
+        L.sla_hip_decoder_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.sla_hip_decode_device.argtypes = [C.c_void_p, u8p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, u32p]
         _lib = L
     return _lib
 
@@ -143,6 +161,11 @@ EXPORTED_SYMBOLS = [
     "SLAEmphasisFilter_Create", "SLAEmphasisFilter_Reset", "SLAEmphasisFilter_Destroy", "SLAEmphasisFilter_PreEmphasisInt32",
     "SLAEmphasisFilter_PreEmphasisDouble", "SLACoder_Create", "SLACoder_Destroy",
     "SLACoder_CalculateInitialRecursiveRiceParameter", "sla_hip_coder_initial_parameter", "sla_hip_bind_residual_planes",
+    # include/SLADecoder.h + the decode-side launchers of include/sla_hip.h
+    "SLADecoder_DecodeHeader", "SLADecoder_Create", "SLADecoder_Destroy", "SLADecoder_SetWaveFormat",
+    "SLADecoder_SetEncodeParameter", "SLADecoder_DecodeWhole", "sla_hip_decoder_last_timing", "sla_hip_decode_device",
+    "sla_hip_launch_dec_bits", "sla_hip_launch_dec_lms", "sla_hip_launch_dec_ltm", "sla_hip_launch_dec_lattice",
+    "sla_hip_launch_dec_finish",
 ]
 
 
@@ -309,6 +332,64 @@ class Encoder:
     def final_residual_ptr(self):
         stride = C.c_uint64(0)
         return self._lib.sla_hip_final_residual(self._h, C.byref(stride)), stride.value
+
+
+class Decoder:
+    """Python face of ``struct SLADecoder`` (reference src/include/public/SLADecoder.h)."""
+
+    def __init__(self, max_num_channels=8, max_num_block_samples=16384, max_parcor_order=48,
+                 max_longterm_order=5, max_lms_order_per_filter=32, enable_crc_check=1):
+        self._lib = lib()
+        cfg = SLADecoderConfig(max_num_channels, max_num_block_samples, max_parcor_order,
+                               max_longterm_order, max_lms_order_per_filter, enable_crc_check, 0)
+        self._h = self._lib.SLADecoder_Create(C.byref(cfg))
+        if not self._h:
+            raise RuntimeError("SLADecoder_Create failed: no usable HIP device or unsupported capacity "
+                               "(libsla_hip has no CPU fallback)")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.SLADecoder_Destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def decode_whole(self, data, capacity, num_channels=None):
+        """.sla bytes -> (result code, planar left-justified int32 [C][n]); like the reference, samples of the
+        blocks before a failing one are returned together with the error code"""
+        buf = np.frombuffer(bytes(data), np.uint8)
+        nch = num_channels if num_channels is not None else (int(buf[14]) if len(buf) > 14 else 1)
+        out = np.zeros((max(nch, 1), max(capacity, 1)), np.int32)
+        ptrs = (i32p * out.shape[0])(*[out[c].ctypes.data_as(i32p) for c in range(out.shape[0])])
+        n = C.c_uint32(0)
+        rc = self._lib.SLADecoder_DecodeWhole(self._h, buf.ctypes.data_as(u8p), len(buf), ptrs, capacity, C.byref(n))
+        return rc, out[:, :n.value]
+
+    def decode_device(self, data, image_ptr, planes_ptr, plane_stride):
+        """decode an image that already lives in device memory into device planes; returns (rc, samples)"""
+        buf = np.frombuffer(bytes(data), np.uint8) if not isinstance(data, np.ndarray) else data
+        n = C.c_uint32(0)
+        rc = self._lib.sla_hip_decode_device(self._h, buf.ctypes.data_as(u8p), C.c_void_p(image_ptr), len(buf),
+                                             C.c_void_p(planes_ptr), plane_stride, C.byref(n))
+        return rc, n.value
+
+    def last_timing(self):
+        """[ms] upload, block walk, kernels (stream events), download, total; number of kernel batches"""
+        t = (C.c_float * 6)()
+        self._lib.sla_hip_decoder_last_timing(self._h, t)
+        return list(t)
+
+
+def decode_header(data):
+    """(result code, SLAHeaderInfo) of the first 43 bytes"""
+    buf = np.frombuffer(bytes(data), np.uint8)
+    h = SLAHeaderInfo()
+    rc = lib().SLADecoder_DecodeHeader(buf.ctypes.data_as(u8p), len(buf), C.byref(h))
+    return rc, h
 
 
 def encode_header(num_channels, bits, rate, lshift, parcor, ltm, lms, chproc, window, max_block,

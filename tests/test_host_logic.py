@@ -30,7 +30,7 @@ def ptr(a, t):
 
 def test_library_exports_every_declared_symbol(L):
     declared = set()
-    for hdr in ("SLAEncoder.h", "sla_hip.h", "SLAPredictor.h", "SLACoder.h"):
+    for hdr in ("SLAEncoder.h", "sla_hip.h", "SLAPredictor.h", "SLACoder.h", "SLADecoder.h"):
         text = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", hdr)).read(), flags=re.S)     # prototypes only, not prose
         declared |= set(re.findall(r"\b(SLA[A-Z][A-Za-z]*_\w+|sla_hip_\w+)\s*\(", text))
     assert declared == set(sla_amd.EXPORTED_SYMBOLS)
