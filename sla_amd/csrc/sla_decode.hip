@@ -46,43 +46,50 @@ __device__ __forceinline__ uint32_t umax_wave(uint32_t v)
 }
 
 // ---------------------------------------------------------------------------------------------
-// MSB-first bit reader over the stream image (the file's bytes, viewed as 32-bit words).  A lane keeps up
-// to 64 unread bits in a register pair and always has the following word in flight, so the serial decode
-// never waits for memory.  Bytes past the end of the stream read as zero; a run of zeros that goes on past
-// the end (only corrupt input does that) kills the reader: every later read returns 0 at once.
+// MSB-first bit reader over the stream image (the file's bytes, viewed as 32-bit words).  Stateless apart
+// from a bit position: a read is "the 32 bits at the position", assembled from two neighbouring words of
+// the lane's row of an LDS window (one ds_read2 + a funnel shift), which the wave refills cooperatively
+// (coalesced 256-byte loads, byte-swapped once) at every tile boundary.  No 64-bit shift register, no refill
+// branches on the serial decode chain.  Words beyond the window (a tile that costs more than 64 bits per
+// sample on average) come straight from memory.  Bytes past the end of the stream read as zero; a run of
+// zeros that goes on past the end (only corrupt input does that) kills the reader: every later read returns 0.
 // ---------------------------------------------------------------------------------------------
 struct bit_reader {
   const uint32_t* img;
+  const uint32_t* win;   // this lane's window row in LDS: words [base, base + win_words) of the image, MSB-first
   uint64_t words;        // words of the image that exist
-  uint64_t w;            // next word to request
-  uint64_t buf;          // unread bits, the first one at bit 63; everything below `have` is zero
-  uint64_t pos;          // absolute bit position of the first unread bit
-  uint64_t limit;        // give up beyond this bit position
-  uint32_t have;         // 32..64 between calls
-  uint32_t next;         // word w-1, already byte-swapped
+  uint64_t base;         // word index of the window start
+  uint64_t limit;        // give up beyond this absolute bit position
+  uint32_t rp;           // bit offset of the first unread bit from the window start
+  uint32_t win_words;
   bool dead;
 
-  __device__ __forceinline__ uint32_t fetch(uint64_t i) const { return (i < words) ? __builtin_bswap32(img[i]) : 0u; }
-  __device__ __forceinline__ void refill()
+  __device__ __forceinline__ uint64_t pos() const { return base * 32 + rp; }
+  __device__ __forceinline__ uint32_t far_word(uint32_t idx) const
   {
-    if (have <= 32) { buf |= (uint64_t)next << (32 - have); have += 32; next = fetch(w); w++; }
+    const uint64_t i = base + idx;
+    return (i < words) ? __builtin_bswap32(img[i]) : 0u;
   }
-  __device__ __forceinline__ void open(const uint32_t* image, uint64_t image_bytes, uint64_t byte_off)
+  // the 32 bits at the read position
+  __device__ __forceinline__ uint32_t peek() const
   {
-    img = image; words = (image_bytes + 3) >> 2; limit = image_bytes * 8 + 64; dead = false;
-    const uint64_t w0 = byte_off >> 2;
-    const uint32_t skip = 8u * (uint32_t)(byte_off & 3);
-    buf = ((uint64_t)fetch(w0) << 32) << skip; have = 32 - skip; pos = byte_off * 8;
-    next = fetch(w0 + 1); w = w0 + 2;
-    refill();
+    const uint32_t idx = rp >> 5, sh = rp & 31;
+    uint32_t hi, lo;
+    if (idx + 1 < win_words) { hi = win[idx]; lo = win[idx + 1]; }
+    else { hi = far_word(idx); lo = far_word(idx + 1); }
+    return sh ? ((hi << sh) | (lo >> (32 - sh))) : hi;
+  }
+  __device__ __forceinline__ void open(const uint32_t* image, uint64_t image_bytes, uint64_t byte_off, const uint32_t* window)
+  {
+    img = image; win = window; words = (image_bytes + 3) >> 2; limit = image_bytes * 8 + 64; dead = false;
+    base = byte_off >> 2; rp = 8u * (uint32_t)(byte_off & 3); win_words = 0;
   }
   // n = 0..32 bits as an unsigned number
   __device__ __forceinline__ uint32_t get(uint32_t n)
   {
     if (n == 0 || dead) { return 0; }
-    const uint32_t v = (uint32_t)(buf >> (64 - n));
-    buf <<= n; have -= n; pos += n;
-    refill();
+    const uint32_t v = peek() >> (32 - n);
+    rp += n;
     return v;
   }
   // any width: the low 32 bits of the number (reference reads up to 64 bits and the callers truncate)
@@ -96,19 +103,36 @@ struct bit_reader {
   {
     uint32_t run = 0;
     if (dead) { return 0; }
-    while (buf == 0) {
-      run += have; pos += have; have = 0;
-      if (pos > limit) { dead = true; return run; }
-      refill(); refill();
+    for (;;) {
+      const uint32_t v = peek();
+      if (v != 0) {
+        const uint32_t z = (uint32_t)__clz((int)v);
+        rp += z + 1;
+        return run + z;
+      }
+      run += 32; rp += 32;
+      if (pos() > limit) { dead = true; return run; }
     }
-    const uint32_t z = (uint32_t)__clzll((long long)buf);
-    const uint32_t c = z + 1;
-    buf = (c >= 64) ? 0 : (buf << c); have -= c; pos += c;
-    refill();
-    return run + z;
   }
-  __device__ __forceinline__ void align() { (void)get((8u - (uint32_t)(pos & 7)) & 7u); }
+  __device__ __forceinline__ void align() { rp = (rp + 7u) & ~7u; }
 };
+
+// the wave moves every owner lane's window to its read position and loads the words from there on
+__device__ __forceinline__ void fill_windows(bit_reader& rd, uint32_t* s_win, uint32_t row_words, uint32_t win_words,
+                                             uint32_t owners, uint32_t lane)
+{
+  __syncthreads();
+  rd.base += rd.rp >> 5; rd.rp &= 31;
+  for (uint32_t o = 0; o < owners; o++) {
+    const uint64_t base = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(rd.base >> 32), (int)o) << 32) | (uint32_t)__shfl((int)(uint32_t)rd.base, (int)o);
+    for (uint32_t k = lane; k < win_words; k += 64) {
+      const uint64_t i = base + k;
+      s_win[o * row_words + k] = (i < rd.words) ? __builtin_bswap32(rd.img[i]) : 0u;
+    }
+  }
+  rd.win_words = (lane < owners) ? win_words : 0u;
+  __syncthreads();
+}
 
 __device__ __forceinline__ uint32_t gamma_get(bit_reader& rd)                  // src/SLACoder.c:140-163
 {
@@ -154,7 +178,7 @@ void k_dec_crc(const uint8_t* __restrict__ bytes, const sla_hip_dec_block* __res
 // flag / pitch / taps, initial Rice parameter) and then the body, whose codewords are interleaved
 // (sample-major, channel-minor) and whose two Rice parameters per channel adapt with every sample: a
 // strictly serial walk, parallel only across blocks.  `lanes` < 64 spreads the blocks over more waves
-// (fewer lanes per wave = less divergence, more SIMDs and memory pipes in use).
+// (fewer lanes per wave = less divergence, more SIMDs and memory pipes in use); lanes * channels <= 64.
 // Output: folded-back residuals (or raw samples / zeros) in the channel planes, right-justified.
 // ---------------------------------------------------------------------------------------------
 struct dec_bits_args {
@@ -165,23 +189,40 @@ struct dec_bits_args {
   sla_hip_dec_info* info; sla_hip_dec_chan* chan; int32_t* kint;
 };
 
+#define DEC_TILE 64          // samples per channel a lane decodes between two flushes
+#define DEC_ROW  (DEC_TILE + 1)
+#define DEC_WIN  128         // words of stream per channel a lane finds in LDS per tile (64 bits per sample)
+
 template <int C>
 __global__ __launch_bounds__(64)
 void k_dec_bits(const dec_bits_args a)
 {
-  if (threadIdx.x >= a.lanes) { return; }
-  const uint32_t j = blockIdx.x * a.lanes + threadIdx.x;
-  if (j >= a.num_blocks) { return; }
-  const sla_hip_dec_block b = a.blocks[j];
+  // [lanes * C] rows of DEC_TILE samples, one word of padding per row: a lane writes its rows sample by sample
+  // (all lanes at the same column -> different banks), the flush reads them row-wise and stores 256 B at a time.
+  // Direct 4-byte stores from the decode loop would sit in the same counter as the reader's prefetch and make
+  // every refill wait for them.
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+  constexpr uint32_t WIN = DEC_WIN * C, WROW = WIN + 1;      // one word of padding: the lanes' rows start in different banks
+  int32_t* s_tile = (int32_t*)s_dyn;                         // [lanes * C][DEC_ROW]
+  uint32_t* s_win = s_dyn + a.lanes * C * DEC_ROW;           // [lanes][WROW]
+  const uint32_t lane = threadIdx.x;
+  const uint32_t j = blockIdx.x * a.lanes + lane;
+  const bool mine = (lane < a.lanes) && (j < a.num_blocks);
+  sla_hip_dec_block b;
+  b.byte_off = 0; b.byte_len = 0; b.smp_off = 0; b.num_samples = 0; b.flags = 0;
+  if (mine) { b = a.blocks[j]; }
   bit_reader rd;
-  rd.open(a.image, a.image_bytes, b.byte_off);
+  rd.open(a.image, a.image_bytes, b.byte_off, s_win + (mine ? lane : 0u) * WROW);
+  fill_windows(rd, s_win, WROW, WIN, a.lanes, lane);       // helper lanes have no row of their own: they only carry words
   (void)rd.get(16);                                        // sync code          src/SLADecoder.c:330-334
   (void)rd.get(32);                                        // size field         (the host walked these)
   (void)rd.get(16);                                        // CRC16
   (void)rd.get(16);                                        // samples per channel
-  const uint32_t type = rd.get(2);
+  const uint32_t type = mine ? rd.get(2) : 1u;
   uint32_t init[C];
-  if (type == 0) {
+#pragma unroll
+  for (uint32_t c = 0; c < (uint32_t)C; c++) { init[c] = 0; }
+  if (mine && type == 0) {
 #pragma unroll
     for (uint32_t c = 0; c < (uint32_t)C; c++) {
       const uint32_t rsh = rd.get(4);
@@ -210,51 +251,68 @@ void k_dec_bits(const dec_bits_args a)
   }
   rd.align();
 
-  const uint32_t n = (b.flags & SLA_HIP_DEC_HEADER_ONLY) ? 0u : b.num_samples;
-  int32_t* out = a.planes + b.smp_off;
-  if (type == 1) {
-    for (uint32_t s = 0; s < n; s++) { for (uint32_t c = 0; c < (uint32_t)C; c++) { out[(uint64_t)c * a.stride + s] = 0; } }
-  } else if (type == 2) {
-    for (uint32_t s = 0; s < n && !rd.dead; s++) {
+  const uint32_t n = (!mine || (b.flags & SLA_HIP_DEC_HEADER_ONLY)) ? 0u : b.num_samples;
+  uint64_t p0[C], p1[C];
+  uint32_t gm[C];
+  uint64_t avg = 0;
 #pragma unroll
-      for (uint32_t c = 0; c < (uint32_t)C; c++) {
-        const uint32_t nb = a.bps - a.lshift + ((c == 1 && a.mid_side) ? 1u : 0u);
-        out[(uint64_t)c * a.stride + s] = unfold_i32(rd.get_wide(nb));
+  for (uint32_t c = 0; c < (uint32_t)C; c++) {
+    p0[c] = p1[c] = (uint64_t)(uint32_t)(init[c] << 8);                        // SLACODER_PARAMETER_SET
+    uint32_t g = (uint32_t)((p0[c] + 128u) >> 8);
+    gm[c] = g ? g : 1u;
+    avg += gm[c];
+  }
+  avg /= (uint32_t)C;
+  const bool adaptive = (avg > 8);                                               // SLACODER_LOW_THRESHOULD_PARAMETER
+  int32_t* row = s_tile + lane * C * DEC_ROW;
+  const uint32_t nmax = umax_wave(n);
+
+  for (uint32_t s0 = 0; s0 < nmax; s0 += DEC_TILE) {
+    const uint32_t cnt = (s0 < n) ? ((n - s0 < DEC_TILE) ? (n - s0) : (uint32_t)DEC_TILE) : 0u;
+    fill_windows(rd, s_win, WROW, WIN, a.lanes, lane);
+    if (type == 1) {
+      for (uint32_t u = 0; u < cnt; u++) {
+#pragma unroll
+        for (uint32_t c = 0; c < (uint32_t)C; c++) { row[c * DEC_ROW + u] = 0; }
       }
-    }
-  } else if (type == 0) {
-    uint64_t p0[C], p1[C];
-    uint32_t gm[C];
-    uint64_t avg = 0;
+    } else if (type == 2) {
+      for (uint32_t u = 0; u < cnt; u++) {
 #pragma unroll
-    for (uint32_t c = 0; c < (uint32_t)C; c++) {
-      p0[c] = p1[c] = (uint64_t)(uint32_t)(init[c] << 8);                      // SLACODER_PARAMETER_SET
-      uint32_t g = (uint32_t)((p0[c] + 128u) >> 8);
-      gm[c] = g ? g : 1u;
-      avg += gm[c];
-    }
-    avg /= (uint32_t)C;
-    if (avg > 8) {                                                               // SLACODER_LOW_THRESHOULD_PARAMETER
-      for (uint32_t s = 0; s < n && !rd.dead; s++) {
+        for (uint32_t c = 0; c < (uint32_t)C; c++) {
+          const uint32_t nb = a.bps - a.lshift + ((c == 1 && a.mid_side) ? 1u : 0u);
+          row[c * DEC_ROW + u] = unfold_i32(rd.get_wide(nb));
+        }
+      }
+    } else if (type == 0 && adaptive) {
+      for (uint32_t u = 0; u < cnt; u++) {
 #pragma unroll
         for (uint32_t c = 0; c < (uint32_t)C; c++) {
           const uint32_t k0 = rice_k(p0[c]), k1 = rice_k(p1[c]);
-          uint32_t q = rd.zero_run(), val;
-          if (q == 0) {
-            val = rd.get(k0);
-            p0[c] = rice_adapt(p0[c], val);
+          const uint32_t m0 = 1u << k0;
+          const uint32_t v = rd.peek();
+          uint32_t q = (uint32_t)__clz((int)v);                      // 32 when v == 0
+          const uint32_t k = q ? k1 : k0;
+          uint32_t val;
+          if (q < 16u && q + 1u + k <= 32u && !rd.dead) {
+            // the whole codeword (unary part, stop bit, k remainder bits) lies inside the 32 bits just read
+            const uint32_t rest = k ? ((v << (q + 1u)) >> (32u - k)) : 0u;
+            rd.rp += q + 1u + k;
+            val = q ? (m0 + ((q - 1u) << k1) + rest) : rest;
           } else {
-            if (q == 16) { q += gamma_get(rd); }
-            const uint32_t m0 = 1u << k0;
-            val = m0 + ((q - 1u) << k1) + rd.get(k1);
-            p0[c] = rice_adapt(p0[c], val);
-            p1[c] = rice_adapt(p1[c], val - m0);
+            q = rd.zero_run();
+            if (q == 0) { val = rd.get(k0); }
+            else {
+              if (q == 16) { q += gamma_get(rd); }
+              val = m0 + ((q - 1u) << k1) + rd.get(k1);
+            }
           }
-          out[(uint64_t)c * a.stride + s] = unfold_i32(val);
+          p0[c] = rice_adapt(p0[c], val);
+          if (q != 0) { p1[c] = rice_adapt(p1[c], val - m0); }
+          row[c * DEC_ROW + u] = unfold_i32(val);
         }
       }
-    } else {
-      for (uint32_t s = 0; s < n && !rd.dead; s++) {
+    } else if (type == 0) {
+      for (uint32_t u = 0; u < cnt; u++) {
 #pragma unroll
         for (uint32_t c = 0; c < (uint32_t)C; c++) {
           const uint32_t m = gm[c];
@@ -268,16 +326,27 @@ void k_dec_bits(const dec_bits_args a)
             if (rest < cut) { val = q * m + rest; }
             else { rest = (rest << 1) + rd.get(1); val = q * m + rest - cut; }
           }
-          out[(uint64_t)c * a.stride + s] = unfold_i32(val);
+          row[c * DEC_ROW + u] = unfold_i32(val);
         }
       }
     }
+    __syncthreads();
+    // flush: row r = (owner lane, channel); the 64 lanes store its 64 samples side by side
+    for (uint32_t r = 0; r < a.lanes * (uint32_t)C; r++) {
+      const uint32_t owner = r / (uint32_t)C, c = r - owner * (uint32_t)C;
+      const uint32_t on = (uint32_t)__shfl((int)n, (int)owner), ooff = (uint32_t)__shfl((int)b.smp_off, (int)owner);
+      const uint32_t s = s0 + lane;
+      if (s < on) { a.planes[(uint64_t)c * a.stride + ooff + s] = s_tile[r * DEC_ROW + lane]; }
+    }
+    __syncthreads();
   }
   rd.align();
-  sla_hip_dec_info* io = a.info + j;
-  io->type = type;
-  io->used_bytes = (uint32_t)((rd.pos >> 3) - b.byte_off);
-  io->overrun = (rd.dead || (rd.pos >> 3) > a.image_bytes) ? 1u : 0u;
+  if (mine) {
+    sla_hip_dec_info* io = a.info + j;
+    io->type = type;
+    io->used_bytes = (uint32_t)((rd.pos() >> 3) - b.byte_off);
+    io->overrun = (rd.dead || (rd.pos() >> 3) > a.image_bytes) ? 1u : 0u;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -464,6 +533,9 @@ void k_dec_lattice(int32_t* __restrict__ planes, uint64_t stride, const sla_hip_
                    const int32_t* __restrict__ kint, uint32_t order)
 {
   constexpr int JPW = 64 / G;
+  // the output lane parks its 16 samples here; the group then stores them side by side (a 4-byte store per
+  // sample would share a counter with the prefetch of the next inputs and stall it)
+  __shared__ int32_t s_out[(256 / G) * 16];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t t = lane & (G - 1);
   const uint32_t grp_base = lane - t;
@@ -476,6 +548,7 @@ void k_dec_lattice(int32_t* __restrict__ planes, uint64_t stride, const sla_hip_
   const bool active = have && info[bi].type == 0 && !(b.flags & SLA_HIP_DEC_HEADER_ONLY);
   const uint32_t n = active ? b.num_samples : 0;
   int32_t* io = planes + (uint64_t)ch * stride + b.smp_off;
+  int32_t* park = s_out + (threadIdx.x / G) * 16;
   const bool is_last = (t == (uint32_t)(G - 1));
   const uint32_t nmax = umax_wave(n);
 
@@ -520,9 +593,14 @@ void k_dec_lattice(int32_t* __restrict__ planes, uint64_t stride, const sla_hip_
         // de-emphasis on the output lane: y[n] = x[n] + ((y[n-1] * 31) >> 5)     src/SLAPredictor.c:1781-1786
         const int32_t y = (int32_t)((uint32_t)f[R - 1] + (uint32_t)((int32_t)((uint32_t)yprev * 31u) >> 5));
         yprev = y;
-        const uint32_t s = s0 + (uint32_t)(u0 + u);
-        if (is_last && s < n) { io[s] = y; }
+        if (is_last) { park[u] = y; }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      {
+        const uint32_t s = s0 + (uint32_t)u0 + (t & 15u);
+        if (t < 16u && s < n) { io[s] = park[t & 15u]; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   }
 }
@@ -579,19 +657,20 @@ extern "C" int sla_hip_launch_dec_bits(const uint32_t* d_image, uint64_t image_b
   // enough waves for every SIMD of the chip before a wave takes a second block
   uint32_t lanes = (num_blocks + 1023) / 1024;
   if (lanes < 1) { lanes = 1; }
-  if (lanes > 64) { lanes = 64; }
+  if (lanes > 64 / num_channels) { lanes = 64 / num_channels; }     // lanes * channels rows of LDS staging
   a.lanes = lanes;
   a.planes = d_planes; a.stride = plane_stride; a.info = d_info; a.chan = d_chan; a.kint = d_kint;
   const dim3 grid((num_blocks + lanes - 1) / lanes), block(64);
+  const size_t lds = sizeof(uint32_t) * ((size_t)lanes * num_channels * DEC_ROW + (size_t)lanes * (DEC_WIN * num_channels + 1));
   switch (num_channels) {
-    case 1: hipLaunchKernelGGL(k_dec_bits<1>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(k_dec_bits<2>, grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL(k_dec_bits<3>, grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL(k_dec_bits<4>, grid, block, 0, st, a); break;
-    case 5: hipLaunchKernelGGL(k_dec_bits<5>, grid, block, 0, st, a); break;
-    case 6: hipLaunchKernelGGL(k_dec_bits<6>, grid, block, 0, st, a); break;
-    case 7: hipLaunchKernelGGL(k_dec_bits<7>, grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL(k_dec_bits<8>, grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL(k_dec_bits<1>, grid, block, lds, st, a); break;
+    case 2: hipLaunchKernelGGL(k_dec_bits<2>, grid, block, lds, st, a); break;
+    case 3: hipLaunchKernelGGL(k_dec_bits<3>, grid, block, lds, st, a); break;
+    case 4: hipLaunchKernelGGL(k_dec_bits<4>, grid, block, lds, st, a); break;
+    case 5: hipLaunchKernelGGL(k_dec_bits<5>, grid, block, lds, st, a); break;
+    case 6: hipLaunchKernelGGL(k_dec_bits<6>, grid, block, lds, st, a); break;
+    case 7: hipLaunchKernelGGL(k_dec_bits<7>, grid, block, lds, st, a); break;
+    default: hipLaunchKernelGGL(k_dec_bits<8>, grid, block, lds, st, a); break;
   }
   return hip_rc(hipGetLastError());
 }
