@@ -231,6 +231,23 @@ def main():
             out["end_to_end"] = {"msamples_s": round(m * nch / e2e / 1e6, 3), "samples": m * nch,
                                  "sla_bytes": len(data), "note": "SLAEncoder_EncodeWhole: pageable host PCM -> .sla bytes incl. PCIe both ways and the device bit-pack"}
             enc2.close()
+            # ---- and back: SLADecoder_DecodeWhole of those bytes must return the input (round trip at full size)
+            if lms in (4, 8, 16, 32) and maxb <= 16384:
+                dec = sla_amd.Decoder(nch, maxb, order, ltm, lms)
+                stream = bytes(data)
+                rc, back = dec.decode_whole(stream, m)
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    rc, back = dec.decode_whole(stream, m)
+                d2e = (time.perf_counter() - t1) / reps
+                tm = dec.last_timing()
+                out["decode"] = {"msamples_s": round(m * nch / d2e / 1e6, 3),
+                                 "kernels_msamples_s": round(m * nch / (tm[2] * 1e3), 3) if tm[2] > 0 else None,
+                                 "round_trip_identical": bool(rc == 0 and np.array_equal(back, sub)),
+                                 "note": "SLADecoder_DecodeWhole of the bytes above: .sla in host memory -> planar PCM in host "
+                                         "memory incl. PCIe both ways; kernels = CRC16, entropy decode, LMS / long-term / "
+                                         "lattice synthesis, de-emphasis between stream events"}
+                dec.close()
 
         # ---- CPU baseline on this box's host cores, same workload, bounded sample -------------------
         if not args.no_cpu_baseline and world == 1:

@@ -79,6 +79,38 @@ def test_header_bytes(L, oracle):
     assert L.SLAEncoder_EncodeHeader(C.byref(h), ptr(small, u8p), 8) == 4
 
 
+def test_decode_header_host_side(L, oracle):
+    """SLADecoder_DecodeHeader is host-only: every field of a header written by the oracle comes back, a damaged
+    header is reported but still delivered, wrong magic / version / size are refused (src/SLADecoder.c:171-251)"""
+    pcm = W.music_like(2, 5000, 24, seed=3)
+    p = S.make_params(2, 24, 96000, 32, 3, 16, 1, 1, 8192)
+    _, data, tr = oracle.encode_trace(p, pcm)
+    rc, h = sla_amd.decode_header(data)
+    assert rc == 0
+    assert (h.wave_format.num_channels, h.wave_format.bit_per_sample, h.wave_format.sampling_rate,
+            h.wave_format.offset_lshift) == (2, 24, 96000, tr.offset_lshift)
+    assert (h.encode_param.parcor_order, h.encode_param.longterm_order, h.encode_param.lms_order_per_filter,
+            h.encode_param.ch_process_method, h.encode_param.max_num_block_samples) == (32, 3, 16, 1, 8192)
+    assert (h.num_samples, h.num_blocks) == (5000, tr.num_blocks)
+    assert h.max_block_size == int(tr.blk_bytes[:tr.num_blocks].max())
+    _, _, hdr = oracle.decode_whole(p, data, 5000)
+    assert h.max_block_size == int(hdr[11]) and h.max_bit_per_second == int.from_bytes(data[39:43], "big")
+    bad = bytearray(data); bad[16] ^= 4
+    rc, h2 = sla_amd.decode_header(bytes(bad))
+    assert rc == 11 and h2.num_samples != 5000 and h2.num_blocks == tr.num_blocks
+    bad = bytearray(data); bad[2] = ord("+")
+    assert sla_amd.decode_header(bytes(bad))[0] == 10
+    bad = bytearray(data); bad[13] = 2
+    assert sla_amd.decode_header(bytes(bad))[0] == 10
+    assert sla_amd.decode_header(data[:42])[0] == 9
+    assert L.SLADecoder_DecodeHeader(None, 43, C.byref(h)) == 2
+    # without a device there is no decoder either
+    import torch
+    if not torch.cuda.is_available():
+        cfg = sla_amd.SLADecoderConfig(2, 4096, 16, 1, 8, 1, 0)
+        assert L.SLADecoder_Create(C.byref(cfg)) is None
+
+
 @pytest.mark.parametrize("wtype", range(5))
 @pytest.mark.parametrize("n", [1, 2, 2048, 3000, 4096])
 def test_window_tables(L, oracle, wtype, n):
