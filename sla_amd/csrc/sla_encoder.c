@@ -269,7 +269,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   e->cfg = *config;
   if (hipGetDevice(&e->device) != hipSuccess) { free(e); return NULL; }
   if (hipGetDeviceProperties(&prop, e->device) == hipSuccess) {
-    snprintf(g_device_name, sizeof(g_device_name), "%s (%s)", prop.name, prop.gcnArchName);
+    snprintf(g_device_name, sizeof(g_device_name), "%.160s (%.80s)", prop.name, prop.gcnArchName);
   }
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess
       || hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess

@@ -1653,10 +1653,10 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
       }
       if (getenv("SLA_HIP_LPC_CLK") != nullptr) {
         unsigned long long h[8] = {0}, z[8] = {0};
-        hipStreamSynchronize((hipStream_t)stream);
-        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lpc_clk), sizeof(h));
-        hipMemcpyToSymbol(HIP_SYMBOL(g_lpc_clk), z, sizeof(z));
-        int occ = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, LB_THREADS, bytes);
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lpc_clk), sizeof(h));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lpc_clk), z, sizeof(z));
+        int occ = 0; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, LB_THREADS, bytes);
         if (h[3] != 0) {
           fprintf(stderr, "[k_lpc_blocks] LDS %zu B, %d workgroups per CU; ", bytes, occ);
           fprintf(stderr, "[k_lpc_blocks] %llu workgroups (pack %u), ticks per workgroup: stage %llu, chains %llu (lag consumer busy %llu, producer busy %llu, energy consumer busy %llu), levinson+quantiser %llu\n",

@@ -416,7 +416,7 @@ SLAPredictorApiResult SLAOptimalEncodeEstimator_SearchOptimalBlockPartitions(
   if (parcor_order == 0 || parcor_order > 255 || num_samples > PREDICTOR_MAX_SAMPLES) { return SLAPREDICTOR_APIRESULT_NG; }
   pair = (uint32_t*)malloc(sizeof(uint32_t) * nodes * nodes);
   cands = (sla_hip_lpc_cand*)malloc(sizeof(*cands) * nodes * nodes);
-  adj = (double*)malloc(sizeof(double) * nodes * nodes);
+  adj = (double*)calloc((size_t)nodes * nodes, sizeof(double));
   out = NULL;
   if (pair == NULL || cands == NULL || adj == NULL) { goto done; }
   /* every (i,j), j > i, whose clipped length is allowed                      src/SLAPredictor.c:1615-1630 */
