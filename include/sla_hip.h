@@ -125,6 +125,12 @@ typedef struct sla_hip_pack_block {
 int sla_hip_launch_prepass(const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_channels,
                            uint32_t num_samples, uint32_t bits_per_sample, uint32_t mid_side,
                            uint32_t* d_or_mask, uint64_t* d_nz_mask, sla_hip_stream_t stream);
+/* The same pass that also stores the OR of every 1024-sample tile (d_tile_or: ceil(num_samples / 4096) * 4 words):
+ * a batch of files laid out back to back on 1024-sample boundaries gets its offset_lshift per file from them. */
+#define SLA_HIP_PREPASS_TILE 1024u
+int sla_hip_launch_prepass_tiles(const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_channels,
+                                 uint32_t num_samples, uint32_t bits_per_sample, uint32_t mid_side,
+                                 uint32_t* d_or_mask, uint64_t* d_nz_mask, uint32_t* d_tile_or, sla_hip_stream_t stream);
 
 /* Autocorrelation + Levinson-Durbin for every candidate of every group.
  * d_out: per slot (order+2) doubles = { r[0], parcor[0..order] }.
@@ -342,6 +348,21 @@ int sla_hip_pack(struct SLAEncoder* encoder, uint8_t* data, uint32_t data_size, 
 /* Same bytes as sla_hip_pack, but the Rice coding, block assembly and CRC16 run on the device and one
  * D2H copy brings the finished image back.  Used by SLAEncoder_EncodeWhole. */
 int sla_hip_pack_device(struct SLAEncoder* encoder, uint8_t* data, uint32_t data_size, uint32_t* output_size);
+
+/* Many files in one call (BASELINE C4: a batch of short clips).  Each file is encoded exactly as
+ * SLAEncoder_EncodeWhole would encode it on its own -- same bytes, own header, own offset_lshift -- but the blocks
+ * of all files travel through the kernels together (they are as independent as the blocks of one file), so a
+ * 10-second clip no longer costs the fixed latency of the whole pipeline.  All files share the encoder's wave format
+ * and parameters.  Returns 0 when the batch ran; each item carries its own SLAApiResult (e.g. a buffer too small). */
+typedef struct sla_hip_batch_item {
+  const int32_t* const* input;     /* in : [num_channels] planes, left-justified in 32 bits */
+  uint32_t num_samples;            /* in  */
+  uint32_t data_size;              /* in : capacity of `data` */
+  uint8_t* data;                   /* in : receives the .sla bytes */
+  uint32_t output_size;            /* out */
+  int32_t  result;                 /* out: SLAApiResult of this file */
+} sla_hip_batch_item;
+int sla_hip_encode_batch(struct SLAEncoder* encoder, sla_hip_batch_item* items, uint32_t num_items);
 
 /* Device pointers of the last analysis (for RCCL gathers / tests). */
 const int32_t* sla_hip_final_residual(const struct SLAEncoder* encoder, uint64_t* plane_stride);

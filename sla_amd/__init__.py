@@ -76,6 +76,11 @@ class HipTrace(C.Structure):
         ("res_lattice", i32p), ("res_final", i32p)]
 
 
+class BatchItem(C.Structure):
+    _fields_ = [("input", C.POINTER(i32p)), ("num_samples", C.c_uint32), ("data_size", C.c_uint32),
+                ("data", u8p), ("output_size", C.c_uint32), ("result", C.c_int32)]
+
+
 class SlaError(RuntimeError):
     def __init__(self, code, where):
         name = API_RESULT[code] if 0 <= code < len(API_RESULT) else ("hipError %d" % (-code))
@@ -124,6 +129,7 @@ def lib():
         L.sla_hip_last_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.sla_hip_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.sla_hip_search_exact_lags.restype = C.c_uint32
+        L.sla_hip_encode_batch.argtypes = [C.c_void_p, C.POINTER(BatchItem), C.c_uint32]
         L.SLADecoder_Create.restype = C.c_void_p
         L.SLADecoder_Create.argtypes = [C.POINTER(SLADecoderConfig)]
         L.SLADecoder_Destroy.argtypes = [C.c_void_p]
@@ -165,7 +171,7 @@ EXPORTED_SYMBOLS = [
     "SLADecoder_DecodeHeader", "SLADecoder_Create", "SLADecoder_Destroy", "SLADecoder_SetWaveFormat",
     "SLADecoder_SetEncodeParameter", "SLADecoder_DecodeWhole", "sla_hip_decoder_last_timing", "sla_hip_decode_device",
     "sla_hip_launch_dec_bits", "sla_hip_launch_dec_lms", "sla_hip_launch_dec_ltm", "sla_hip_launch_dec_lattice",
-    "sla_hip_launch_dec_finish",
+    "sla_hip_launch_dec_finish", "sla_hip_launch_prepass_tiles", "sla_hip_encode_batch",
 ]
 
 
@@ -272,6 +278,21 @@ class Encoder:
                     "SLAEncoder_EncodeWhole")
         self.num_samples = n
         return buf[:size.value] if out is not None else buf[:size.value].tobytes()
+
+    def encode_batch(self, pcms, capacities=None):
+        """many files in one pass (sla_hip_encode_batch): list of planar int32 [C][n_i] -> list of (result, bytes)"""
+        keep, items = [], (BatchItem * len(pcms))()
+        for i, pcm in enumerate(pcms):
+            pcm, ptrs = self._planes(pcm)
+            cap = capacities[i] if capacities is not None else 8 * pcm.shape[0] * pcm.shape[1] + 65536
+            buf = np.zeros(cap, np.uint8)
+            keep.append((pcm, ptrs, buf))
+            items[i].input = ptrs
+            items[i].num_samples = pcm.shape[1]
+            items[i].data = buf.ctypes.data_as(u8p)
+            items[i].data_size = cap
+        self._check(self._lib.sla_hip_encode_batch(self._h, items, len(pcms)), "sla_hip_encode_batch")
+        return [(int(items[i].result), keep[i][2][:items[i].output_size].tobytes()) for i in range(len(pcms))]
 
     def encode_block(self, pcm, capacity=None):
         pcm, ptrs = self._planes(pcm)

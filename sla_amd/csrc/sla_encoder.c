@@ -89,6 +89,13 @@ struct SLAEncoder {
   /* caller-owned residual planes (e.g. torch tensors that feed an RCCL all-gather), optional */
   int32_t* user_res1; int32_t* user_res2; uint64_t user_stride;
 
+  /* batch of files in one pass (sla_hip_encode_batch): the files occupy [seg_start, seg_start + seg_len) of the
+   * planes, every start a multiple of SLA_HIP_PREPASS_TILE, all with the same offset_lshift.  nsegs == 0: one file
+   * = [0, num_samples). */
+  uint32_t nsegs; const uint32_t* seg_start; const uint32_t* seg_len;
+  uint32_t batch_lshift, batch_or;
+  devbuf_t d_tile_or; pinbuf_t h_tile_or;
+
   /* last analysis */
   const int32_t* pcm_dev;           /* borrowed or &d_pcm */
   uint64_t stride;
@@ -356,6 +363,8 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   h[22] = &e->h_parts; h[23] = &e->h_nparts; h[24] = &e->h_pstatus;
   for (i = 0; i < 25; i++) { if (h[i]->ptr != NULL) { (void)hipHostFree(h[i]->ptr); } }
   if (e->h_or != NULL) { (void)hipHostFree(e->h_or); }
+  if (e->d_tile_or.ptr != NULL) { (void)hipFree(e->d_tile_or.ptr); }
+  if (e->h_tile_or.ptr != NULL) { (void)hipHostFree(e->h_tile_or.ptr); }
   for (i = 0; i < 2; i++) {
     if (e->h_stage[i].ptr != NULL) { (void)hipHostFree(e->h_stage[i].ptr); }
     if (e->d_stage[i].ptr != NULL) { (void)hipFree(e->d_stage[i].ptr); }
@@ -595,13 +604,17 @@ static int build_tables(struct SLAEncoder* e, actx_t* a, const uint64_t* nz)
   extern uint32_t sla_hip_lattice_chunk_samples(uint32_t order);
   const uint32_t chunk_samples = sla_hip_lattice_chunk_samples(order);
   sla_hip_lpc_cand* cands; sla_hip_lpc_group* groups;
-  uint32_t sf_cap = 0, shapes_cap = 8, pos, i;
+  uint32_t sf_cap = 0, shapes_cap = 8, pos, i, sg;
+  const uint32_t nsegs = e->nsegs ? e->nsegs : 1u;
 
-  /* super-frame table (sequential hop over silence runs)        src/SLAEncoder.c:846-869, 392-408 */
+  /* super-frame table (sequential hop over silence runs)        src/SLAEncoder.c:846-869, 392-408
+   * -- per file: a batch restarts the hop at every file's first sample */
   a->shapes = (shape_t*)malloc(sizeof(shape_t) * shapes_cap);
   if (a->shapes == NULL) { return SLA_APIRESULT_NG; }
-  for (pos = 0; pos < n;) {
-    const uint32_t remain = n - pos;
+  for (sg = 0; sg < nsegs; sg++) {
+  const uint32_t seg_lo = e->nsegs ? e->seg_start[sg] : 0u, seg_hi = e->nsegs ? seg_lo + e->seg_len[sg] : n;
+  for (pos = seg_lo; pos < seg_hi;) {
+    const uint32_t remain = seg_hi - pos;
     const uint32_t window = (maxb < remain) ? maxb : remain;
     const uint32_t min_blk = (SLAI_MIN_BLOCK < remain) ? SLAI_MIN_BLOCK : remain;
     const uint32_t run = slai_zero_run(nz, pos, window);
@@ -637,6 +650,7 @@ static int build_tables(struct SLAEncoder* e, actx_t* a, const uint64_t* nz)
       a->blocks_bound += window / min_blk + 1;
       a->lchunks_bound += C * (window / chunk_samples + window / min_blk + 2);
     }
+  }
   }
 
   PTRACE("super-frame table");
@@ -737,6 +751,15 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
   int rebuild = 0;
 
   g_trace_t0 = now_ms();
+  if (e->nsegs != 0) {
+    /* batch: sla_hip_encode_batch ran the prepass over all files, the whole mask is on the host and the files of
+     * this pass share one offset_lshift */
+    e->lshift = e->batch_lshift; e->h_or[0] = e->batch_or;
+    RCCHK(build_tables(e, a, (const uint64_t*)e->h_nz.ptr));
+    a->exact = (e->search_exact && SLAI_SEARCH_DELTA == SLA_HIP_XTILE && maxb <= SLA_HIP_XTILE * SLA_HIP_XTILES
+                && sla_hip_search_exact_lags(order) != 0 && e->h_or[0] != 0);
+    return 0;
+  }
   RCCHK(dev_reserve(&e->d_or, 64));
   RCCHK(dev_reserve(&e->d_nz, (size_t)(nwords + 2) * 8));
   RCCHK(pin_reserve(&e->h_nz, (size_t)(nwords + 2) * 8));
@@ -1593,18 +1616,28 @@ int sla_hip_pack(struct SLAEncoder* e, uint8_t* data, uint32_t data_size, uint32
  * bit counts into block sizes/offsets, and writes the 43-byte file header. */
 static int download_bytes(struct SLAEncoder* e, uint8_t* dst, const uint8_t* d_src, size_t bytes);
 
-int sla_hip_pack_device(struct SLAEncoder* e, uint8_t* data, uint32_t data_size, uint32_t* output_size)
+/* One output file of a pack pass: the blocks that start inside [lo, hi) of the planes. */
+typedef struct {
+  uint32_t lo, hi;                       /* in  */
+  uint8_t* data; uint32_t data_size;     /* in: the caller's buffer */
+  uint32_t out_size; int result;         /* out */
+  uint32_t num_blocks, max_block, max_bps;
+  uint64_t img_off;                      /* where the file starts in the device image */
+} pack_seg_t;
+
+static int download_bytes(struct SLAEncoder* e, uint8_t* dst, const uint8_t* d_src, size_t bytes);
+
+/* Rice code lengths, block assembly and CRC16 on the device for every file of the analysed planes (segs sorted by
+ * position, blocks are), one image holding the files back to back; each file is then copied to its buffer and gets
+ * its 43-byte header.  A file that does not fit its buffer is reported in its `result`, the others are delivered. */
+static int pack_device_core(struct SLAEncoder* e, pack_seg_t* segs, uint32_t nsegs)
 {
-  uint32_t C, O1, nb, b, ch, njobs = 0, maxblk = 0, maxbps = 0;
+  uint32_t C, O1, nb, b, ch, njobs = 0, sg;
   sla_hip_rice_job* jobs; sla_hip_pack_block* pb; uint8_t* hdr; uint32_t* job_of;
   size_t hdr_used = 0, hdr_cap;
-  uint64_t cur = SLA_HEADER_SIZE;
+  uint64_t cur = 0;
   struct SLAHeaderInfo hinfo;
   int rc = 0;
-  if (e == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
-  if (!e->analysed) { return SLA_APIRESULT_PARAMETER_NOT_SET; }
-  if (data == NULL || output_size == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
-  if (data_size < SLA_HEADER_SIZE) { return SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE; }
   C = e->wave_format.num_channels; O1 = e->encode_param.parcor_order + 1; nb = e->num_blocks;
   hdr_cap = (size_t)nb * (16 + C * (8 + 2 * O1 + 16)) + 64;
   RCCHK(pin_reserve(&e->h_pk_jobs, sizeof(sla_hip_rice_job) * ((size_t)nb * C + 1)));
@@ -1661,11 +1694,18 @@ int sla_hip_pack_device(struct SLAEncoder* e, uint8_t* data, uint32_t data_size,
     HIPCHK(hipStreamSynchronize(e->stream));
   }
 
-  /* block sizes -> offsets */
+  /* block sizes -> offsets; a file = 43 header bytes + its blocks */
+  for (sg = 0; sg < nsegs; sg++) { segs[sg].out_size = 0; segs[sg].result = 0; segs[sg].num_blocks = 0; segs[sg].max_block = 0; segs[sg].max_bps = 0; }
+  sg = 0; segs[0].img_off = 0; cur = SLA_HEADER_SIZE;
   for (b = 0; b < nb; b++) {
     const blk_t* k = &e->blk[b];
     uint64_t body_bits = 0, bytes;
     uint32_t bps_blk;
+    while (sg + 1 < nsegs && k->start >= segs[sg].hi) {
+      segs[sg].out_size = (uint32_t)(cur - segs[sg].img_off);
+      sg++;
+      segs[sg].img_off = cur; cur += SLA_HEADER_SIZE;
+    }
     if (k->type == SLAI_BLK_COMPRESS) {
       for (ch = 0; ch < C; ch++) { body_bits += ((const uint64_t*)e->h_fold.ptr)[job_of[b] + ch]; }
     } else if (k->type == SLAI_BLK_RAW) {
@@ -1674,15 +1714,26 @@ int sla_hip_pack_device(struct SLAEncoder* e, uint8_t* data, uint32_t data_size,
       body_bits = per_sample * k->nsmpl;
     }
     bytes = pb[b].header_bytes + (body_bits + 7) / 8;
-    if (bytes > 0xFFFFFFF0ull || cur >= data_size || bytes > (uint64_t)data_size - cur) { free(job_of); return SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE; }
+    if (bytes > 0xFFFFFFF0ull) { free(job_of); return SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE; }
+    if (cur - segs[sg].img_off >= segs[sg].data_size || bytes > (uint64_t)segs[sg].data_size - (cur - segs[sg].img_off)) {
+      segs[sg].result = SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE;
+    }
     pb[b].out_off = cur; pb[b].out_bytes = (uint32_t)bytes;
     e->blk[b].bytes = (uint32_t)bytes;
     cur += bytes;
-    if (bytes > maxblk) { maxblk = (uint32_t)bytes; }
+    segs[sg].num_blocks++;
+    if (bytes > segs[sg].max_block) { segs[sg].max_block = (uint32_t)bytes; }
     bps_blk = (8 * (uint32_t)bytes * e->wave_format.sampling_rate) / k->nsmpl;        /* src/SLAEncoder.c:895 */
-    if (bps_blk > maxbps) { maxbps = bps_blk; }
+    if (bps_blk > segs[sg].max_bps) { segs[sg].max_bps = bps_blk; }
+  }
+  for (;;) {                               /* close the file of the last block and the block-less files behind it */
+    segs[sg].out_size = (uint32_t)(cur - segs[sg].img_off);
+    if (sg + 1 >= nsegs) { break; }
+    sg++;
+    segs[sg].img_off = cur; cur += SLA_HEADER_SIZE;
   }
   free(job_of);
+  if (nsegs == 1 && segs[0].result != 0) { return segs[0].result; }     /* one file: nothing worth assembling */
 
   /* assemble the image on the device, bring it back with one copy */
   {
@@ -1701,14 +1752,37 @@ int sla_hip_pack_device(struct SLAEncoder* e, uint8_t* data, uint32_t data_size,
                                       e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS,
                                       (uint32_t*)e->d_image.ptr, e->stream));
     }
-    RCCHK(download_bytes(e, data, (const uint8_t*)e->d_image.ptr, (size_t)cur));
+    for (sg = 0; sg < nsegs; sg++) {
+      if (segs[sg].result != 0) { continue; }
+      RCCHK(download_bytes(e, segs[sg].data, (const uint8_t*)e->d_image.ptr + segs[sg].img_off, (size_t)segs[sg].out_size));
+    }
   }
-  hinfo.wave_format = e->wave_format; hinfo.wave_format.offset_lshift = (uint8_t)e->lshift;
-  hinfo.encode_param = e->encode_param; hinfo.num_samples = e->num_samples; hinfo.num_blocks = nb;
-  hinfo.max_block_size = maxblk; hinfo.max_bit_per_second = maxbps;
-  rc = slai_write_header(&hinfo, data, data_size);
-  *output_size = (uint32_t)cur;
-  return rc;
+  for (sg = 0; sg < nsegs; sg++) {
+    if (segs[sg].result != 0) { continue; }
+    hinfo.wave_format = e->wave_format; hinfo.wave_format.offset_lshift = (uint8_t)e->lshift;
+    hinfo.encode_param = e->encode_param; hinfo.num_samples = segs[sg].hi - segs[sg].lo; hinfo.num_blocks = segs[sg].num_blocks;
+    hinfo.max_block_size = segs[sg].max_block; hinfo.max_bit_per_second = segs[sg].max_bps;
+    rc = slai_write_header(&hinfo, segs[sg].data, segs[sg].data_size);
+    if (rc != 0) { segs[sg].result = rc; }
+  }
+  return 0;
+}
+
+int sla_hip_pack_device(struct SLAEncoder* e, uint8_t* data, uint32_t data_size, uint32_t* output_size)
+{
+  pack_seg_t seg;
+  int rc;
+  if (e == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (!e->analysed) { return SLA_APIRESULT_PARAMETER_NOT_SET; }
+  if (data == NULL || output_size == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (data_size < SLA_HEADER_SIZE) { return SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE; }
+  memset(&seg, 0, sizeof(seg));
+  seg.lo = 0; seg.hi = e->num_samples; seg.data = data; seg.data_size = data_size;
+  rc = pack_device_core(e, &seg, 1);
+  if (rc != 0) { return rc; }
+  if (seg.result != 0) { return seg.result; }
+  *output_size = seg.out_size;
+  return 0;
 }
 
 /* -------------------------------------------------------------- public encode API */
@@ -1830,6 +1904,219 @@ SLAApiResult SLAEncoder_EncodeWhole(struct SLAEncoder* e, const int32_t* const* 
   rc = sla_hip_analyze_device(e, e->pcm_dev, e->stride, num_samples, NULL, NULL);
   if (rc == 0) { rc = sla_hip_pack_device(e, data, data_size, output_size); }
   return (rc >= 0) ? (SLAApiResult)rc : SLA_APIRESULT_NG;
+}
+
+/* ---- many files in one pass (BASELINE C4: a batch of short clips) --------------------------------------------
+ * A 10-second clip is 235 blocks: far too few to fill the chip, and every stage of the pipeline is a kernel whose
+ * duration is set by ONE block's serial chain, so a clip costs the same few milliseconds as a file a hundred times
+ * longer.  Blocks of different files are as independent as blocks of one file, so the batch lays the
+ * files out back to back in one set of planes (starts on 1024-sample tile boundaries, gaps zero), restarts the
+ * super-frame hop at every file, and runs the pipeline ONCE; offset_lshift is per file (OR of the file's prepass
+ * tiles) -- files that share a value share a pass.  Every file comes out byte-identical to its own
+ * SLAEncoder_EncodeWhole. */
+typedef struct {
+  const sla_hip_batch_item* items; const uint32_t* start;      /* plane position of every file of the pass */
+  uint32_t first, count;                                        /* items [first, first + count) */
+  uint32_t ch; size_t plane_lo;                                 /* this slot covers plane samples [plane_lo, plane_lo + n) */
+  size_t n; int16_t* dst16; int32_t* dst32; uint32_t lowbits;
+} stage_batch_t;
+
+static void stage_batch_one(void* vctx, uint32_t g)
+{
+  stage_batch_t* c = (stage_batch_t*)vctx;
+  const size_t lo = (size_t)g * XFER_GRAIN, hi = (lo + XFER_GRAIN < c->n) ? lo + XFER_GRAIN : c->n;
+  const size_t p_lo = c->plane_lo + lo, p_hi = c->plane_lo + hi;
+  uint32_t a = 0, b = c->count, i, low = 0;
+  size_t at = p_lo;
+  /* first file whose end lies behind p_lo (starts ascend) */
+  while (a < b) { const uint32_t m = (a + b) / 2; if ((size_t)c->start[m] + c->items[c->first + m].num_samples <= p_lo) { a = m + 1; } else { b = m; } }
+  for (i = a; at < p_hi; i++) {
+    const size_t f_lo = (i < c->count) ? c->start[i] : p_hi, f_hi = (i < c->count) ? f_lo + c->items[c->first + i].num_samples : p_hi;
+    const size_t z_hi = (f_lo < p_hi) ? ((f_lo > at) ? f_lo : at) : p_hi;      /* gap [at, z_hi): zeros */
+    size_t k;
+    if (c->dst16 != NULL) { memset(c->dst16 + (at - c->plane_lo), 0, (z_hi - at) * 2); } else { memset(c->dst32 + (at - c->plane_lo), 0, (z_hi - at) * 4); }
+    at = z_hi;
+    if (at >= p_hi || i >= c->count) { break; }
+    {
+      const size_t c_hi = (f_hi < p_hi) ? f_hi : p_hi;
+      const int32_t* src = c->items[c->first + i].input[c->ch] + (at - f_lo);
+      if (c_hi <= at) { continue; }                                            /* a file of zero samples */
+      if (c->dst16 != NULL) {
+        int16_t* d = c->dst16 + (at - c->plane_lo);
+        for (k = 0; k < c_hi - at; k++) { const int32_t v = src[k]; low |= (uint32_t)v & 0xFFFFu; d[k] = (int16_t)(v >> 16); }
+      } else {
+        memcpy(c->dst32 + (at - c->plane_lo), src, sizeof(int32_t) * (c_hi - at));
+      }
+      at = c_hi;
+    }
+  }
+  if (low) { __atomic_fetch_or(&c->lowbits, low, __ATOMIC_RELAXED); }
+}
+
+static int upload_batch_pass(struct SLAEncoder* e, const sla_hip_batch_item* items, const uint32_t* start, uint32_t first,
+                             uint32_t count, size_t span, uint64_t stride, int mode16, uint32_t* lowbits)
+{
+  extern int sla_hip_launch_unpack16(const int16_t*, int32_t*, uint64_t, sla_hip_stream_t);
+  const uint32_t C = e->wave_format.num_channels;
+  const size_t slot_samples = mode16 ? (XFER_SLOT_BYTES / 2) : (XFER_SLOT_BYTES / 4);
+  uint32_t ch, k = 0;
+  size_t o;
+  stage_batch_t ctx;
+  ctx.items = items; ctx.start = start; ctx.first = first; ctx.count = count; ctx.lowbits = 0;
+  for (ch = 0; ch < C; ch++) {
+    for (o = 0; o < span; o += slot_samples, k++) {
+      const uint32_t slot = k & 1;
+      const size_t n = (span - o < slot_samples) ? (span - o) : slot_samples;
+      int32_t* dst = (int32_t*)e->d_pcm.ptr + (size_t)ch * stride + o;
+      if (k >= 2) { HIPCHK(hipEventSynchronize(e->ev_stage[slot])); }
+      ctx.ch = ch; ctx.plane_lo = o; ctx.n = n;
+      ctx.dst16 = mode16 ? (int16_t*)e->h_stage[slot].ptr : NULL;
+      ctx.dst32 = mode16 ? NULL : (int32_t*)e->h_stage[slot].ptr;
+      parallel_for(e->pool, (uint32_t)((n + XFER_GRAIN - 1) / XFER_GRAIN), stage_batch_one, &ctx);
+      if (mode16) {
+        HIPCHK(hipMemcpyAsync(e->d_stage[slot].ptr, e->h_stage[slot].ptr, n * 2, hipMemcpyHostToDevice, e->stream));
+        RCCHK(sla_hip_launch_unpack16((const int16_t*)e->d_stage[slot].ptr, dst, n, e->stream));
+      } else {
+        HIPCHK(hipMemcpyAsync(dst, e->h_stage[slot].ptr, n * 4, hipMemcpyHostToDevice, e->stream));
+      }
+      HIPCHK(hipEventRecord(e->ev_stage[slot], e->stream));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  *lowbits = ctx.lowbits;
+  return 0;
+}
+
+#define BATCH_MAX_SPAN (1u << 28)        /* samples per channel in one pass: C x 1 GiB of planes (x3 with the residuals) */
+
+/* items [first, first + count): one upload, one prepass, one pipeline pass per distinct offset_lshift */
+static int encode_batch_pass(struct SLAEncoder* e, sla_hip_batch_item* items, uint32_t first, uint32_t count)
+{
+  const uint32_t C = e->wave_format.num_channels, bps = e->wave_format.bit_per_sample;
+  const uint32_t ms = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
+  uint32_t *start, *lsh, *seg_start, *seg_len, *seg_item, *tile_or, *orv;
+  pack_seg_t* segs;
+  uint32_t i, lowbits = 0, ntiles;
+  uint64_t span = 0, stride, nwords;
+  int mode16 = (bps <= 16), rc = 0;
+
+  start = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)count * 6 + 64);
+  segs = (pack_seg_t*)malloc(sizeof(pack_seg_t) * ((size_t)count + 1));
+  if (start == NULL || segs == NULL) { free(start); free(segs); return SLA_APIRESULT_NG; }
+  lsh = start + count; seg_start = lsh + count; seg_len = seg_start + count; seg_item = seg_len + count; orv = seg_item + count;
+  for (i = 0; i < count; i++) {
+    start[i] = (uint32_t)span;
+    span += ((uint64_t)items[first + i].num_samples + SLA_HIP_PREPASS_TILE - 1) / SLA_HIP_PREPASS_TILE * SLA_HIP_PREPASS_TILE;
+  }
+  if (span == 0) { span = SLA_HIP_PREPASS_TILE; }
+  stride = span;
+#define BATCH_CHK(call) do { rc = (call); if (rc != 0) { goto done; } } while (0)
+#define BATCH_HIP(call) do { if ((call) != hipSuccess) { rc = SLA_APIRESULT_NG; goto done; } } while (0)
+  BATCH_CHK(dev_reserve(&e->d_pcm, sizeof(int32_t) * (size_t)C * (stride + 64)));
+  for (i = 0; i < 2; i++) { BATCH_CHK(pin_reserve(&e->h_stage[i], XFER_SLOT_BYTES)); BATCH_CHK(dev_reserve(&e->d_stage[i], XFER_SLOT_BYTES)); }
+  BATCH_CHK(upload_batch_pass(e, items, start, first, count, (size_t)span, stride, mode16, &lowbits));
+  if (mode16 && lowbits != 0) { BATCH_CHK(upload_batch_pass(e, items, start, first, count, (size_t)span, stride, 0, &lowbits)); }
+  e->pcm_dev = (const int32_t*)e->d_pcm.ptr; e->stride = stride; e->num_samples = (uint32_t)span;
+
+  /* prepass over everything: silence mask, OR per 1024-sample tile */
+  nwords = (span + 63) / 64;
+  ntiles = (uint32_t)((span + 4 * SLA_HIP_PREPASS_TILE - 1) / (4 * SLA_HIP_PREPASS_TILE) * 4);
+  BATCH_CHK(dev_reserve(&e->d_or, 64));
+  BATCH_CHK(dev_reserve(&e->d_nz, (size_t)(nwords + 2) * 8));
+  BATCH_CHK(pin_reserve(&e->h_nz, (size_t)(nwords + 2) * 8));
+  BATCH_CHK(dev_reserve(&e->d_tile_or, sizeof(uint32_t) * ((size_t)ntiles + 4)));
+  BATCH_CHK(pin_reserve(&e->h_tile_or, sizeof(uint32_t) * ((size_t)ntiles + 4)));
+  BATCH_HIP(hipEventRecord(e->ev[0], e->stream));
+  BATCH_CHK(sla_hip_launch_prepass_tiles(e->pcm_dev, e->stride, C, (uint32_t)span, bps, ms, (uint32_t*)e->d_or.ptr, (uint64_t*)e->d_nz.ptr,
+                                         (uint32_t*)e->d_tile_or.ptr, e->stream));
+  BATCH_HIP(hipEventRecord(e->ev[1], e->stream));
+  BATCH_HIP(hipMemcpyAsync(e->h_nz.ptr, e->d_nz.ptr, (size_t)nwords * 8, hipMemcpyDeviceToHost, e->stream));
+  BATCH_HIP(hipMemcpyAsync(e->h_tile_or.ptr, e->d_tile_or.ptr, sizeof(uint32_t) * ntiles, hipMemcpyDeviceToHost, e->stream));
+  BATCH_HIP(hipStreamSynchronize(e->stream));
+  ((uint64_t*)e->h_nz.ptr)[nwords] = 0; ((uint64_t*)e->h_nz.ptr)[nwords + 1] = 0;
+  e->nz_ones_words = 0;                                   /* the single-file path may not assume anything about h_nz any more */
+  tile_or = (uint32_t*)e->h_tile_or.ptr;
+
+  /* offset_lshift per file                                                    src/SLAEncoder.c:425-455 */
+  for (i = 0; i < count; i++) {
+    const uint32_t t0 = start[i] / SLA_HIP_PREPASS_TILE;
+    const uint32_t t1 = t0 + (items[first + i].num_samples + SLA_HIP_PREPASS_TILE - 1) / SLA_HIP_PREPASS_TILE;
+    uint32_t t, mask = 0;
+    for (t = t0; t < t1; t++) { mask |= tile_or[t]; }
+    orv[i] = mask; lsh[i] = 0;
+    items[first + i].result = SLA_APIRESULT_OK; items[first + i].output_size = 0;
+    if (mask != 0) {
+      const uint32_t ntz = (uint32_t)__builtin_ctz(mask);
+      if (bps < 32 - ntz || bps - (32 - ntz) >= bps) { items[first + i].result = SLA_APIRESULT_INVALID_ARGUMENT; lsh[i] = 0xFFFFFFFFu; continue; }
+      lsh[i] = bps - (32 - ntz);
+    }
+    if (items[first + i].data == NULL || items[first + i].data_size < SLA_HEADER_SIZE) {
+      items[first + i].result = (items[first + i].data == NULL) ? SLA_APIRESULT_INVALID_ARGUMENT : SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE;
+      lsh[i] = 0xFFFFFFFFu;
+    }
+  }
+
+  /* one pipeline pass per distinct offset_lshift (normally one) */
+  for (;;) {
+    uint32_t v = 0xFFFFFFFFu, ns = 0, s, gor = 0;
+    for (i = 0; i < count; i++) { if (lsh[i] != 0xFFFFFFFFu) { v = lsh[i]; break; } }
+    if (v == 0xFFFFFFFFu) { break; }
+    for (i = 0; i < count; i++) {
+      if (lsh[i] != v) { continue; }
+      seg_start[ns] = start[i]; seg_len[ns] = items[first + i].num_samples; seg_item[ns] = first + i; gor |= orv[i];
+      lsh[i] = 0xFFFFFFFFu; ns++;
+    }
+    e->nsegs = ns; e->seg_start = seg_start; e->seg_len = seg_len; e->batch_lshift = v; e->batch_or = gor;
+    e->analysed = 0;
+    memset(e->timing, 0, sizeof(e->timing));
+    rc = run_pipeline(e, 0);
+    e->nsegs = 0; e->seg_start = NULL; e->seg_len = NULL;
+    if (rc != 0) { goto done; }
+    e->wave_format.offset_lshift = (uint8_t)e->lshift;
+    e->analysed = 1;
+    for (s = 0; s < ns; s++) {
+      memset(&segs[s], 0, sizeof(segs[s]));
+      segs[s].lo = seg_start[s]; segs[s].hi = seg_start[s] + seg_len[s];
+      segs[s].data = items[seg_item[s]].data; segs[s].data_size = items[seg_item[s]].data_size;
+    }
+    /* a file of zero samples owns no tile: give it an empty range behind its predecessor so that the ranges stay sorted */
+    rc = pack_device_core(e, segs, ns);
+    if (rc != 0) { goto done; }
+    for (s = 0; s < ns; s++) { items[seg_item[s]].result = segs[s].result; items[seg_item[s]].output_size = (segs[s].result == 0) ? segs[s].out_size : 0; }
+  }
+done:
+  e->nsegs = 0; e->seg_start = NULL; e->seg_len = NULL;
+  e->analysed = 0;                                        /* the planes hold a batch, not a file: no trace / pack afterwards */
+  free(start); free(segs);
+  return rc;
+#undef BATCH_CHK
+#undef BATCH_HIP
+}
+
+int sla_hip_encode_batch(struct SLAEncoder* e, sla_hip_batch_item* items, uint32_t num_items)
+{
+  uint32_t first = 0, i, ch;
+  int rc;
+  if (e == NULL || (items == NULL && num_items != 0)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if ((rc = check_ready(e)) != 0) { return rc; }
+  for (i = 0; i < num_items; i++) {
+    if (items[i].input == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+    for (ch = 0; ch < e->wave_format.num_channels; ch++) { if (items[i].input[ch] == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; } }
+    if (items[i].num_samples > BATCH_MAX_SPAN - SLA_HIP_PREPASS_TILE) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
+  }
+  while (first < num_items) {
+    uint64_t span = 0;
+    uint32_t count = 0;
+    while (first + count < num_items) {
+      const uint64_t add = ((uint64_t)items[first + count].num_samples + SLA_HIP_PREPASS_TILE - 1) / SLA_HIP_PREPASS_TILE * SLA_HIP_PREPASS_TILE;
+      if (count > 0 && span + add > BATCH_MAX_SPAN) { break; }
+      span += add; count++;
+    }
+    rc = encode_batch_pass(e, items, first, count);
+    if (rc != 0) { return (rc > 0) ? rc : SLA_APIRESULT_NG; }
+    first += count;
+  }
+  return 0;
 }
 
 /* One block with the encoder's current offset_lshift; no partition search (src/SLAEncoder.c:458-801). */

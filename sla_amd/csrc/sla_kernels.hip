@@ -95,7 +95,8 @@ __device__ __forceinline__ uint32_t umax_wave(uint32_t v)
 template <int NCH>      // 1, 2 or 0 = any
 __global__ __launch_bounds__(256)
 void k_prepass(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t nch_rt, uint32_t n,
-               uint32_t shift, uint32_t ms, uint32_t* __restrict__ or_mask, uint64_t* __restrict__ nz_mask)
+               uint32_t shift, uint32_t ms, uint32_t* __restrict__ or_mask, uint64_t* __restrict__ nz_mask,
+               uint32_t* __restrict__ tile_or)
 {
   const uint32_t nch = (NCH != 0) ? (uint32_t)NCH : nch_rt;
   const uint32_t lane = threadIdx.x & 63;
@@ -150,6 +151,7 @@ void k_prepass(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t nch_rt
   // thousands of waves, one word: only the few that still add a bit pay for the atomic (a stale read just costs one)
   if (lane == 0 && (acc & ~__atomic_load_n(or_mask, __ATOMIC_RELAXED)) != 0) { atomicOr(or_mask, acc); }
   if (lane == 0 && zero_words != 0) { atomicAdd(or_mask + 1, zero_words); }
+  if (tile_or != nullptr && lane == 0) { tile_or[wave] = acc; }       // OR of this wave's 1024 samples (batches: offset_lshift per file)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1547,9 +1549,9 @@ static hipError_t ensure_dynamic_lds(const void* fn, size_t bytes)
 
 static inline int hip_rc(hipError_t e) { return (e == hipSuccess) ? 0 : -(int)e; }
 
-extern "C" int sla_hip_launch_prepass(const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_channels,
-                                      uint32_t num_samples, uint32_t bits_per_sample, uint32_t mid_side,
-                                      uint32_t* d_or_mask, uint64_t* d_nz_mask, sla_hip_stream_t stream)
+static int launch_prepass_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_channels,
+                               uint32_t num_samples, uint32_t bits_per_sample, uint32_t mid_side,
+                               uint32_t* d_or_mask, uint64_t* d_nz_mask, uint32_t* d_tile_or, sla_hip_stream_t stream)
 {
   if (d_pcm == nullptr || d_or_mask == nullptr || d_nz_mask == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (num_channels == 0 || num_channels > 8 || bits_per_sample == 0 || bits_per_sample > 32
@@ -1562,13 +1564,28 @@ extern "C" int sla_hip_launch_prepass(const int32_t* d_pcm, uint64_t plane_strid
   uint32_t nblocks = (uint32_t)((nwords + 4 * PREPASS_WORDS - 1) / (4 * PREPASS_WORDS));
   const uint32_t shift = 32u - bits_per_sample;
   if (num_channels == 1) {
-    hipLaunchKernelGGL(k_prepass<1>, dim3(nblocks), dim3(256), 0, st, d_pcm, plane_stride, num_channels, num_samples, shift, mid_side, d_or_mask, d_nz_mask);
+    hipLaunchKernelGGL(k_prepass<1>, dim3(nblocks), dim3(256), 0, st, d_pcm, plane_stride, num_channels, num_samples, shift, mid_side, d_or_mask, d_nz_mask, d_tile_or);
   } else if (num_channels == 2) {
-    hipLaunchKernelGGL(k_prepass<2>, dim3(nblocks), dim3(256), 0, st, d_pcm, plane_stride, num_channels, num_samples, shift, mid_side, d_or_mask, d_nz_mask);
+    hipLaunchKernelGGL(k_prepass<2>, dim3(nblocks), dim3(256), 0, st, d_pcm, plane_stride, num_channels, num_samples, shift, mid_side, d_or_mask, d_nz_mask, d_tile_or);
   } else {
-    hipLaunchKernelGGL(k_prepass<0>, dim3(nblocks), dim3(256), 0, st, d_pcm, plane_stride, num_channels, num_samples, shift, mid_side, d_or_mask, d_nz_mask);
+    hipLaunchKernelGGL(k_prepass<0>, dim3(nblocks), dim3(256), 0, st, d_pcm, plane_stride, num_channels, num_samples, shift, mid_side, d_or_mask, d_nz_mask, d_tile_or);
   }
   return hip_rc(hipGetLastError());
+}
+
+extern "C" int sla_hip_launch_prepass(const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_channels,
+                                      uint32_t num_samples, uint32_t bits_per_sample, uint32_t mid_side,
+                                      uint32_t* d_or_mask, uint64_t* d_nz_mask, sla_hip_stream_t stream)
+{
+  return launch_prepass_impl(d_pcm, plane_stride, num_channels, num_samples, bits_per_sample, mid_side, d_or_mask, d_nz_mask, nullptr, stream);
+}
+
+extern "C" int sla_hip_launch_prepass_tiles(const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_channels,
+                                            uint32_t num_samples, uint32_t bits_per_sample, uint32_t mid_side,
+                                            uint32_t* d_or_mask, uint64_t* d_nz_mask, uint32_t* d_tile_or, sla_hip_stream_t stream)
+{
+  if (d_tile_or == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  return launch_prepass_impl(d_pcm, plane_stride, num_channels, num_samples, bits_per_sample, mid_side, d_or_mask, d_nz_mask, d_tile_or, stream);
 }
 
 static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,

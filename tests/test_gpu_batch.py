@@ -1,0 +1,122 @@
+"""GPU parity tests of sla_hip_encode_batch (BASELINE C4: a batch of clips in one pass; run with -m gpu).
+
+Every file of a batch must come out byte-identical to the oracle's encode of that file alone -- own header, own
+offset_lshift, own super-frame grid, silent / raw / compressed blocks, ragged tails -- and to SLAEncoder_EncodeWhole of
+the same handle.  Nothing here reads /root/reference."""
+import numpy as np
+import pytest
+
+import slalibs as S
+import waveforms as W
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    torch.cuda.init()
+    import sla_amd
+    sla_amd.lib()
+    return sla_amd
+
+
+def make_encoder(hip, p):
+    enc = hip.Encoder(p.cap_channels, p.cap_block_samples, p.cap_parcor_order, p.cap_longterm_order, p.cap_lms_order)
+    enc.set_wave_format(p.num_channels, p.bits_per_sample, p.sampling_rate)
+    enc.set_encode_parameter(p.parcor_order, p.longterm_order, p.lms_order, p.ch_process_method, p.window_type, p.max_block_samples)
+    return enc
+
+
+def check_batch(oracle, hip, p, pcms, also_single=True):
+    enc = make_encoder(hip, p)
+    try:
+        got = enc.encode_batch(pcms)
+        assert len(got) == len(pcms)
+        for i, (pcm, (rc, data)) in enumerate(zip(pcms, got)):
+            ret, want = oracle.encode_whole(p, pcm)
+            assert ret == 0
+            assert rc == 0, (i, rc)
+            assert data == want, ("file", i, len(data), len(want))
+        if also_single:                       # the same handle keeps working file by file, before and after a batch
+            assert enc.encode_whole(pcms[0]) == got[0][1]
+            again = enc.encode_batch(pcms[:2])
+            assert [d for _, d in again] == [d for _, d in got[:2]]
+    finally:
+        enc.close()
+
+
+def test_c4_clips(oracle, hip):
+    """48 kHz 16-bit stereo MS, order 16, 4096-sample frames: clips of different lengths and contents"""
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096, cap=(2, 4096, 16, 1, 8))
+    lens = [48000, 30001, 4096, 4097, 1, 2047, 2048, 100000, 777, 12288]
+    pcms = [S.synth_pcm(2, n, 16, 48000, seed=50 + i) if i % 2 == 0 else W.music_like(2, n, 16, seed=i) for i, n in enumerate(lens)]
+    check_batch(oracle, hip, p, pcms)
+
+
+def test_files_with_silence_raw_and_different_lshift(oracle, hip):
+    rng = np.random.default_rng(4)
+    n = 30000
+    a = W.music_like(2, n, 16, seed=1)
+    a[:, :5000] = 0                                     # leading silence: SILENT block, shifted frames
+    b = (rng.integers(-32768, 32768, (2, n)) << 16).astype(np.int32)      # incompressible: RAW blocks
+    c = (W.music_like(2, n, 16, seed=2) >> 18) << 18    # two low bits of the 16 are always zero: offset_lshift 2
+    d = np.zeros((2, 9000), np.int32)                   # all silent
+    e = W.music_like(2, n, 16, seed=3)
+    e[:, -3000:] = 0                                    # trailing silence up to the end of the file
+    f = (W.music_like(2, 5000, 16, seed=4) >> 20) << 20 # offset_lshift 4
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096)
+    check_batch(oracle, hip, p, [a, b, c, d, e, f])
+
+
+@pytest.mark.parametrize("cfg", [(1, 16, 16, 1, 8, 0, 4096), (2, 24, 32, 3, 8, 1, 4096), (8, 24, 48, 3, 8, 0, 8192),
+                                 (1, 8, 4, 1, 4, 0, 16384), (3, 24, 10, 5, 32, 0, 3072)])
+def test_other_formats(oracle, hip, cfg):
+    nch, bits, order, ltm, lms, ms, mb = cfg
+    p = S.make_params(nch, bits, 48000, order, ltm, lms, ms, 1, mb)
+    pcms = [W.music_like(nch, n, bits, seed=n) for n in (20000, 3000, 8193)] + [S.synth_pcm(nch, 15000, bits, 48000, seed=9, gaps=True)]
+    check_batch(oracle, hip, p, pcms, also_single=False)
+
+
+def test_buffer_too_small_is_reported_per_file(oracle, hip):
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096)
+    pcms = [W.music_like(2, 20000, 16, seed=i) for i in range(3)]
+    enc = make_encoder(hip, p)
+    try:
+        got = enc.encode_batch(pcms, capacities=[200000, 1000, 200000])
+        assert [rc for rc, _ in got] == [0, 4, 0]
+        for i in (0, 2):
+            assert got[i][1] == oracle.encode_whole(p, pcms[i])[1]
+        got = enc.encode_batch(pcms, capacities=[200000, 20, 200000])
+        assert [rc for rc, _ in got] == [0, 4, 0]
+    finally:
+        enc.close()
+
+
+def test_many_small_files(oracle, hip):
+    """200 files, lengths 1 .. 6000, mono 16-bit"""
+    rng = np.random.default_rng(8)
+    p = S.make_params(1, 16, 48000, 8, 1, 4, 0, 1, 4096)
+    pcms = [W.music_like(1, int(n), 16, seed=int(n)) for n in rng.integers(1, 6000, 200)]
+    check_batch(oracle, hip, p, pcms, also_single=False)
+
+
+def test_argument_checks(hip):
+    import ctypes as C
+    L = hip.lib()
+    p = S.make_params(1, 16, 48000, 8, 1, 4, 0, 1, 4096)
+    enc = make_encoder(hip, p)
+    try:
+        assert L.sla_hip_encode_batch(None, None, 0) == 2
+        assert L.sla_hip_encode_batch(enc._h, None, 3) == 2
+        assert L.sla_hip_encode_batch(enc._h, None, 0) == 0
+        items = (hip.BatchItem * 1)()
+        assert L.sla_hip_encode_batch(enc._h, items, 1) == 2          # NULL planes
+    finally:
+        enc.close()
+    raw = hip.Encoder()
+    try:
+        items = (hip.BatchItem * 1)()
+        assert L.sla_hip_encode_batch(raw._h, items, 1) == 15         # parameters not set
+    finally:
+        raw.close()
