@@ -279,19 +279,25 @@ class Encoder:
         self.num_samples = n
         return buf[:size.value] if out is not None else buf[:size.value].tobytes()
 
-    def encode_batch(self, pcms, capacities=None):
-        """many files in one pass (sla_hip_encode_batch): list of planar int32 [C][n_i] -> list of (result, bytes)"""
+    def encode_batch(self, pcms, capacities=None, outs=None):
+        """many files in one pass (sla_hip_encode_batch): list of planar int32 [C][n_i] -> list of (result, bytes).
+        `outs`: optional preallocated uint8 arrays, one per file (views of them are returned instead of copies)"""
         keep, items = [], (BatchItem * len(pcms))()
         for i, pcm in enumerate(pcms):
             pcm, ptrs = self._planes(pcm)
-            cap = capacities[i] if capacities is not None else 8 * pcm.shape[0] * pcm.shape[1] + 65536
-            buf = np.zeros(cap, np.uint8)
+            if outs is not None:
+                buf, cap = outs[i], len(outs[i])
+            else:
+                cap = capacities[i] if capacities is not None else 8 * pcm.shape[0] * pcm.shape[1] + 65536
+                buf = np.empty(cap, np.uint8)
             keep.append((pcm, ptrs, buf))
             items[i].input = ptrs
             items[i].num_samples = pcm.shape[1]
             items[i].data = buf.ctypes.data_as(u8p)
             items[i].data_size = cap
         self._check(self._lib.sla_hip_encode_batch(self._h, items, len(pcms)), "sla_hip_encode_batch")
+        if outs is not None:
+            return [(int(items[i].result), keep[i][2][:items[i].output_size]) for i in range(len(pcms))]
         return [(int(items[i].result), keep[i][2][:items[i].output_size].tobytes()) for i in range(len(pcms))]
 
     def encode_block(self, pcm, capacity=None):

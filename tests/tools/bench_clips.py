@@ -32,11 +32,12 @@ enc = sla_amd.Encoder(2, 4096, 16, 1, 8)
 enc.set_wave_format(2, 16, 48000)
 enc.set_encode_parameter(16, 1, 8, sla_amd.CH_STEREO_MS, sla_amd.WINDOW_SIN, 4096)
 single = [enc.encode_whole(pcms[i]) for i in range(8)]
+outs = [np.zeros(4 * 2 * n + 65536, np.uint8) for _ in range(clips)]
 for rep in range(3):
     t0 = time.perf_counter()
-    got = enc.encode_batch(pcms)
+    got = enc.encode_batch(pcms, outs=outs)
     dt = time.perf_counter() - t0
-ok = all(rc == 0 and data == single[i % 8] for i, (rc, data) in enumerate(got))
+ok = all(rc == 0 and data.tobytes() == single[i % 8] for i, (rc, data) in enumerate(got))
 print("sla_hip_encode_batch: %d clips in %.1f ms -> %.3f ms per clip, %.0f Msamples/s (every clip identical to its own EncodeWhole: %s)"
       % (clips, dt * 1e3, dt * 1e3 / clips, clips * n * 2 / dt / 1e6, ok))
 enc.close()
