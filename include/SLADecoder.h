@@ -10,7 +10,8 @@
  *
  * Error behaviour follows the reference block by block: blocks are examined in file order, the first
  * failing one decides the result (src/SLADecoder.c:696-722), and the samples of the blocks before it have
- * been written to `buffer`.
+ * been written to `buffer`; *output_num_samples then holds their count (the reference leaves it unwritten on
+ * failure, src/SLADecoder.c:729).
  *
  * Differences a caller can observe:
  *   - SLADecoder_Create returns NULL when no HIP device is usable (there is no CPU fallback) and for

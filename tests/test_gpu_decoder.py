@@ -1,8 +1,8 @@
 """GPU parity tests of the decode path (run with -m gpu on an MI355X).
 
 SLADecoder_DecodeWhole of libsla_hip.so must return the same result code and the same samples as the CPU
-oracle's decoder (oracle/sla_oracle.c: slao_decode_whole, pinned against the unmodified reference decoder in
-tests/test_oracle_vs_ref.py) on streams written by the oracle's encoder: the reference's own round-trip matrix
+oracle's decoder (oracle/sla_oracle.c: slao_decode_whole, pinned against the unmodified reference decoder -- samples and the
+result codes on damaged streams -- in tests/test_oracle_vs_ref.py) on streams written by the oracle's encoder: the reference's own round-trip matrix
 (test/test_SLAEncodeDecode.c:558-1172), BASELINE.json's configurations, every filter order the kernels
 specialise on, silent / raw blocks, ragged lengths, and damaged streams (the first failing block decides the
 code; the samples before it are delivered).  Nothing here reads /root/reference."""

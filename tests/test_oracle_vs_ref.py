@@ -411,3 +411,53 @@ def test_error_codes(oracle, ref):
     assert ro == rr == 5
     small = S.make_params(1, 16, 48000, 8, 1, 8, 0, 1, 1024)        # block below the 2048 minimum
     assert oracle.encode_whole(small, pcm[:1])[0] == 3
+
+
+def test_decoder_result_codes_on_damaged_streams(oracle, ref):
+    """The oracle's decoder is what the HIP decoder is checked against (tests/test_gpu_decoder.py); here its result codes
+    on damaged streams are pinned to the unmodified reference decoder's.  (On failure the reference does not report how
+    many samples it had already written -- src/SLADecoder.c:729 is only reached on success -- so only the codes and,
+    for streams that still decode, the samples are compared.)"""
+    def same(data, cap, p):
+        ro, do, _ = oracle.decode_whole(p, bytes(data), cap)
+        rr, dr, _ = ref.decode_whole(p, bytes(data), cap)
+        assert ro == rr, (ro, rr)
+        if ro == 0:
+            assert np.array_equal(do, dr)
+        return ro
+
+    pcm = W.music_like(2, 30000, 16, seed=9)
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096)
+    ret, data, tr = oracle.encode_trace(p, pcm)
+    assert ret == 0
+    offs = np.concatenate(([43], 43 + np.cumsum(tr.blk_bytes[:tr.num_blocks]))).astype(int)
+    d = bytearray(data); d[offs[3] + 40] ^= 0x10
+    assert same(d, 30000, p) == 11                       # corrupt block
+    d = bytearray(data); d[20] ^= 1
+    assert same(d, 30000, p) == 11                       # corrupt file header
+    d = bytearray(data); d[0] = ord("X")
+    assert same(d, 30000, p) == 10                       # not an SLA file
+    for cut in (offs[2] + 100, offs[4], offs[4] + 5, 43, 50):
+        assert same(data[:cut], 30000, p) == 9           # truncated
+    d = bytearray(data); d[offs[2]] = 0x7F
+    assert same(d, 30000, p) == 12                       # lost sync
+    cap = int(tr.blk_start[3]) + 10
+    assert same(data, cap, p) == 4                       # output buffer too small
+    d = bytearray(data); d[offs[3] + 30] ^= 1
+    assert same(d, cap, p) == 11                         # ... and damaged: the CRC is checked first
+    small = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096, cap=(2, 4096, 8, 1, 8))
+    assert same(data, 30000, small) == 3                 # beyond the handle's capacity
+
+    pcm1 = W.music_like(1, 30000, 16, seed=9)
+    p1 = S.make_params(1, 16, 48000, 16, 1, 8, 0, 1, 4096)
+    ret, data1, tr1 = oracle.encode_trace(p1, pcm1)
+    offs1 = np.concatenate(([43], 43 + np.cumsum(tr1.blk_bytes[:tr1.num_blocks]))).astype(int)
+    # a size field that disagrees with the body: the reference continues from where its bit reader stopped
+    d = bytearray(data1); k = 2
+    size = int.from_bytes(d[offs1[k] + 2:offs1[k] + 6], "big") + 1
+    d[offs1[k] + 2:offs1[k] + 6] = size.to_bytes(4, "big")
+    d[offs1[k] + 6:offs1[k] + 8] = int(oracle.crc16(bytes(d[offs1[k] + 8:offs1[k] + 6 + size]))).to_bytes(2, "big")
+    assert same(d, 30000, p1) == 0
+    d = bytearray(data1); d[28] = 1                      # mid/side on a mono stream
+    d[8:10] = int(oracle.crc16(bytes(d[10:43]))).to_bytes(2, "big")
+    assert same(d, 30000, p1) == 5
