@@ -16,13 +16,14 @@
  * Differences a caller can observe:
  *   - SLADecoder_Create returns NULL when no HIP device is usable (there is no CPU fallback) and for
  *     capacities the kernels do not cover: more than 8 channels, blocks above 16384 samples (long-term
- *     synthesis keeps a block in LDS), LMS filters above 32 coefficients, more than 5 long-term taps;
+ *     synthesis keeps a block in LDS), more than 5 long-term taps; a stream whose LMS filters are not 4, 8,
+ *     16 or 32 coefficients long fails with SLA_APIRESULT_FAILED_TO_SYNTHESIZE at its first compressed block;
  *   - a block whose header announces more samples than max_num_block_samples is refused with
  *     SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE (the reference writes past its work buffers);
  *   - a block type the format does not define returns SLA_APIRESULT_INVALID_HEADER_FORMAT (the reference
  *     asserts).
- * Not provided: the streaming decoder (SLAStreamingDecoder_*, reference src/SLADecoder.c:735-1123), a
- * real-time playback front end outside the batch path.
+ * The streaming decoder (SLAStreamingDecoder_*, reference src/SLADecoder.c:735-1123) is here too, with the
+ * reference's entry points and fragment bookkeeping; its unit of device work is a whole block (see below).
  */
 #ifndef SLA_DECODER_H_INCLUDED
 #define SLA_DECODER_H_INCLUDED
@@ -32,6 +33,7 @@
 #define SLA_DECODER_VERSION_STRING   "0.0.1(beta)"
 
 struct SLADecoder;                     /* opaque: device buffers, stream, host block table */
+struct SLAStreamingDecoder;            /* opaque: a decoder + fragment queue + block buffer       */
 
 /* Capacity of a handle (layout = reference src/include/public/SLADecoder.h:16-24). */
 struct SLADecoderConfig {
@@ -39,9 +41,16 @@ struct SLADecoderConfig {
   uint32_t max_num_block_samples;      /* <= 16384 here                                          */
   uint32_t max_parcor_order;           /* PARCOR coefficients per channel, <= 255                */
   uint32_t max_longterm_order;         /* long-term taps, <= 5                                   */
-  uint32_t max_lms_order_per_filter;   /* LMS coefficients per cascade stage, <= 32              */
+  uint32_t max_lms_order_per_filter;   /* LMS coefficients per cascade stage                     */
   uint8_t  enable_crc_check;           /* 1: verify the CRC16 of every block (on the device)     */
   uint8_t  verpose_flag;               /* (sic) unused                                           */
+};
+
+/* layout = reference src/include/public/SLADecoder.h:27-31 */
+struct SLAStreamingDecoderConfig {
+  struct SLADecoderConfig core_config;
+  float                   decode_interval_hz;   /* Decode calls per second of audio          */
+  uint32_t                max_bit_per_sample;   /* sizes the block buffer                    */
 };
 
 #ifdef __cplusplus
@@ -81,6 +90,61 @@ SLADecoder_DecodeWhole(struct SLADecoder* decoder,
                        int32_t**          buffer,
                        uint32_t           buffer_num_samples,
                        uint32_t*          output_num_samples);
+
+/* ---- streaming decoder (reference src/SLADecoder.c:735-1123) -------------------------------------------------
+ * Append fragments of the stream (referenced in place, at most 8 outstanding; CollectDataFragment hands back what
+ * has been copied into the block buffer), then draw ceil(1.05 * sampling_rate / decode_interval_hz) samples per
+ * Decode call.  A block is decoded on the device as soon as all its bytes have arrived and calls are served from
+ * its samples, so the PCM is exactly DecodeWhole's.  Difference: where the reference starts on a block whose tail
+ * has not been appended yet, Decode returns the samples it has (possibly 0) with SLA_APIRESULT_OK and continues
+ * once the rest is there; SLA_APIRESULT_INSUFFICIENT_DATA_SIZE means that not even a block header is available. */
+struct SLAStreamingDecoder*
+SLAStreamingDecoder_Create(const struct SLAStreamingDecoderConfig* config);
+
+void
+SLAStreamingDecoder_Destroy(struct SLAStreamingDecoder* decoder);
+
+SLAApiResult
+SLAStreamingDecoder_SetWaveFormat(struct SLAStreamingDecoder* decoder,
+                                  const struct SLAWaveFormat* wave_format);
+
+SLAApiResult
+SLAStreamingDecoder_SetEncodeParameter(struct SLAStreamingDecoder*      decoder,
+                                       const struct SLAEncodeParameter* encode_param);
+
+/* bytes worth one Decode call at the current block's average rate (at least a block header)   :877-900 */
+SLAApiResult
+SLAStreamingDecoder_EstimateMinimumNessesaryDataSize(struct SLAStreamingDecoder* decoder,
+                                                     uint32_t*                   estimate_data_size);
+
+/* samples the appended-but-undecoded bytes are worth at that rate                                :903-929 */
+SLAApiResult
+SLAStreamingDecoder_EstimateDecodableNumSamples(struct SLAStreamingDecoder* decoder,
+                                                uint32_t*                   estimate_num_samples);
+
+SLAApiResult
+SLAStreamingDecoder_GetOutputNumSamplesPerDecode(struct SLAStreamingDecoder* decoder,
+                                                 uint32_t*                   output_num_samples);
+
+SLAApiResult
+SLAStreamingDecoder_AppendDataFragment(struct SLAStreamingDecoder* decoder,
+                                       const uint8_t*              data,
+                                       uint32_t                    data_size);
+
+SLAApiResult
+SLAStreamingDecoder_CollectDataFragment(struct SLAStreamingDecoder* decoder,
+                                        const uint8_t**             data_ptr,
+                                        uint32_t*                   data_size);
+
+SLAApiResult
+SLAStreamingDecoder_GetRemainDataSize(struct SLAStreamingDecoder* decoder,
+                                      uint32_t*                   remain_data_size);
+
+SLAApiResult
+SLAStreamingDecoder_Decode(struct SLAStreamingDecoder* decoder,
+                           int32_t**                   buffer,
+                           uint32_t                    buffer_num_samples,
+                           uint32_t*                   num_output_samples);
 
 /* Wall time [ms] of the last DecodeWhole, 6 floats: upload, block walk, kernels (device, stream events),
  * download, total, number of kernel batches (1 unless a block's size field disagreed with its contents). */

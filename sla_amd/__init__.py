@@ -48,6 +48,10 @@ class SLADecoderConfig(C.Structure):
                 ("verpose_flag", C.c_uint8)]
 
 
+class SLAStreamingDecoderConfig(C.Structure):
+    _fields_ = [("core_config", SLADecoderConfig), ("decode_interval_hz", C.c_float), ("max_bit_per_sample", C.c_uint32)]
+
+
 class SLAWaveFormat(C.Structure):
     _fields_ = [("num_channels", C.c_uint32), ("bit_per_sample", C.c_uint32),
                 ("sampling_rate", C.c_uint32), ("offset_lshift", C.c_uint8)]
@@ -139,6 +143,18 @@ def lib():
         L.SLADecoder_SetEncodeParameter.argtypes = [C.c_void_p, C.POINTER(SLAEncodeParameter)]
         L.SLADecoder_DecodeWhole.argtypes = [C.c_void_p, u8p, C.c_uint32, C.POINTER(i32p), C.c_uint32, u32p]
         L.sla_hip_decoder_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.SLAStreamingDecoder_Create.restype = C.c_void_p
+        L.SLAStreamingDecoder_Create.argtypes = [C.POINTER(SLAStreamingDecoderConfig)]
+        L.SLAStreamingDecoder_Destroy.argtypes = [C.c_void_p]
+        L.SLAStreamingDecoder_Destroy.restype = None
+        L.SLAStreamingDecoder_SetWaveFormat.argtypes = [C.c_void_p, C.POINTER(SLAWaveFormat)]
+        L.SLAStreamingDecoder_SetEncodeParameter.argtypes = [C.c_void_p, C.POINTER(SLAEncodeParameter)]
+        for name in ("EstimateMinimumNessesaryDataSize", "EstimateDecodableNumSamples", "GetOutputNumSamplesPerDecode",
+                     "GetRemainDataSize"):
+            getattr(L, "SLAStreamingDecoder_" + name).argtypes = [C.c_void_p, u32p]
+        L.SLAStreamingDecoder_AppendDataFragment.argtypes = [C.c_void_p, u8p, C.c_uint32]
+        L.SLAStreamingDecoder_CollectDataFragment.argtypes = [C.c_void_p, C.POINTER(u8p), u32p]
+        L.SLAStreamingDecoder_Decode.argtypes = [C.c_void_p, C.POINTER(i32p), C.c_uint32, u32p]
         L.sla_hip_decode_device.argtypes = [C.c_void_p, u8p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, u32p]
         _lib = L
     return _lib
@@ -172,6 +188,11 @@ EXPORTED_SYMBOLS = [
     "SLADecoder_SetEncodeParameter", "SLADecoder_DecodeWhole", "sla_hip_decoder_last_timing", "sla_hip_decode_device",
     "sla_hip_launch_dec_bits", "sla_hip_launch_dec_lms", "sla_hip_launch_dec_ltm", "sla_hip_launch_dec_lattice",
     "sla_hip_launch_dec_finish", "sla_hip_launch_prepass_tiles", "sla_hip_encode_batch",
+    "SLAStreamingDecoder_Create", "SLAStreamingDecoder_Destroy", "SLAStreamingDecoder_SetWaveFormat",
+    "SLAStreamingDecoder_SetEncodeParameter", "SLAStreamingDecoder_EstimateMinimumNessesaryDataSize",
+    "SLAStreamingDecoder_EstimateDecodableNumSamples", "SLAStreamingDecoder_GetOutputNumSamplesPerDecode",
+    "SLAStreamingDecoder_AppendDataFragment", "SLAStreamingDecoder_CollectDataFragment",
+    "SLAStreamingDecoder_GetRemainDataSize", "SLAStreamingDecoder_Decode",
 ]
 
 
@@ -409,6 +430,58 @@ class Decoder:
         t = (C.c_float * 6)()
         self._lib.sla_hip_decoder_last_timing(self._h, t)
         return list(t)
+
+
+def streaming_decode(data, decode_interval_hz=120.0, feed=None, max_bit_per_sample=24, crc=1,
+                     capacity=(8, 16384, 48, 5, 40)):
+    """Drive SLAStreamingDecoder_* the way the reference CLI does (src/main.c:277-420): header, then per call
+    append the estimated number of bytes (or `feed(i)` bytes), decode, collect.  Returns (rc, pcm [C][n], calls)."""
+    L = lib()
+    buf = np.frombuffer(bytes(data), np.uint8)
+    h = SLAHeaderInfo()
+    rc = L.SLADecoder_DecodeHeader(buf.ctypes.data_as(u8p), len(buf), C.byref(h))
+    if rc != 0:
+        return rc, None, 0
+    cfg = SLAStreamingDecoderConfig(SLADecoderConfig(*capacity, crc, 0), decode_interval_hz, max_bit_per_sample)
+    dec = L.SLAStreamingDecoder_Create(C.byref(cfg))
+    if not dec:
+        raise RuntimeError("SLAStreamingDecoder_Create failed")
+    try:
+        rc = L.SLAStreamingDecoder_SetWaveFormat(dec, C.byref(h.wave_format))
+        if rc == 0:
+            rc = L.SLAStreamingDecoder_SetEncodeParameter(dec, C.byref(h.encode_param))
+        if rc != 0:
+            return rc, None, 0
+        nch, total = h.wave_format.num_channels, h.num_samples
+        out = np.zeros((nch, max(total, 1)), np.int32)
+        sample_pos, data_pos, calls = 0, 43, 0
+        est, got = C.c_uint32(0), C.c_uint32(0)
+        dummy_p, dummy_n = u8p(), C.c_uint32(0)
+        while sample_pos < total:
+            if feed is not None:
+                want = int(feed(calls))
+            elif sample_pos == 0 and calls == 0:
+                want = h.max_block_size
+            else:
+                L.SLAStreamingDecoder_EstimateMinimumNessesaryDataSize(dec, C.byref(est))
+                want = est.value
+            put = min(want, len(buf) - data_pos)
+            rc = L.SLAStreamingDecoder_AppendDataFragment(dec, buf[data_pos:].ctypes.data_as(u8p) if put > 0 else buf.ctypes.data_as(u8p), put)
+            if rc != 0:
+                return rc, out[:, :sample_pos], calls
+            ptrs = (i32p * nch)(*[out[c, sample_pos:].ctypes.data_as(i32p) for c in range(nch)])
+            rc = L.SLAStreamingDecoder_Decode(dec, ptrs, total - sample_pos, C.byref(got))
+            calls += 1
+            if rc != 0:
+                return rc, out[:, :sample_pos], calls
+            L.SLAStreamingDecoder_CollectDataFragment(dec, C.byref(dummy_p), C.byref(dummy_n))
+            data_pos += put
+            sample_pos += got.value
+            if got.value == 0 and put == 0 and data_pos >= len(buf):
+                return 9, out[:, :sample_pos], calls          # the stream ended inside a block
+        return 0, out[:, :total], calls
+    finally:
+        L.SLAStreamingDecoder_Destroy(dec)
 
 
 def decode_header(data):

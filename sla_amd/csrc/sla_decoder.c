@@ -10,6 +10,7 @@
 #include "sla_internal.h"
 #include "SLADecoder.h"
 
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -94,7 +95,7 @@ struct SLADecoder* SLADecoder_Create(const struct SLADecoderConfig* config)
   if (config == NULL) { return NULL; }
   if (config->max_num_channels == 0 || config->max_num_channels > SLAI_MAX_CHANNELS
       || config->max_num_block_samples > DEC_MAX_BLOCK_SAMPLES || config->max_parcor_order > SLAI_MAX_ORDER
-      || config->max_longterm_order > SLAI_MAX_TAPS || config->max_lms_order_per_filter > 32) { return NULL; }
+      || config->max_longterm_order > SLAI_MAX_TAPS) { return NULL; }
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     fprintf(stderr, "libsla_hip: no HIP device available -- the decode path has no CPU fallback\n");
     return NULL;
@@ -163,8 +164,11 @@ static int host_tables_reserve(struct SLADecoder* d, uint32_t blocks)
  * memory is either uploaded from it or supplied by the caller, the planes likewise are the handle's or the caller's. */
 static SLAApiResult decode_run(struct SLADecoder* d, const uint8_t* data, uint32_t data_size, const uint32_t* d_image_user,
                                int32_t* d_planes_user, uint64_t stride_user, int32_t** buffer,
-                               uint32_t buffer_num_samples, uint32_t* output_num_samples)
+                               uint32_t buffer_num_samples, uint32_t* output_num_samples, uint32_t* one_block_size)
 {
+  /* one_block_size == NULL: a whole file (header, then blocks until header.num_samples samples are out);
+   * otherwise `data` starts at a block's sync code and exactly that block is decoded with the handle's current
+   * format / parameters (the streaming decoder's unit; reference SLADecoder_DecodeBlock, src/SLADecoder.c:583-657) */
   struct SLAHeaderInfo header;
   SLAApiResult ret, result = SLA_APIRESULT_OK;
   uint32_t C, total, order, ntaps, lms, ms, bps, lshift, cap_n;
@@ -177,9 +181,17 @@ static SLAApiResult decode_run(struct SLADecoder* d, const uint8_t* data, uint32
   double t0 = now_ms(), t_up = 0.0, t_walk = 0.0, t1;
 
   memset(d->timing, 0, sizeof(d->timing));
-  if ((ret = SLADecoder_DecodeHeader(data, data_size, &header)) != SLA_APIRESULT_OK) { return ret; }
-  if ((ret = SLADecoder_SetWaveFormat(d, &header.wave_format)) != SLA_APIRESULT_OK) { return ret; }
-  if ((ret = SLADecoder_SetEncodeParameter(d, &header.encode_param)) != SLA_APIRESULT_OK) { return ret; }
+  if (one_block_size == NULL) {
+    if ((ret = SLADecoder_DecodeHeader(data, data_size, &header)) != SLA_APIRESULT_OK) { return ret; }
+    if ((ret = SLADecoder_SetWaveFormat(d, &header.wave_format)) != SLA_APIRESULT_OK) { return ret; }
+    if ((ret = SLADecoder_SetEncodeParameter(d, &header.encode_param)) != SLA_APIRESULT_OK) { return ret; }
+  } else {
+    if (!(d->status_flag & STATUS_WAVE_FORMAT) || !(d->status_flag & STATUS_ENCODE_PARAM)) { return SLA_APIRESULT_PARAMETER_NOT_SET; }
+    memset(&header, 0, sizeof(header));
+    header.wave_format = d->wave_format; header.encode_param = d->encode_param;
+    header.num_samples = 1;               /* the walk stops behind the first block */
+    off = 0; *one_block_size = 0;
+  }
   C = header.wave_format.num_channels; total = header.num_samples;
   bps = header.wave_format.bit_per_sample; lshift = header.wave_format.offset_lshift;
   order = header.encode_param.parcor_order; ntaps = header.encode_param.longterm_order;
@@ -279,6 +291,7 @@ static SLAApiResult decode_run(struct SLADecoder* d, const uint8_t* data, uint32
       if (in->type > 2) { result = SLA_APIRESULT_INVALID_HEADER_FORMAT; break; }
       if (in->type == 0 && !lms_ok) { result = SLA_APIRESULT_FAILED_TO_SYNTHESIZE; break; }
       done_samples = b->smp_off + b->num_samples;
+      if (one_block_size != NULL) { *one_block_size = in->used_bytes; break; }     /* src/SLADecoder.c:651 */
       if (in->used_bytes != b->byte_len) {
         /* the body did not end where the size field says: the reference continues from where its reader stopped (:715) */
         off = (uint32_t)b->byte_off + in->used_bytes; pos = done_samples; resync = 1;
@@ -316,7 +329,7 @@ SLAApiResult SLADecoder_DecodeWhole(struct SLADecoder* decoder, const uint8_t* d
                                     int32_t** buffer, uint32_t buffer_num_samples, uint32_t* output_num_samples)
 {
   if (decoder == NULL || buffer == NULL || data == NULL || output_num_samples == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
-  return decode_run(decoder, data, data_size, NULL, NULL, 0, buffer, buffer_num_samples, output_num_samples);
+  return decode_run(decoder, data, data_size, NULL, NULL, 0, buffer, buffer_num_samples, output_num_samples, NULL);
 }
 
 SLAApiResult sla_hip_decode_device(struct SLADecoder* decoder, const uint8_t* host_data, const uint32_t* d_image,
@@ -325,7 +338,7 @@ SLAApiResult sla_hip_decode_device(struct SLADecoder* decoder, const uint8_t* ho
 {
   if (decoder == NULL || host_data == NULL || d_image == NULL || d_planes == NULL || output_num_samples == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   return decode_run(decoder, host_data, data_size, d_image, d_planes, plane_stride, NULL,
-                    (plane_stride > 0xFFFFFFFFull) ? 0xFFFFFFFFu : (uint32_t)plane_stride, output_num_samples);
+                    (plane_stride > 0xFFFFFFFFull) ? 0xFFFFFFFFu : (uint32_t)plane_stride, output_num_samples, NULL);
 }
 
 int sla_hip_decoder_last_timing(const struct SLADecoder* decoder, float* timing_ms)
@@ -333,4 +346,225 @@ int sla_hip_decoder_last_timing(const struct SLADecoder* decoder, float* timing_
   if (decoder == NULL || timing_ms == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   memcpy(timing_ms, decoder->timing, sizeof(decoder->timing));
   return 0;
+}
+
+/* One block that starts at data[0]: its samples, its sample count and the bytes it occupied. */
+static SLAApiResult decode_one_block(struct SLADecoder* d, const uint8_t* data, uint32_t data_size, int32_t** buffer,
+                                     uint32_t buffer_num_samples, uint32_t* block_size, uint32_t* num_samples)
+{
+  return decode_run(d, data, data_size, NULL, NULL, 0, buffer, buffer_num_samples, num_samples, block_size);
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Streaming decoder (reference src/SLADecoder.c:735-1123): the caller appends fragments of the stream and draws
+ * ceil(1.05 * sampling_rate / decode_interval_hz) samples per call.  Same entry points, same packet bookkeeping
+ * (up to 8 fragments referenced in place, copied into a block buffer of twice the largest possible block as room
+ * allows, handed back through CollectDataFragment).  The unit of device work is a whole block: a block is decoded
+ * (one SLADecoder block decode on the device) as soon as all its bytes are in the buffer, and calls are served
+ * from its samples.  Where the reference would start on a block whose tail has not arrived yet, this decoder
+ * returns the samples it has (possibly none) with SLA_APIRESULT_OK and continues once the rest has been appended.
+ * ------------------------------------------------------------------------------------------------------------ */
+#define STREAM_MAX_PACKETS 8              /* SLA_STREAMING_DECODE_MAX_NUM_PACKETS */
+#define STREAM_MARGIN      1.05f          /* SLA_STREAMING_DECODE_NUM_SAMPLES_MARGIN */
+
+typedef struct { const uint8_t* data; uint32_t size, used; } packet_t;
+
+struct SLAStreamingDecoder {
+  struct SLADecoder* core;
+  float     decode_interval_hz;
+  uint32_t  max_bit_per_sample;
+  uint32_t  samples_per_decode;
+  float     bytes_per_sample;                 /* estimate, refreshed by every block header */
+  uint8_t*  data; uint32_t data_cap, data_size;
+  packet_t  packets[STREAM_MAX_PACKETS];
+  uint32_t  write_pos, read_pos, collect_pos, free_packets;
+  int32_t*  cache[SLAI_MAX_CHANNELS];         /* samples of the current block */
+  uint32_t  cache_cap, cache_n, cache_pos;
+  uint32_t  cur_block_size;
+};
+
+struct SLAStreamingDecoder* SLAStreamingDecoder_Create(const struct SLAStreamingDecoderConfig* config)
+{
+  struct SLAStreamingDecoder* s;
+  uint32_t ch;
+  if (config == NULL || config->decode_interval_hz <= 0.0f) { return NULL; }
+  s = (struct SLAStreamingDecoder*)calloc(1, sizeof(*s));
+  if (s == NULL) { return NULL; }
+  s->core = SLADecoder_Create(&config->core_config);
+  if (s->core == NULL) { free(s); return NULL; }
+  s->decode_interval_hz = config->decode_interval_hz;
+  s->max_bit_per_sample = config->max_bit_per_sample;
+  s->data_cap = 2u * SLA_CalculateSufficientBlockSize(config->core_config.max_num_channels, config->core_config.max_num_block_samples,
+                                                      config->max_bit_per_sample);
+  if (s->data_cap < 64) { s->data_cap = 64; }
+  s->data = (uint8_t*)calloc(s->data_cap, 1);
+  s->cache_cap = config->core_config.max_num_block_samples;
+  for (ch = 0; ch < config->core_config.max_num_channels; ch++) { s->cache[ch] = (int32_t*)malloc(sizeof(int32_t) * (s->cache_cap + 1)); }
+  s->bytes_per_sample = (float)((double)config->core_config.max_num_channels * (config->max_bit_per_sample / 8));
+  s->free_packets = STREAM_MAX_PACKETS;
+  if (s->data == NULL) { SLAStreamingDecoder_Destroy(s); return NULL; }
+  for (ch = 0; ch < config->core_config.max_num_channels; ch++) { if (s->cache[ch] == NULL) { SLAStreamingDecoder_Destroy(s); return NULL; } }
+  return s;
+}
+
+void SLAStreamingDecoder_Destroy(struct SLAStreamingDecoder* s)
+{
+  uint32_t ch;
+  if (s == NULL) { return; }
+  SLADecoder_Destroy(s->core);
+  for (ch = 0; ch < SLAI_MAX_CHANNELS; ch++) { free(s->cache[ch]); }
+  free(s->data);
+  free(s);
+}
+
+SLAApiResult SLAStreamingDecoder_SetWaveFormat(struct SLAStreamingDecoder* s, const struct SLAWaveFormat* wave_format)
+{
+  SLAApiResult ret;
+  if (s == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if ((ret = SLADecoder_SetWaveFormat(s->core, wave_format)) != SLA_APIRESULT_OK) { return ret; }
+  if (wave_format->bit_per_sample > s->max_bit_per_sample) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
+  s->samples_per_decode = (uint32_t)ceil(STREAM_MARGIN * (float)wave_format->sampling_rate / s->decode_interval_hz);
+  return SLA_APIRESULT_OK;
+}
+
+SLAApiResult SLAStreamingDecoder_SetEncodeParameter(struct SLAStreamingDecoder* s, const struct SLAEncodeParameter* encode_param)
+{
+  if (s == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  return SLADecoder_SetEncodeParameter(s->core, encode_param);
+}
+
+SLAApiResult SLAStreamingDecoder_EstimateMinimumNessesaryDataSize(struct SLAStreamingDecoder* s, uint32_t* estimate_data_size)
+{
+  uint32_t v;
+  if (s == NULL || estimate_data_size == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  v = (uint32_t)ceil((double)s->bytes_per_sample * s->samples_per_decode);
+  *estimate_data_size = (v > DEC_MIN_BLOCK_HEADER) ? v : DEC_MIN_BLOCK_HEADER;
+  return SLA_APIRESULT_OK;
+}
+
+static uint32_t queue_remain(const struct SLAStreamingDecoder* s)
+{
+  uint32_t pos, size = 0;
+  if (s->free_packets == STREAM_MAX_PACKETS) { return 0; }
+  pos = s->read_pos;
+  do {
+    size += s->packets[pos].size - s->packets[pos].used;
+    pos = (pos + 1) % STREAM_MAX_PACKETS;
+  } while (pos != s->write_pos);
+  return size;
+}
+
+SLAApiResult SLAStreamingDecoder_GetRemainDataSize(struct SLAStreamingDecoder* s, uint32_t* remain_data_size)
+{
+  uint32_t inside = 0;
+  if (s == NULL || remain_data_size == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  /* the reference consumes a block's bytes as it hands its samples out; here the block is decoded at once, so the
+   * share of its bytes that belongs to the samples still waiting is counted as remaining */
+  if (s->cache_n > s->cache_pos && s->cache_n > 0) {
+    inside = (uint32_t)(((uint64_t)s->cur_block_size * (s->cache_n - s->cache_pos)) / s->cache_n);
+  }
+  *remain_data_size = queue_remain(s) + s->data_size + inside;
+  return SLA_APIRESULT_OK;
+}
+
+SLAApiResult SLAStreamingDecoder_EstimateDecodableNumSamples(struct SLAStreamingDecoder* s, uint32_t* estimate_num_samples)
+{
+  uint32_t remain;
+  SLAApiResult ret;
+  if (s == NULL || estimate_num_samples == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if ((ret = SLAStreamingDecoder_GetRemainDataSize(s, &remain)) != SLA_APIRESULT_OK) { return ret; }
+  *estimate_num_samples = (uint32_t)floor((float)remain / s->bytes_per_sample);
+  return SLA_APIRESULT_OK;
+}
+
+SLAApiResult SLAStreamingDecoder_GetOutputNumSamplesPerDecode(struct SLAStreamingDecoder* s, uint32_t* output_num_samples)
+{
+  if (s == NULL || output_num_samples == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  *output_num_samples = s->samples_per_decode;
+  return SLA_APIRESULT_OK;
+}
+
+/* queued fragments -> block buffer, as far as there is room */
+static void stream_pull(struct SLAStreamingDecoder* s)
+{
+  while (s->free_packets != STREAM_MAX_PACKETS && s->data_size < s->data_cap) {
+    packet_t* p = &s->packets[s->read_pos];
+    uint32_t take;
+    if (s->read_pos == s->write_pos && p->size == p->used) { break; }
+    take = p->size - p->used;
+    if (take > s->data_cap - s->data_size) { take = s->data_cap - s->data_size; }
+    memcpy(s->data + s->data_size, p->data + p->used, take);
+    s->data_size += take; p->used += take;
+    if (p->used == p->size) { s->read_pos = (s->read_pos + 1) % STREAM_MAX_PACKETS; }
+    if (take == 0) { break; }
+  }
+}
+
+SLAApiResult SLAStreamingDecoder_AppendDataFragment(struct SLAStreamingDecoder* s, const uint8_t* data, uint32_t data_size)
+{
+  if (s == NULL || data == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (s->free_packets == 0) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
+  if (data_size != 0) {
+    packet_t* p = &s->packets[s->write_pos];
+    p->data = data; p->size = data_size; p->used = 0;
+    s->write_pos = (s->write_pos + 1) % STREAM_MAX_PACKETS;
+    s->free_packets--;
+  }
+  stream_pull(s);
+  return SLA_APIRESULT_OK;
+}
+
+SLAApiResult SLAStreamingDecoder_CollectDataFragment(struct SLAStreamingDecoder* s, const uint8_t** data_ptr, uint32_t* data_size)
+{
+  packet_t* p;
+  if (s == NULL || data_ptr == NULL || data_size == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (s->free_packets == STREAM_MAX_PACKETS) { return SLA_APIRESULT_NO_DATA_FRAGMENTS; }
+  p = &s->packets[s->collect_pos];
+  if (p->used == 0) { return SLA_APIRESULT_NO_DATA_FRAGMENTS; }
+  *data_ptr = p->data; *data_size = p->used;
+  p->size -= p->used; p->data += p->used; p->used = 0;
+  if (p->size == 0) { s->collect_pos = (s->collect_pos + 1) % STREAM_MAX_PACKETS; s->free_packets++; }
+  return SLA_APIRESULT_OK;
+}
+
+SLAApiResult SLAStreamingDecoder_Decode(struct SLAStreamingDecoder* s, int32_t** buffer, uint32_t buffer_num_samples,
+                                        uint32_t* num_output_samples)
+{
+  uint32_t goal, progress = 0, ch;
+  const uint32_t C = (s != NULL) ? s->core->wave_format.num_channels : 0;
+  if (s == NULL || buffer == NULL || num_output_samples == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  goal = (buffer_num_samples < s->samples_per_decode) ? buffer_num_samples : s->samples_per_decode;
+  while (progress < goal) {
+    uint32_t take;
+    if (s->cache_pos >= s->cache_n) {
+      /* next block: header fields first (src/SLADecoder.c:1031-1049), then the whole block once it is here */
+      uint32_t bsize, nsmpl = 0, used = 0;
+      SLAApiResult ret;
+      stream_pull(s);
+      if (!(s->core->status_flag & STATUS_WAVE_FORMAT) || !(s->core->status_flag & STATUS_ENCODE_PARAM)) { return SLA_APIRESULT_PARAMETER_NOT_SET; }
+      if (s->data_size < DEC_MIN_BLOCK_HEADER) {
+        if (progress > 0) { break; }
+        return SLA_APIRESULT_INSUFFICIENT_DATA_SIZE;
+      }
+      if (rd_be16(s->data) != SLAI_SYNC_CODE) { return SLA_APIRESULT_FAILED_TO_FIND_SYNC_CODE; }
+      bsize = rd_be32(s->data + 2) + 6u;
+      if (bsize > s->data_size) { break; }                      /* the rest of the block has not been appended yet */
+      ret = decode_one_block(s->core, s->data, s->data_size, s->cache, s->cache_cap, &used, &nsmpl);
+      if (ret != SLA_APIRESULT_OK) { return ret; }
+      if (used == 0 || used > s->data_size) { return SLA_APIRESULT_NG; }
+      s->bytes_per_sample = (nsmpl > 0) ? (float)((double)bsize / nsmpl) : s->bytes_per_sample;
+      s->cur_block_size = bsize;
+      memmove(s->data, s->data + used, s->data_size - used);      /* src/SLADecoder.c:1086-1092 */
+      s->data_size -= used;
+      s->cache_n = nsmpl; s->cache_pos = 0;
+      stream_pull(s);
+      if (nsmpl == 0) { continue; }
+    }
+    take = s->cache_n - s->cache_pos;
+    if (take > goal - progress) { take = goal - progress; }
+    for (ch = 0; ch < C; ch++) { memcpy(buffer[ch] + progress, s->cache[ch] + s->cache_pos, sizeof(int32_t) * take); }
+    s->cache_pos += take; progress += take;
+  }
+  *num_output_samples = progress;
+  return SLA_APIRESULT_OK;
 }

@@ -276,8 +276,8 @@ def test_argument_checks(hip):
         assert L.SLADecoder_SetEncodeParameter(None, None) == 2
     finally:
         dec.close()
-    for bad in (dict(max_num_channels=9), dict(max_num_block_samples=32768), dict(max_lms_order_per_filter=64),
-                dict(max_longterm_order=7), dict(max_parcor_order=256)):
+    for bad in (dict(max_num_channels=9), dict(max_num_block_samples=32768), dict(max_longterm_order=7),
+                dict(max_parcor_order=256)):
         with pytest.raises(RuntimeError):
             hip.Decoder(**bad)
 
@@ -310,6 +310,87 @@ def test_handle_is_reusable_and_crc_check_can_be_switched_off(oracle, hip):
         assert rc == 0 and np.array_equal(got, short)
     finally:
         dec.close()
+
+
+# ------------------------------------------------------------------ streaming decoder
+
+@pytest.mark.parametrize("cfg", [(1, 16, 48000, 16, 1, 8, 0, 4096), (2, 24, 44100, 32, 3, 8, 1, 12288), (8, 16, 96000, 8, 1, 4, 0, 2048)])
+@pytest.mark.parametrize("hz", [120.0, 30.0, 1000.0])
+def test_streaming_decoder_fed_like_the_reference_cli(oracle, hip, cfg, hz):
+    """src/main.c:277-420: first the largest block's worth of bytes, then the estimate per call -> the PCM of DecodeWhole"""
+    nch, bits, rate, order, ltm, lms, ms, mb = cfg
+    n = 40000
+    pcm = W.music_like(nch, n, bits, seed=int(hz))
+    pcm[:, 9000:13000] = 0                                # a silent block on the way
+    p = S.make_params(nch, bits, rate, order, ltm, lms, ms, 1, mb)
+    data = encode(oracle, p, pcm)
+    rc, got, calls = hip.streaming_decode(data, decode_interval_hz=hz)
+    assert rc == 0 and np.array_equal(got, pcm)
+    per_call = int(np.ceil(np.float32(1.05) * np.float32(rate) / np.float32(hz)))
+    assert calls >= -(-n // per_call)
+
+
+@pytest.mark.parametrize("chunk", [1, 7, 64, 1000, 100000])
+def test_streaming_decoder_with_arbitrary_fragments(oracle, hip, chunk):
+    pcm = W.music_like(2, 20000, 16, seed=chunk)
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096)
+    data = encode(oracle, p, pcm)
+    rc, got, calls = hip.streaming_decode(data, feed=lambda i: chunk)
+    assert rc == 0 and np.array_equal(got, pcm)
+
+
+def test_streaming_decoder_bookkeeping_and_errors(oracle, hip):
+    import ctypes as C
+    L = hip.lib()
+    pcm = W.music_like(1, 12000, 16, seed=3)
+    p = S.make_params(1, 16, 48000, 8, 1, 4, 0, 1, 4096)
+    data = np.frombuffer(encode(oracle, p, pcm), np.uint8)
+    rc, h = hip.decode_header(data)
+    u8p, u32p, i32p = hip.u8p, hip.u32p, hip.i32p
+    assert L.SLAStreamingDecoder_Create(None) is None
+    bad = hip.SLAStreamingDecoderConfig(hip.SLADecoderConfig(1, 4096, 8, 1, 4, 1, 0), 0.0, 16)
+    assert L.SLAStreamingDecoder_Create(C.byref(bad)) is None
+    cfg = hip.SLAStreamingDecoderConfig(hip.SLADecoderConfig(1, 4096, 8, 1, 4, 1, 0), 100.0, 16)
+    dec = L.SLAStreamingDecoder_Create(C.byref(cfg))
+    assert dec
+    try:
+        out = np.zeros(20000, np.int32)
+        ptrs = (i32p * 1)(out.ctypes.data_as(i32p))
+        got, v = C.c_uint32(0), C.c_uint32(0)
+        assert L.SLAStreamingDecoder_Decode(dec, ptrs, 20000, C.byref(got)) == 15             # parameters not set
+        wf24 = hip.SLAWaveFormat(1, 24, 48000, 0)
+        assert L.SLAStreamingDecoder_SetWaveFormat(dec, C.byref(wf24)) == 3                 # deeper than max_bit_per_sample
+        assert L.SLAStreamingDecoder_SetWaveFormat(dec, C.byref(h.wave_format)) == 0
+        assert L.SLAStreamingDecoder_SetEncodeParameter(dec, C.byref(h.encode_param)) == 0
+        assert L.SLAStreamingDecoder_GetOutputNumSamplesPerDecode(dec, C.byref(v)) == 0 and v.value == 504   # ceil(1.05 * 48000 / 100)
+        assert L.SLAStreamingDecoder_EstimateMinimumNessesaryDataSize(dec, C.byref(v)) == 0 and v.value == 504 * 2   # 1 ch x 16 bit before any block
+        assert L.SLAStreamingDecoder_Decode(dec, ptrs, 20000, C.byref(got)) == 9              # nothing appended yet
+        body = data[43:]
+        # nine fragments: the ninth does not fit the queue of eight
+        for i in range(8):
+            assert L.SLAStreamingDecoder_AppendDataFragment(dec, body[i * 10:].ctypes.data_as(u8p), 10) == 0
+        assert L.SLAStreamingDecoder_GetRemainDataSize(dec, C.byref(v)) == 0 and v.value == 80
+        assert L.SLAStreamingDecoder_AppendDataFragment(dec, body[80:].ctypes.data_as(u8p), 10) == 3
+        ptr, size = u8p(), C.c_uint32(0)
+        for i in range(8):
+            assert L.SLAStreamingDecoder_CollectDataFragment(dec, C.byref(ptr), C.byref(size)) == 0 and size.value == 10
+        assert L.SLAStreamingDecoder_CollectDataFragment(dec, C.byref(ptr), C.byref(size)) == 14   # no data fragments
+        assert L.SLAStreamingDecoder_Decode(dec, ptrs, 20000, C.byref(got)) == 0 and got.value == 0   # a block header, not yet the block
+        assert L.SLAStreamingDecoder_AppendDataFragment(dec, body[80:].ctypes.data_as(u8p), len(body) - 80) == 0
+        done = 0
+        while done < 12000:
+            ptrs = (i32p * 1)(out[done:].ctypes.data_as(i32p))
+            assert L.SLAStreamingDecoder_Decode(dec, ptrs, 12000 - done, C.byref(got)) == 0
+            assert got.value == min(504, 12000 - done)
+            done += got.value
+        assert np.array_equal(out[:12000], pcm[0])
+        assert L.SLAStreamingDecoder_EstimateDecodableNumSamples(dec, C.byref(v)) == 0 and v.value == 0
+        junk = np.full(64, 0x55, np.uint8)
+        assert L.SLAStreamingDecoder_AppendDataFragment(dec, junk.ctypes.data_as(u8p), 64) == 0
+        assert L.SLAStreamingDecoder_Decode(dec, ptrs, 100, C.byref(got)) == 12            # no sync code
+        assert L.SLAStreamingDecoder_Decode(None, ptrs, 100, C.byref(got)) == 2
+    finally:
+        L.SLAStreamingDecoder_Destroy(dec)
 
 
 # ------------------------------------------------------------------ the codec end to end on the device
