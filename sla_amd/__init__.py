@@ -472,6 +472,8 @@ def streaming_decode(data, decode_interval_hz=120.0, feed=None, max_bit_per_samp
             ptrs = (i32p * nch)(*[out[c, sample_pos:].ctypes.data_as(i32p) for c in range(nch)])
             rc = L.SLAStreamingDecoder_Decode(dec, ptrs, total - sample_pos, C.byref(got))
             calls += 1
+            if rc == 9 and data_pos + put < len(buf):         # not even a block header yet: keep feeding
+                rc, got.value = 0, 0
             if rc != 0:
                 return rc, out[:, :sample_pos], calls
             L.SLAStreamingDecoder_CollectDataFragment(dec, C.byref(dummy_p), C.byref(dummy_n))
