@@ -533,6 +533,7 @@ SLAApiResult SLAStreamingDecoder_Decode(struct SLAStreamingDecoder* s, int32_t**
   uint32_t goal, progress = 0, ch;
   const uint32_t C = (s != NULL) ? s->core->wave_format.num_channels : 0;
   if (s == NULL || buffer == NULL || num_output_samples == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (!(s->core->status_flag & STATUS_WAVE_FORMAT) || !(s->core->status_flag & STATUS_ENCODE_PARAM)) { return SLA_APIRESULT_PARAMETER_NOT_SET; }
   goal = (buffer_num_samples < s->samples_per_decode) ? buffer_num_samples : s->samples_per_decode;
   while (progress < goal) {
     uint32_t take;
@@ -541,7 +542,6 @@ SLAApiResult SLAStreamingDecoder_Decode(struct SLAStreamingDecoder* s, int32_t**
       uint32_t bsize, nsmpl = 0, used = 0;
       SLAApiResult ret;
       stream_pull(s);
-      if (!(s->core->status_flag & STATUS_WAVE_FORMAT) || !(s->core->status_flag & STATUS_ENCODE_PARAM)) { return SLA_APIRESULT_PARAMETER_NOT_SET; }
       if (s->data_size < DEC_MIN_BLOCK_HEADER) {
         if (progress > 0) { break; }
         return SLA_APIRESULT_INSUFFICIENT_DATA_SIZE;
