@@ -707,7 +707,7 @@ def _full_length_check(oracle, hip, p, cap, nch, n, bits, rate, prefix_frames):
     enc = hip.Encoder(*cap)
     enc.set_wave_format(nch, bits, rate)
     enc.set_encode_parameter(p.parcor_order, p.longterm_order, p.lms_order, p.ch_process_method, p.window_type, p.max_block_samples)
-    out = np.zeros(4 * nch * n + 65536, np.uint8)
+    out = np.zeros(min(4 * nch * n + 65536, 0xFFFFFFF0), np.uint8)      # the API's sizes are 32-bit
     data = enc.encode_whole(pcm, out=out)
     t2 = time.time()
     enc.close()
