@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--sync-gather", action="store_true", help="N > 1: wait for each step's all-gather before the next step starts")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--clips", type=int, default=125, help="C4 only: clips per GPU and step (1000 clips over 8 GPUs)")
     args = ap.parse_args()
 
     import torch
@@ -76,11 +77,28 @@ def main():
     if args.seconds is not None:
         seconds = args.seconds
     n = int(rate * seconds)
-    # every rank encodes its own, different shard (seed by rank)
-    pcm = S.synth_pcm(nch, n, bits, rate, seed=12345 + rank)
-    stride = (n + 63) // 64 * 64
-    d_pcm = torch.zeros((nch, stride), dtype=torch.int32, device="cuda")
-    d_pcm[:, :n] = torch.from_numpy(pcm).cuda()
+    batch = None
+    if args.config == "C4":
+        # a batch of clips per step (BASELINE config 3: 1000 clips over 8 GPUs), laid out back to back on
+        # 1024-sample boundaries and analysed in ONE pipeline pass (sla_hip_analyze_batch_device)
+        clip_n, tile = n, 1024
+        pitch = (clip_n + tile - 1) // tile * tile
+        distinct = [S.synth_pcm(nch, clip_n, bits, rate, seed=4000 + 16 * rank + k) for k in range(min(16, args.clips))]
+        clips = [distinct[k % len(distinct)] for k in range(args.clips)]
+        batch = {"starts": np.arange(args.clips, dtype=np.uint32) * pitch, "lens": np.full(args.clips, clip_n, np.uint32),
+                 "clips": clips, "span": args.clips * pitch}
+        n = clip_n * args.clips                          # samples per channel that are audio
+        stride = batch["span"]
+        d_pcm = torch.zeros((nch, stride), dtype=torch.int32, device="cuda")
+        for k, c in enumerate(clips):
+            d_pcm[:, k * pitch:k * pitch + clip_n] = torch.from_numpy(c).cuda()
+        pcm = None
+    else:
+        # every rank encodes its own, different shard (seed by rank)
+        pcm = S.synth_pcm(nch, n, bits, rate, seed=12345 + rank)
+        stride = (n + 63) // 64 * 64
+        d_pcm = torch.zeros((nch, stride), dtype=torch.int32, device="cuda")
+        d_pcm[:, :n] = torch.from_numpy(pcm).cuda()
     # N > 1 over RCCL: the all-gather of one step's residual planes travels while the next step is analysed into
     # a second set of planes (two sets take turns), so the collective over xGMI and the kernels overlap
     overlap = (world > 1 and args.backend == "nccl" and not args.sync_gather)
@@ -112,7 +130,10 @@ def main():
         settle(b)                                             # the planes of two steps ago have been gathered
         if nbuf > 1:
             enc.bind_residual_planes(d_lat[b].data_ptr(), d_fin[b].data_ptr(), stride)
-        t = enc.analyze_device(d_pcm.data_ptr(), stride, n)
+        if batch is not None:
+            t, _ = enc.analyze_batch_device(d_pcm.data_ptr(), stride, batch["span"], batch["starts"], batch["lens"])
+        else:
+            t = enc.analyze_device(d_pcm.data_ptr(), stride, n)
         span_ms[:] += np.array(enc.last_kernel_ms())
         if world > 1:
             if overlap:
@@ -155,7 +176,8 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64+int32",
         "data": "synthetic",
-        "config": {"workload": WORKLOAD_NAME[args.config] + (" x%d ranks" % world if world > 1 else ""),
+        "config": {"workload": WORKLOAD_NAME[args.config] + (", batch of %d clips per GPU in one pass" % args.clips if batch else "")
+                               + (" x%d ranks" % world if world > 1 else ""),
                    "name": args.config, "channels": nch, "bits": bits, "rate": rate, "seconds": seconds,
                    "parcor_order": order, "longterm_order": ltm, "lms_order": lms,
                    "max_block_samples": maxb, "samples_per_step_per_gpu": n * nch,
@@ -215,7 +237,22 @@ def main():
         out["device"] = sla_amd.device_name()
 
         # ---- end-to-end .sla encode from host PCM (PCIe + host bit-pack included); never `value` ------
-        if not args.no_e2e and world == 1:
+        if not args.no_e2e and world == 1 and batch is not None:
+            enc2 = sla_amd.Encoder(*cap)
+            enc2.set_wave_format(nch, bits, rate)
+            enc2.set_encode_parameter(order, ltm, lms, ms, win, maxb)
+            outs = [np.zeros(4 * nch * int(l) + 65536, np.uint8) for l in batch["lens"]]
+            got = enc2.encode_batch(batch["clips"], outs=outs)
+            reps = 3
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                got = enc2.encode_batch(batch["clips"], outs=outs)
+            e2e = (time.perf_counter() - t1) / reps
+            out["end_to_end"] = {"msamples_s": round(n * nch / e2e / 1e6, 3), "samples": n * nch,
+                                 "sla_bytes": int(sum(len(d) for _, d in got)), "files_ok": int(sum(1 for rc, _ in got if rc == 0)),
+                                 "note": "sla_hip_encode_batch: pageable host PCM of every clip -> its own .sla bytes incl. PCIe both ways"}
+            enc2.close()
+        if not args.no_e2e and world == 1 and batch is None:
             enc2 = sla_amd.Encoder(*cap)
             enc2.set_wave_format(nch, bits, rate)
             enc2.set_encode_parameter(order, ltm, lms, ms, win, maxb)
@@ -254,15 +291,25 @@ def main():
             p = S.make_params(nch, bits, rate, order, ltm, lms, ms, win, maxb, cap=cap)
             ref = S.ref()
             checker, kind = (ref, "reference") if ref is not None else (S.oracle(), "port")
-            m = min(n, int(rate * 600 / nch))            # about 10-30 s of single-thread CPU work
-            sub = np.ascontiguousarray(pcm[:, :m])
-            t1 = time.perf_counter()
-            ret, data = checker.encode_whole(p, sub)
-            cpu_s = time.perf_counter() - t1
-            assert ret == 0
+            if batch is not None:                        # clip by clip, like the reference CLI would: the first 24 clips
+                k = min(24, len(batch["clips"]))
+                m = int(batch["lens"][0]) * k
+                t1 = time.perf_counter()
+                for c in batch["clips"][:k]:
+                    ret, data = checker.encode_whole(p, c)
+                    assert ret == 0
+                cpu_s = time.perf_counter() - t1
+            else:
+                m = min(n, int(rate * 600 / nch))            # about 10-30 s of single-thread CPU work
+                sub = np.ascontiguousarray(pcm[:, :m])
+                t1 = time.perf_counter()
+                ret, data = checker.encode_whole(p, sub)
+                cpu_s = time.perf_counter() - t1
+                assert ret == 0
             out["cpu_baseline"] = {"value": round(m * nch / cpu_s / 1e6, 3), "unit": "Msamples/s", "cores": 1,
                                    "kind": kind, "seconds": round(cpu_s, 2),
-                                   "sample": "first %d samples x %d ch of the same workload, full single-thread "
+                                   "sample": ("first %d clips, one after the other; " % min(24, len(batch["clips"])) if batch is not None else "")
+                                             + "first %d samples x %d ch of the same workload, full single-thread "
                                              "EncodeWhole (%s)" % (m, nch, "unmodified reference, oracle/_ref"
                                                                    if kind == "reference" else "oracle restatement")}
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)

@@ -363,6 +363,14 @@ typedef struct sla_hip_batch_item {
   int32_t  result;                 /* out: SLAApiResult of this file */
 } sla_hip_batch_item;
 int sla_hip_encode_batch(struct SLAEncoder* encoder, sla_hip_batch_item* items, uint32_t num_items);
+/* The analysis of such a batch when the planes already live in device memory ([C][plane_stride] int32, files at
+ * file_start[i] -- multiples of SLA_HIP_PREPASS_TILE, ascending, gaps zero -- of file_samples[i] samples, all inside
+ * [0, span)): the batch counterpart of sla_hip_analyze_device.  file_lshift (may be NULL) receives every file's
+ * offset_lshift; files that share a value share a pipeline pass.  After a single pass sla_hip_get_trace describes the
+ * blocks of all files (positions relative to the planes). */
+int sla_hip_analyze_batch_device(struct SLAEncoder* encoder, const int32_t* d_pcm, uint64_t plane_stride, uint32_t span,
+                                 const uint32_t* file_start, const uint32_t* file_samples, uint32_t num_files,
+                                 uint32_t* file_lshift, float* timing_ms);
 
 /* Device pointers of the last analysis (for RCCL gathers / tests). */
 const int32_t* sla_hip_final_residual(const struct SLAEncoder* encoder, uint64_t* plane_stride);

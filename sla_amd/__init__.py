@@ -134,6 +134,8 @@ def lib():
         L.sla_hip_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.sla_hip_search_exact_lags.restype = C.c_uint32
         L.sla_hip_encode_batch.argtypes = [C.c_void_p, C.POINTER(BatchItem), C.c_uint32]
+        L.sla_hip_analyze_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, u32p, u32p, C.c_uint32,
+                                                   u32p, C.POINTER(C.c_float)]
         L.SLADecoder_Create.restype = C.c_void_p
         L.SLADecoder_Create.argtypes = [C.POINTER(SLADecoderConfig)]
         L.SLADecoder_Destroy.argtypes = [C.c_void_p]
@@ -187,7 +189,7 @@ EXPORTED_SYMBOLS = [
     "SLADecoder_DecodeHeader", "SLADecoder_Create", "SLADecoder_Destroy", "SLADecoder_SetWaveFormat",
     "SLADecoder_SetEncodeParameter", "SLADecoder_DecodeWhole", "sla_hip_decoder_last_timing", "sla_hip_decode_device",
     "sla_hip_launch_dec_bits", "sla_hip_launch_dec_lms", "sla_hip_launch_dec_ltm", "sla_hip_launch_dec_lattice",
-    "sla_hip_launch_dec_finish", "sla_hip_launch_prepass_tiles", "sla_hip_encode_batch",
+    "sla_hip_launch_dec_finish", "sla_hip_launch_prepass_tiles", "sla_hip_encode_batch", "sla_hip_analyze_batch_device",
     "SLAStreamingDecoder_Create", "SLAStreamingDecoder_Destroy", "SLAStreamingDecoder_SetWaveFormat",
     "SLAStreamingDecoder_SetEncodeParameter", "SLAStreamingDecoder_EstimateMinimumNessesaryDataSize",
     "SLAStreamingDecoder_EstimateDecodableNumSamples", "SLAStreamingDecoder_GetOutputNumSamplesPerDecode",
@@ -340,6 +342,19 @@ class Encoder:
                     "sla_hip_analyze_device")
         self.num_samples = num_samples
         return list(timing)
+
+    def analyze_batch_device(self, device_ptr, plane_stride, span, starts, lens):
+        """hot path on a batch of files resident in HBM (files at starts[i], multiples of 1024); returns
+        (the 12 stage timings [ms], offset_lshift per file)"""
+        st = np.ascontiguousarray(starts, np.uint32)
+        ln = np.ascontiguousarray(lens, np.uint32)
+        lsh = np.zeros(len(st), np.uint32)
+        timing = (C.c_float * 12)()
+        self._check(self._lib.sla_hip_analyze_batch_device(self._h, C.c_void_p(device_ptr), plane_stride, span,
+                                                           st.ctypes.data_as(u32p), ln.ctypes.data_as(u32p), len(st),
+                                                           lsh.ctypes.data_as(u32p), timing), "sla_hip_analyze_batch_device")
+        self.num_samples = span
+        return list(timing), lsh
 
     def last_timing(self):
         """the 12 stage timings / counters of the last analysis (see include/sla_hip.h)"""

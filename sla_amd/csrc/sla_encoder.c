@@ -1989,15 +1989,55 @@ static int upload_batch_pass(struct SLAEncoder* e, const sla_hip_batch_item* ite
 
 #define BATCH_MAX_SPAN (1u << 28)        /* samples per channel in one pass: C x 1 GiB of planes (x3 with the residuals) */
 
+/* Prepass over planes that hold `count` files back to back: the silence mask of everything on the host, and per file
+ * the OR of its samples (from the 1024-sample tiles) and its offset_lshift (src/SLAEncoder.c:425-455; 0xFFFFFFFF:
+ * samples wider than the declared depth). */
+static int batch_prepass(struct SLAEncoder* e, uint64_t span, const uint32_t* start, const uint32_t* len, uint32_t count,
+                         uint32_t* lsh, uint32_t* orv)
+{
+  const uint32_t C = e->wave_format.num_channels, bps = e->wave_format.bit_per_sample;
+  const uint32_t ms = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
+  const uint64_t nwords = (span + 63) / 64;
+  const uint32_t ntiles = (uint32_t)((span + 4 * SLA_HIP_PREPASS_TILE - 1) / (4 * SLA_HIP_PREPASS_TILE) * 4);
+  const uint32_t* tile_or;
+  uint32_t i;
+  RCCHK(dev_reserve(&e->d_or, 64));
+  RCCHK(dev_reserve(&e->d_nz, (size_t)(nwords + 2) * 8));
+  RCCHK(pin_reserve(&e->h_nz, (size_t)(nwords + 2) * 8));
+  RCCHK(dev_reserve(&e->d_tile_or, sizeof(uint32_t) * ((size_t)ntiles + 4)));
+  RCCHK(pin_reserve(&e->h_tile_or, sizeof(uint32_t) * ((size_t)ntiles + 4)));
+  HIPCHK(hipEventRecord(e->ev[0], e->stream));
+  RCCHK(sla_hip_launch_prepass_tiles(e->pcm_dev, e->stride, C, (uint32_t)span, bps, ms, (uint32_t*)e->d_or.ptr, (uint64_t*)e->d_nz.ptr,
+                                     (uint32_t*)e->d_tile_or.ptr, e->stream));
+  HIPCHK(hipEventRecord(e->ev[1], e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_nz.ptr, e->d_nz.ptr, (size_t)nwords * 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_tile_or.ptr, e->d_tile_or.ptr, sizeof(uint32_t) * ntiles, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  ((uint64_t*)e->h_nz.ptr)[nwords] = 0; ((uint64_t*)e->h_nz.ptr)[nwords + 1] = 0;
+  e->nz_ones_words = 0;                                   /* the single-file path may not assume anything about h_nz any more */
+  tile_or = (const uint32_t*)e->h_tile_or.ptr;
+  for (i = 0; i < count; i++) {
+    const uint32_t t0 = start[i] / SLA_HIP_PREPASS_TILE;
+    const uint32_t t1 = t0 + (len[i] + SLA_HIP_PREPASS_TILE - 1) / SLA_HIP_PREPASS_TILE;
+    uint32_t t, mask = 0;
+    for (t = t0; t < t1; t++) { mask |= tile_or[t]; }
+    orv[i] = mask; lsh[i] = 0;
+    if (mask != 0) {
+      const uint32_t ntz = (uint32_t)__builtin_ctz(mask);
+      lsh[i] = (bps < 32 - ntz || bps - (32 - ntz) >= bps) ? 0xFFFFFFFFu : bps - (32 - ntz);
+    }
+  }
+  return 0;
+}
+
 /* items [first, first + count): one upload, one prepass, one pipeline pass per distinct offset_lshift */
 static int encode_batch_pass(struct SLAEncoder* e, sla_hip_batch_item* items, uint32_t first, uint32_t count)
 {
   const uint32_t C = e->wave_format.num_channels, bps = e->wave_format.bit_per_sample;
-  const uint32_t ms = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
-  uint32_t *start, *lsh, *seg_start, *seg_len, *seg_item, *tile_or, *orv;
+  uint32_t *start, *lsh, *seg_start, *seg_len, *seg_item, *orv;
   pack_seg_t* segs;
-  uint32_t i, lowbits = 0, ntiles;
-  uint64_t span = 0, stride, nwords;
+  uint32_t i, lowbits = 0;
+  uint64_t span = 0, stride;
   int mode16 = (bps <= 16), rc = 0;
 
   start = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)count * 6 + 64);
@@ -2018,38 +2058,12 @@ static int encode_batch_pass(struct SLAEncoder* e, sla_hip_batch_item* items, ui
   if (mode16 && lowbits != 0) { BATCH_CHK(upload_batch_pass(e, items, start, first, count, (size_t)span, stride, 0, &lowbits)); }
   e->pcm_dev = (const int32_t*)e->d_pcm.ptr; e->stride = stride; e->num_samples = (uint32_t)span;
 
-  /* prepass over everything: silence mask, OR per 1024-sample tile */
-  nwords = (span + 63) / 64;
-  ntiles = (uint32_t)((span + 4 * SLA_HIP_PREPASS_TILE - 1) / (4 * SLA_HIP_PREPASS_TILE) * 4);
-  BATCH_CHK(dev_reserve(&e->d_or, 64));
-  BATCH_CHK(dev_reserve(&e->d_nz, (size_t)(nwords + 2) * 8));
-  BATCH_CHK(pin_reserve(&e->h_nz, (size_t)(nwords + 2) * 8));
-  BATCH_CHK(dev_reserve(&e->d_tile_or, sizeof(uint32_t) * ((size_t)ntiles + 4)));
-  BATCH_CHK(pin_reserve(&e->h_tile_or, sizeof(uint32_t) * ((size_t)ntiles + 4)));
-  BATCH_HIP(hipEventRecord(e->ev[0], e->stream));
-  BATCH_CHK(sla_hip_launch_prepass_tiles(e->pcm_dev, e->stride, C, (uint32_t)span, bps, ms, (uint32_t*)e->d_or.ptr, (uint64_t*)e->d_nz.ptr,
-                                         (uint32_t*)e->d_tile_or.ptr, e->stream));
-  BATCH_HIP(hipEventRecord(e->ev[1], e->stream));
-  BATCH_HIP(hipMemcpyAsync(e->h_nz.ptr, e->d_nz.ptr, (size_t)nwords * 8, hipMemcpyDeviceToHost, e->stream));
-  BATCH_HIP(hipMemcpyAsync(e->h_tile_or.ptr, e->d_tile_or.ptr, sizeof(uint32_t) * ntiles, hipMemcpyDeviceToHost, e->stream));
-  BATCH_HIP(hipStreamSynchronize(e->stream));
-  ((uint64_t*)e->h_nz.ptr)[nwords] = 0; ((uint64_t*)e->h_nz.ptr)[nwords + 1] = 0;
-  e->nz_ones_words = 0;                                   /* the single-file path may not assume anything about h_nz any more */
-  tile_or = (uint32_t*)e->h_tile_or.ptr;
-
-  /* offset_lshift per file                                                    src/SLAEncoder.c:425-455 */
+  /* prepass over everything: silence mask, offset_lshift per file */
+  for (i = 0; i < count; i++) { seg_len[i] = items[first + i].num_samples; }
+  BATCH_CHK(batch_prepass(e, span, start, seg_len, count, lsh, orv));
   for (i = 0; i < count; i++) {
-    const uint32_t t0 = start[i] / SLA_HIP_PREPASS_TILE;
-    const uint32_t t1 = t0 + (items[first + i].num_samples + SLA_HIP_PREPASS_TILE - 1) / SLA_HIP_PREPASS_TILE;
-    uint32_t t, mask = 0;
-    for (t = t0; t < t1; t++) { mask |= tile_or[t]; }
-    orv[i] = mask; lsh[i] = 0;
     items[first + i].result = SLA_APIRESULT_OK; items[first + i].output_size = 0;
-    if (mask != 0) {
-      const uint32_t ntz = (uint32_t)__builtin_ctz(mask);
-      if (bps < 32 - ntz || bps - (32 - ntz) >= bps) { items[first + i].result = SLA_APIRESULT_INVALID_ARGUMENT; lsh[i] = 0xFFFFFFFFu; continue; }
-      lsh[i] = bps - (32 - ntz);
-    }
+    if (lsh[i] == 0xFFFFFFFFu) { items[first + i].result = SLA_APIRESULT_INVALID_ARGUMENT; continue; }
     if (items[first + i].data == NULL || items[first + i].data_size < SLA_HEADER_SIZE) {
       items[first + i].result = (items[first + i].data == NULL) ? SLA_APIRESULT_INVALID_ARGUMENT : SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE;
       lsh[i] = 0xFFFFFFFFu;
@@ -2091,6 +2105,60 @@ done:
   return rc;
 #undef BATCH_CHK
 #undef BATCH_HIP
+}
+
+/* The hot path over a batch that already lives in device memory (what bench.py --config C4 times). */
+int sla_hip_analyze_batch_device(struct SLAEncoder* e, const int32_t* d_pcm, uint64_t plane_stride, uint32_t span,
+                                 const uint32_t* file_start, const uint32_t* file_samples, uint32_t num_files,
+                                 uint32_t* file_lshift, float* timing_ms)
+{
+  const double t_start = now_ms();
+  uint32_t *lsh, *orv, *seg_start, *seg_len;
+  uint32_t i, passes = 0;
+  float acc[12];
+  int rc = 0;
+  if (e == NULL || d_pcm == NULL || (num_files != 0 && (file_start == NULL || file_samples == NULL))) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  RCCHK(check_ready(e));
+  if (plane_stride < span || span > BATCH_MAX_SPAN) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  for (i = 0; i < num_files; i++) {
+    if (file_start[i] % SLA_HIP_PREPASS_TILE != 0 || (uint64_t)file_start[i] + file_samples[i] > span
+        || (i > 0 && (uint64_t)file_start[i - 1] + file_samples[i - 1] > file_start[i])) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  }
+  e->analysed = 0;
+  if (num_files == 0 || span == 0) { return 0; }
+  lsh = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)num_files * 4);
+  if (lsh == NULL) { return SLA_APIRESULT_NG; }
+  orv = lsh + num_files; seg_start = orv + num_files; seg_len = seg_start + num_files;
+  e->pcm_dev = d_pcm; e->stride = plane_stride; e->num_samples = span;
+  memset(acc, 0, sizeof(acc));
+  rc = batch_prepass(e, span, file_start, file_samples, num_files, lsh, orv);
+  for (i = 0; rc == 0 && i < num_files; i++) {
+    if (file_lshift != NULL) { file_lshift[i] = lsh[i]; }
+    if (lsh[i] == 0xFFFFFFFFu) { rc = SLA_APIRESULT_INVALID_ARGUMENT; }
+  }
+  while (rc == 0) {
+    uint32_t v = 0xFFFFFFFFu, ns = 0, gor = 0, k;
+    for (i = 0; i < num_files; i++) { if (lsh[i] != 0xFFFFFFFFu) { v = lsh[i]; break; } }
+    if (v == 0xFFFFFFFFu) { break; }
+    for (i = 0; i < num_files; i++) {
+      if (lsh[i] != v) { continue; }
+      seg_start[ns] = file_start[i]; seg_len[ns] = file_samples[i]; gor |= orv[i]; lsh[i] = 0xFFFFFFFFu; ns++;
+    }
+    e->nsegs = ns; e->seg_start = seg_start; e->seg_len = seg_len; e->batch_lshift = v; e->batch_or = gor;
+    memset(e->timing, 0, sizeof(e->timing));
+    rc = run_pipeline(e, 0);
+    e->nsegs = 0; e->seg_start = NULL; e->seg_len = NULL;
+    for (k = 0; k < 12; k++) { acc[k] = (k == 9 || k == 11) ? e->timing[k] : acc[k] + e->timing[k]; }
+    passes++;
+  }
+  free(lsh);
+  if (rc != 0) { return rc; }
+  memcpy(e->timing, acc, sizeof(acc));
+  e->timing[7] = (float)(now_ms() - t_start);
+  e->wave_format.offset_lshift = (uint8_t)e->lshift;
+  if (timing_ms != NULL) { memcpy(timing_ms, e->timing, sizeof(e->timing)); }
+  e->analysed = (passes == 1);          /* one pass: the block table of the whole batch is there for sla_hip_get_trace */
+  return 0;
 }
 
 int sla_hip_encode_batch(struct SLAEncoder* e, sla_hip_batch_item* items, uint32_t num_items)

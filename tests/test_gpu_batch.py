@@ -120,3 +120,50 @@ def test_argument_checks(hip):
         assert L.sla_hip_encode_batch(raw._h, items, 1) == 15         # parameters not set
     finally:
         raw.close()
+
+
+def test_batch_analysis_on_device_resident_planes(oracle, hip):
+    """sla_hip_analyze_batch_device: files back to back in HBM, one pipeline pass; the block table, PARCOR doubles,
+    codes, Rice parameters and residual planes of every file equal the oracle's analysis of that file alone"""
+    import torch
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096, cap=(2, 4096, 16, 1, 8))
+    lens = [30000, 4097, 12288, 1, 20000]
+    pcms = [W.music_like(2, n, 16, seed=70 + i) for i, n in enumerate(lens)]
+    pcms[2][:, :5000] = 0
+    starts, at = [], 0
+    for n in lens:
+        starts.append(at)
+        at += (n + 1023) // 1024 * 1024
+    span = at
+    d_pcm = torch.zeros((2, span), dtype=torch.int32, device="cuda")
+    for s0, x in zip(starts, pcms):
+        d_pcm[:, s0:s0 + x.shape[1]] = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    enc = make_encoder(hip, p)
+    try:
+        timing, lsh = enc.analyze_batch_device(d_pcm.data_ptr(), span, span, starts, lens)
+        assert list(lsh) == [0] * len(lens)
+        enc.num_channels, enc.order, enc.ltm_order = 2, 16, 1
+        tr = enc.trace()
+        nb = tr.num_blocks
+        b = 0
+        for s0, x in zip(starts, pcms):
+            ret, _, to = oracle.encode_trace(p, x)
+            assert ret == 0
+            k = to.num_blocks
+            assert np.array_equal(tr.blk_start[b:b + k], to.blk_start[:k] + s0)
+            assert np.array_equal(tr.blk_nsmpl[b:b + k], to.blk_nsmpl[:k]) and np.array_equal(tr.blk_type[b:b + k], to.blk_type[:k])
+            comp = to.blk_type[:k] == 0
+            assert np.array_equal(tr.parcor[b:b + k].view(np.uint64)[comp], to.parcor[:k].view(np.uint64)[comp])
+            for f in ("code", "kint", "rshift", "pitch", "rice_init"):
+                assert np.array_equal(getattr(tr, f)[b:b + k][comp], getattr(to, f)[:k][comp]), f
+            for j in np.nonzero(comp)[0]:
+                a, n = int(to.blk_start[j]), int(to.blk_nsmpl[j])
+                assert np.array_equal(tr.res_final[:, s0 + a:s0 + a + n], to.res_final[:, a:a + n])
+            b += k
+        assert b == nb
+        # a start off the 1024-sample grid is refused
+        with pytest.raises(hip.SlaError):
+            enc.analyze_batch_device(d_pcm.data_ptr(), span, span, [0, 1000], [500, 500])
+    finally:
+        enc.close()
