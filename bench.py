@@ -21,6 +21,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+# The pipeline keeps five HIP streams busy (search, block kernels, serial tail, uploads, downloads).  The ROCm runtime
+# multiplexes streams onto 4 hardware queues by default, where a cross-stream event wait of one stream holds up the
+# kernels of another that happens to share its queue; 8 queues give every stream its own (measured: +1..3 %).
+# Must be in the environment before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np      # noqa: E402
 
 # name: (channels, bits, rate, seconds, order, ltm, lms, ms, window, max_block, capacity)
