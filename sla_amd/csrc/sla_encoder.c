@@ -954,12 +954,19 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
                                 (const double*)e->d_lpc_out.ptr, (uint32_t*)e->d_parts.ptr + (size_t)live_lo * SLA_HIP_PLAN_NODES,
                                 (uint32_t*)e->d_nparts.ptr + live_lo, (uint32_t*)e->d_pstatus.ptr + live_lo, e->stream));
       HIPCHK(hipEventRecord(ev[EV_PLANNED], e->stream));
-      HIPCHK(hipStreamWaitEvent(e->stream_down, ev[EV_PLANNED], 0));
-      HIPCHK(hipMemcpyAsync((uint32_t*)e->h_parts.ptr + (size_t)live_lo * SLA_HIP_PLAN_NODES, (uint32_t*)e->d_parts.ptr + (size_t)live_lo * SLA_HIP_PLAN_NODES,
-                            sizeof(uint32_t) * (size_t)live * SLA_HIP_PLAN_NODES, hipMemcpyDeviceToHost, e->stream_down));
-      HIPCHK(hipMemcpyAsync((uint32_t*)e->h_nparts.ptr + live_lo, (uint32_t*)e->d_nparts.ptr + live_lo, sizeof(uint32_t) * live, hipMemcpyDeviceToHost, e->stream_down));
-      HIPCHK(hipMemcpyAsync((uint32_t*)e->h_pstatus.ptr + live_lo, (uint32_t*)e->d_pstatus.ptr + live_lo, sizeof(uint32_t) * live, hipMemcpyDeviceToHost, e->stream_down));
-      HIPCHK(hipEventRecord(ev[EV_SEARCH_DONE], e->stream_down));      /* what the host waits for */
+      {
+        /* The three small result copies stay on the search stream, in order behind k_plan.  On the download stream
+         * they would sit there waiting for every chunk's search in turn, in front of whatever shares that stream's
+         * hardware queue (measured with one queue per stream: 2.9 instead of 3.05 ms per C2 step;
+         * SLA_HIP_PLAN_COPY=down restores the download stream). */
+        const hipStream_t st = (getenv("SLA_HIP_PLAN_COPY") != NULL && strcmp(getenv("SLA_HIP_PLAN_COPY"), "down") == 0) ? e->stream_down : e->stream;
+        if (st != e->stream) { HIPCHK(hipStreamWaitEvent(st, ev[EV_PLANNED], 0)); }
+        HIPCHK(hipMemcpyAsync((uint32_t*)e->h_parts.ptr + (size_t)live_lo * SLA_HIP_PLAN_NODES, (uint32_t*)e->d_parts.ptr + (size_t)live_lo * SLA_HIP_PLAN_NODES,
+                              sizeof(uint32_t) * (size_t)live * SLA_HIP_PLAN_NODES, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync((uint32_t*)e->h_nparts.ptr + live_lo, (uint32_t*)e->d_nparts.ptr + live_lo, sizeof(uint32_t) * live, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync((uint32_t*)e->h_pstatus.ptr + live_lo, (uint32_t*)e->d_pstatus.ptr + live_lo, sizeof(uint32_t) * live, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(ev[EV_SEARCH_DONE], st));      /* what the host waits for */
+      }
       return 0;
     } else {
       HIPCHK(hipMemcpyAsync((double*)e->h_lpc_out.ptr + (size_t)k->slot_lo * O2, (double*)e->d_lpc_out.ptr + (size_t)k->slot_lo * O2,
