@@ -290,7 +290,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   }
   for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { if (hipEventCreate(&e->ev[i]) != hipSuccess) { free(e); return NULL; } }
   if (hipEventCreate(&e->ev_stage[0]) != hipSuccess || hipEventCreate(&e->ev_stage[1]) != hipSuccess) { free(e); return NULL; }
-  e->chunks = 3;
+  e->chunks = 2;
   env = getenv("SLA_HIP_CHUNKS");
   if (env != NULL && atoi(env) > 0) { e->chunks = (uint32_t)atoi(env); }
   env = getenv("SLA_HIP_CHUNK_SPLIT");
@@ -1312,9 +1312,12 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   if (want_chunks < 1) { want_chunks = 1; }
   a.nchunks = want_chunks;
   /* chunk boundaries in 1/1000 of the super-frames: equal parts unless SLA_HIP_CHUNK_SPLIT gave the shares */
-  if (e->split_count != a.nchunks && a.nchunks == 3) {
-    /* measured on C2: a shorter first chunk fills the pipeline sooner (the host plans it while nothing else can
-     * run), and k_tail -- latency-bound, one wave per SIMD -- costs the same for any chunk up to 1024 waves */
+  if (e->split_count != a.nchunks && a.nchunks == 2) {
+    /* measured on C2..C5 (one hardware queue per stream): two chunks, 40 % / 60 %.  The shorter first chunk fills the
+     * pipeline sooner (the host plans it while nothing else can run); every further chunk costs one more k_tail --
+     * latency-bound, the same 0.35 ms for any chunk up to 1024 waves -- and one more round of cross-stream hand-overs */
+    e->chunk_cut[0] = 0; e->chunk_cut[1] = 400; e->chunk_cut[2] = 1000;
+  } else if (e->split_count != a.nchunks && a.nchunks == 3) {
     e->chunk_cut[0] = 0; e->chunk_cut[1] = 250; e->chunk_cut[2] = 625; e->chunk_cut[3] = 1000;
   } else if (e->split_count != a.nchunks) {
     for (c = 0; c <= a.nchunks; c++) { e->chunk_cut[c] = 1000u * c / a.nchunks; }
