@@ -107,6 +107,7 @@ struct SLAEncoder {
   size_t   coef_cap;
   int      analysed;
   float    timing[12];
+  int      wall_clock_khz;          /* rate of the device's constant clock (cached) */
   float    kernel_ms[4];            /* last analysis: on-device execution spans of k_lpc_blocks, k_lattice, k_ltm_acf, k_tail, summed over chunks */
 };
 
@@ -318,7 +319,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   if (env != NULL && strcmp(env, "chain") == 0) { e->search_exact = 0; }
   env = getenv("SLA_HIP_EXACT_BITS");
   if (env != NULL && atoi(env) > 0 && atoi(env) < 51) { e->exact_bits = atoi(env); }
-  if (hipHostMalloc((void**)&e->h_or, 64, hipHostMallocDefault) != hipSuccess) { free(e); return NULL; }
+  if (hipHostMalloc((void**)&e->h_or, 4096, hipHostMallocDefault) != hipSuccess) { free(e); return NULL; }   /* [0,1] prepass words, [2] rerun counter, +64 B: kernel spans */
   {
     uint32_t fft = 1;
     while (fft < config->max_num_block_samples * 2) { fft <<= 1; }    /* src/SLAEncoder.c:110 */
@@ -1396,19 +1397,30 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
       TRACE("tail launched", a.nchunks - 1);
     }
   }
+  /* the rerun counter and the kernels' execution spans ride home behind the last k_tail (every other stream has been
+   * waited for by then): two synchronous copies here cost 70-90 us per step */
+  {
+    unsigned long long* sp_host = (unsigned long long*)((uint8_t*)e->h_or + 64);
+    int copied = 0;
+    if (rc == 0) {
+      copied = (hipMemcpyAsync(sp_host, e->d_spans.ptr, sizeof(unsigned long long) * MAX_CHUNKS * 4 * 2, hipMemcpyDeviceToHost, e->stream3) == hipSuccess);
+      if (!preset_blocks && hipMemcpyAsync(e->h_or + 2, (uint32_t*)e->d_or.ptr + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream3) != hipSuccess) { rc = SLA_APIRESULT_NG; }
+    }
   if (hipStreamSynchronize(e->stream) != hipSuccess || hipStreamSynchronize(e->stream2) != hipSuccess
-      || hipStreamSynchronize(e->stream3) != hipSuccess || hipStreamSynchronize(e->stream_up) != hipSuccess
-      || hipStreamSynchronize(e->stream_down) != hipSuccess) { if (rc == 0) { rc = SLA_APIRESULT_NG; } }
-  if (rc == 0 && !preset_blocks) {
-    if (hipMemcpy(&e->fallback_groups, (uint32_t*)e->d_or.ptr + 2, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) { rc = SLA_APIRESULT_NG; }
-  }
+      || hipStreamSynchronize(e->stream_up) != hipSuccess || hipStreamSynchronize(e->stream_down) != hipSuccess
+      || hipStreamSynchronize(e->stream3) != hipSuccess) { if (rc == 0) { rc = SLA_APIRESULT_NG; } }
+  if (rc == 0 && !preset_blocks) { e->fallback_groups = e->h_or[2]; }
   memset(e->kernel_ms, 0, sizeof(e->kernel_ms));
   if (rc == 0) {
-    unsigned long long sp[MAX_CHUNKS * 4 * 2];
-    int rate_khz = 100000;
-    (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, e->device);
-    if (rate_khz <= 0) { rate_khz = 100000; }
-    if (hipMemcpy(sp, e->d_spans.ptr, sizeof(sp), hipMemcpyDeviceToHost) == hipSuccess) {
+    const unsigned long long* sp = sp_host;
+    int rate_khz = e->wall_clock_khz;
+    if (rate_khz <= 0) {
+      rate_khz = 100000;
+      (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, e->device);
+      if (rate_khz <= 0) { rate_khz = 100000; }
+      e->wall_clock_khz = rate_khz;
+    }
+    if (copied) {
       for (c = 0; c < a.nchunks; c++) {
         for (i = 0; i < 4; i++) {
           const unsigned long long st = ~sp[(c * 4 + i) * 2], en = sp[(c * 4 + i) * 2 + 1];
@@ -1416,6 +1428,7 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
         }
       }
     }
+  }
   }
   TRACE("all streams idle", 0);
   if (rc == 0) {
