@@ -445,3 +445,47 @@ def test_random_parameter_walk(oracle, hip):
         rg, got = hip_decode(hip, p, data, n)
         assert rg == ro, ctx
         assert np.array_equal(got, want), ctx
+
+
+def test_garbage_reaches_the_kernels_without_harm(oracle, hip):
+    """CRC check off, bytes damaged at random (headers, coefficients, entropy-coded bodies, size fields): whatever the
+    result code, every call returns (every reader loop is bounded by the stream length), nothing is written outside the
+    caller's buffers, and the handle decodes a clean stream afterwards"""
+    rng = np.random.default_rng(99)
+    pcm = W.music_like(2, 30000, 16, seed=12)
+    p = S.make_params(2, 16, 48000, 16, 3, 8, 1, 1, 4096)
+    clean = encode(oracle, p, pcm)
+    dec = hip.Decoder(2, 4096, 16, 3, 8, enable_crc_check=0)
+    try:
+        seen = set()
+        for trial in range(150):
+            data = bytearray(clean)
+            kind = trial % 5
+            if kind == 0:                                   # a few bit flips anywhere behind the file header
+                for _ in range(int(rng.integers(1, 6))):
+                    data[int(rng.integers(43, len(data)))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:                                 # a burst of random bytes
+                a = int(rng.integers(43, len(data) - 300))
+                data[a:a + 256] = rng.integers(0, 256, 256, dtype=np.uint8).tobytes()
+            elif kind == 2:                                 # zeros: endless unary runs
+                a = int(rng.integers(43, len(data) - 3000))
+                data[a:a + 2048] = bytes(2048)
+            elif kind == 3:                                 # truncated somewhere
+                data = data[:int(rng.integers(43, len(data)))]
+            else:                                           # ones: maximal codes
+                a = int(rng.integers(43, len(data) - 3000))
+                data[a:a + 1024] = b"\xff" * 1024
+            guard = np.full((2, 30000 + 64), 0x5A5A5A5A, np.int32)
+            import ctypes as C
+            ptrs = (hip.i32p * 2)(guard[0].ctypes.data_as(hip.i32p), guard[1].ctypes.data_as(hip.i32p))
+            n = C.c_uint32(0)
+            buf = np.frombuffer(bytes(data), np.uint8)
+            rc = hip.lib().SLADecoder_DecodeWhole(dec._h, buf.ctypes.data_as(hip.u8p), len(buf), ptrs, 30000, C.byref(n))
+            seen.add(rc)
+            assert 0 <= rc <= 15 and n.value <= 30000
+            assert (guard[:, 30000:] == 0x5A5A5A5A).all()
+        rc, got = dec.decode_whole(clean, 30000)
+        assert rc == 0 and np.array_equal(got, pcm)
+        assert len(seen) >= 2, seen
+    finally:
+        dec.close()
