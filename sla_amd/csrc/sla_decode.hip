@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include "sla_hip.h"
+#include "sla_crc_dev.h"
 
 namespace {
 
@@ -143,34 +144,21 @@ __device__ __forceinline__ uint32_t gamma_get(bit_reader& rd)                  /
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_dec_crc: one lane per block, CRC16-IBM over [8, byte_len).
+// k_dec_crc: one wave per block, slice-parallel CRC16-IBM over [8, byte_len) (sla_crc_dev.h).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(256)
 void k_dec_crc(const uint8_t* __restrict__ bytes, const sla_hip_dec_block* __restrict__ blocks, uint32_t num_blocks,
                sla_hip_dec_info* __restrict__ info)
 {
   __shared__ uint16_t table[256];
-  for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
-    uint32_t c = i;
-    for (int k = 0; k < 8; k++) { c = (c & 1u) ? ((c >> 1) ^ 0xA001u) : (c >> 1); }
-    table[i] = (uint16_t)c;
-  }
+  crc16_build_table(table);
   __syncthreads();
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= num_blocks) { return; }
   const sla_hip_dec_block b = blocks[j];
-  uint32_t crc = 0;
-  uint64_t at = b.byte_off + 8;
-  const uint64_t end = b.byte_off + b.byte_len;
-  for (; at + 16 <= end; at += 16) {                   // byte loads first, then the serial table walk
-    uint8_t v[16];
-#pragma unroll
-    for (int u = 0; u < 16; u++) { v[u] = bytes[at + u]; }
-#pragma unroll
-    for (int u = 0; u < 16; u++) { crc = (crc >> 8) ^ table[(crc ^ v[u]) & 0xFFu]; }
-  }
-  for (; at < end; at++) { crc = (crc >> 8) ^ table[(crc ^ bytes[at]) & 0xFFu]; }
-  info[j].crc = crc;
+  const uint32_t crc = crc16_wave(bytes, b.byte_off + 8, b.byte_off + b.byte_len, table, lane);
+  if (lane == 0) { info[j].crc = crc; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -647,7 +635,7 @@ extern "C" int sla_hip_launch_dec_bits(const uint32_t* d_image, uint64_t image_b
   if (num_blocks == 0) { return 0; }
   hipStream_t st = (hipStream_t)stream;
   if (want_crc) {
-    hipLaunchKernelGGL(k_dec_crc, dim3((num_blocks + 63) / 64), dim3(64), 0, st, (const uint8_t*)d_image, d_blocks, num_blocks, d_info);
+    hipLaunchKernelGGL(k_dec_crc, dim3((num_blocks + 3) / 4), dim3(256), 0, st, (const uint8_t*)d_image, d_blocks, num_blocks, d_info);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { return hip_rc(e); }
   }

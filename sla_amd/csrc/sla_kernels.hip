@@ -34,6 +34,7 @@
 #include <string.h>
 
 #include "sla_hip.h"
+#include "sla_crc_dev.h"
 
 #define SLA_WAVE 64
 
@@ -1903,7 +1904,7 @@ extern "C" int sla_hip_launch_ltm_acf(const int32_t* d_residual, uint64_t plane_
 //                elements -- code length from (value, k0, k1), workgroup prefix sum -> bit offset, and
 //                the <= 3 non-zero pieces of the codeword OR-ed into the zero-initialised image
 //                (MSB-first, 32-bit atomics on byte-swapped words).  Unary zero runs cost nothing.
-//   k_block_crc  one lane per block: CRC16-IBM over the block, size + CRC patched into the header.
+//   k_block_crc  one wave per block: slice-parallel CRC16-IBM over the block, size + CRC patched into the header.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t fold_u32(int32_t s) { const uint32_t u = (uint32_t)s << 1; return (s < 0) ? ~u : u; }
 __device__ __forceinline__ uint32_t ceil_log2_u32(uint32_t x) { return (x > 1) ? (32u - (uint32_t)__builtin_clz(x - 1u)) : 0u; }
@@ -2079,31 +2080,19 @@ void k_rice_write(const int32_t* __restrict__ res, const int32_t* __restrict__ p
   }
 }
 
-__global__ __launch_bounds__(64)
+// one wave per block (4 blocks per workgroup): slice-parallel CRC16, see sla_crc_dev.h
+__global__ __launch_bounds__(256)
 void k_block_crc(const sla_hip_pack_block* __restrict__ blocks, uint32_t num_blocks, uint32_t* __restrict__ img)
 {
   __shared__ uint16_t table[256];
-  for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
-    uint32_t c = i;
-    for (int k = 0; k < 8; k++) { c = (c & 1u) ? ((c >> 1) ^ 0xA001u) : (c >> 1); }
-    table[i] = (uint16_t)c;
-  }
+  crc16_build_table(table);
   __syncthreads();
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= num_blocks) { return; }
   const sla_hip_pack_block b = blocks[j];
-  const uint8_t* bytes = (const uint8_t*)img;
-  uint32_t crc = 0;
-  uint64_t at = b.out_off + 8;
-  const uint64_t end = b.out_off + b.out_bytes;
-  for (; at + 16 <= end; at += 16) {                   // byte loads first, then the serial table walk
-    uint8_t v[16];
-#pragma unroll
-    for (int u = 0; u < 16; u++) { v[u] = bytes[at + u]; }
-#pragma unroll
-    for (int u = 0; u < 16; u++) { crc = (crc >> 8) ^ table[(crc ^ v[u]) & 0xFFu]; }
-  }
-  for (; at < end; at++) { crc = (crc >> 8) ^ table[(crc ^ bytes[at]) & 0xFFu]; }
+  const uint32_t crc = crc16_wave((const uint8_t*)img, b.out_off + 8, b.out_off + b.out_bytes, table, lane);
+  if (lane != 0) { return; }
   // size field = bytes after sync + size (32 bit, big endian), then the CRC (16 bit)
   const uint32_t sz = b.out_bytes - 6;
   const uint8_t patch[6] = { (uint8_t)(sz >> 24), (uint8_t)(sz >> 16), (uint8_t)(sz >> 8), (uint8_t)sz,
@@ -2139,7 +2128,7 @@ extern "C" int sla_hip_launch_rice_write(const int32_t* d_residual, const int32_
                      d_headers, num_channels, raw_shift, mid_side, d_image);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { return hip_rc(e); }
-  hipLaunchKernelGGL(k_block_crc, dim3((num_blocks + 63) / 64), dim3(64), 0, st, d_blocks, num_blocks, d_image);
+  hipLaunchKernelGGL(k_block_crc, dim3((num_blocks + 3) / 4), dim3(256), 0, st, d_blocks, num_blocks, d_image);
   return hip_rc(hipGetLastError());
 }
 
