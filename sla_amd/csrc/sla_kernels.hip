@@ -205,24 +205,39 @@ __device__ __forceinline__ double chain_lag(const double* __restrict__ xs, uint3
   const uint32_t span = groups * lag2;
   double acc = 0.0;
   if (groups > 0) {
+    // The walk is kept as ONE byte offset: a step moves it by 2*lag samples, the last step of an i by
+    // 1 - (groups-1)*2*lag samples (back to the start, one sample further).  Per step that is a decrement, a compare,
+    // two selects and three adds -- the chains are bound by VALU issue, so every integer instruction counts.
     const uint32_t steps = groups * lag;
-    uint32_t i = 0, left = groups, s = 0;     // `left` steps remain in the current i
-    const double* p = xs;                     // &xs[l + i]
+    const uint32_t lagB = lag * 8u, lag2B = lag * 16u;
+    const uint32_t wrapB = 8u - (groups - 1u) * lag2B;      // modulo 2^32: added to the offset
+    const int32_t stepB = (int32_t)lag2B, backB = (int32_t)wrapB;
+    const char* p = reinterpret_cast<const char*>(xs);
+    uint32_t left = groups, s = 0;
     for (; s + CHAIN_U <= steps; s += CHAIN_U) {
       double a[CHAIN_U], c[CHAIN_U], b[CHAIN_U];
 #pragma unroll
       for (int u = 0; u < CHAIN_U; u++) {
-        a[u] = p[0]; c[u] = p[lag]; b[u] = p[lag2];
-        p += lag2;
-        if (--left == 0) { left = groups; i++; p = xs + i; }
+        a[u] = *reinterpret_cast<const double*>(p);
+        c[u] = *reinterpret_cast<const double*>(p + lagB);
+        b[u] = *reinterpret_cast<const double*>(p + lag2B);
+        left--;
+        const bool wrap = (left == 0);
+        p += wrap ? backB : stepB;
+        left = wrap ? groups : left;
       }
 #pragma unroll
       for (int u = 0; u < CHAIN_U; u++) { acc += c[u] * (a[u] + b[u]); }
     }
     for (; s < steps; s++) {
-      acc += p[lag] * (p[0] + p[lag2]);
-      p += lag2;
-      if (--left == 0) { left = groups; i++; p = xs + i; }
+      const double a = *reinterpret_cast<const double*>(p);
+      const double c = *reinterpret_cast<const double*>(p + lagB);
+      const double b = *reinterpret_cast<const double*>(p + lag2B);
+      acc += c * (a + b);
+      left--;
+      const bool wrap = (left == 0);
+      p += wrap ? backB : stepB;
+      left = wrap ? groups : left;
     }
   }
   const uint32_t rest = n - span - lag;
