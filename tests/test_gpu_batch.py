@@ -167,3 +167,21 @@ def test_batch_analysis_on_device_resident_planes(oracle, hip):
             enc.analyze_batch_device(d_pcm.data_ptr(), span, span, [0, 1000], [500, 500])
     finally:
         enc.close()
+
+
+def test_empty_file_inside_a_batch(oracle, hip):
+    """a file of zero samples is a 43-byte header, alone (reference behaviour) and between other files of a batch"""
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096)
+    a, b = W.music_like(2, 5000, 16, seed=1), W.music_like(2, 9000, 16, seed=2)
+    empty = np.zeros((2, 0), np.int32)
+    want_empty = oracle.encode_whole(p, empty)[1]
+    assert len(want_empty) == 43
+    enc = make_encoder(hip, p)
+    try:
+        assert enc.encode_whole(empty) == want_empty
+        for files in ([a, empty, b], [empty, a], [a, empty], [empty], [empty, empty, b]):
+            got = enc.encode_batch(files)
+            for x, (rc, data) in zip(files, got):
+                assert rc == 0 and data == oracle.encode_whole(p, x)[1]
+    finally:
+        enc.close()
