@@ -22,9 +22,12 @@
  *   SLAEmphasisFilter_Create / _Reset / _Destroy /
  *     _PreEmphasisInt32 / _PreEmphasisDouble                    src/SLAPredictor.c:1708-1765, 1794-1813
  *
- * Not provided: the decode side (SLALPCSynthesizer_SynthesizeByParcorCoefInt32, SLALongTermSynthesizer_SynthesizeInt32,
- * SLALMSFilter_SynthesizeInt32, SLAEmphasisFilter_DeEmphasisInt32) -- out of scope, SURVEY 8(f) row 4 -- and
- * SLALPCCalculator_CalculateResidualPower, which the encoder never calls.
+ * The decode side is here as well, one block per call through the synthesis kernels of sla_decode.hip:
+ *   SLALPCSynthesizer_SynthesizeByParcorCoefInt32               src/SLAPredictor.c:610-740
+ *   SLALongTermSynthesizer_SynthesizeInt32                      src/SLAPredictor.c:1034-1119
+ *   SLALMSFilter_SynthesizeInt32                                src/SLAPredictor.c:1334-1463
+ *   SLAEmphasisFilter_DeEmphasisInt32                           src/SLAPredictor.c:1768-1791
+ * Not provided: SLALPCCalculator_CalculateResidualPower, which neither the encoder nor the decoder calls.
  *
  * Differences a caller can observe:
  *   - every Create returns NULL without a HIP device (no CPU fallback);
@@ -83,6 +86,12 @@ SLAPredictorApiResult SLALPCSynthesizer_PredictByParcorCoefInt32(
     const int32_t* data, uint32_t num_samples,
     const int32_t* parcor_coef, uint32_t order,
     int32_t* residual);
+/* the inverse: residual -> samples (IIR lattice) */
+SLAPredictorApiResult SLALPCSynthesizer_SynthesizeByParcorCoefInt32(
+    struct SLALPCSynthesizer* lpcs,
+    const int32_t* residual, uint32_t num_samples,
+    const int32_t* parcor_coef, uint32_t order,
+    int32_t* output);
 
 /* long-term (pitch) analysis: FFT autocorrelation, pitch pick, Toeplitz solve */
 struct SLALongTermCalculator* SLALongTermCalculator_Create(
@@ -103,6 +112,12 @@ SLAPredictorApiResult SLALongTermSynthesizer_PredictInt32(
     const int32_t* data, uint32_t num_samples,
     uint32_t pitch_period,
     const int32_t* ltm_coef, uint32_t num_taps, int32_t* residual);
+/* the inverse: output[n] = residual[n] + sum_k coef[k] * output[n - pitch - taps/2 + k] */
+SLAPredictorApiResult SLALongTermSynthesizer_SynthesizeInt32(
+    struct SLALongTermSynthesizer* ltm,
+    const int32_t* residual, uint32_t num_samples,
+    uint32_t pitch_period,
+    const int32_t* ltm_coef, uint32_t num_taps, int32_t* output);
 
 /* sign-log LMS cascade */
 struct SLALMSFilter* SLALMSFilter_Create(uint32_t max_num_coef);
@@ -111,6 +126,9 @@ SLAPredictorApiResult SLALMSFilter_Reset(struct SLALMSFilter* nlms);
 SLAPredictorApiResult SLALMSFilter_PredictInt32(
     struct SLALMSFilter* nlms, uint32_t num_coef,
     const int32_t* data, uint32_t num_samples, int32_t* residual);
+SLAPredictorApiResult SLALMSFilter_SynthesizeInt32(
+    struct SLALMSFilter* nlms, uint32_t num_coef,
+    const int32_t* residual, uint32_t num_samples, int32_t* output);
 
 /* block partition search over one super-frame (data[ch] = num_samples un-windowed doubles) */
 struct SLAOptimalBlockPartitionEstimator* SLAOptimalEncodeEstimator_Create(
@@ -134,6 +152,10 @@ SLAPredictorApiResult SLAEmphasisFilter_PreEmphasisInt32(
     struct SLAEmphasisFilter* emp,
     int32_t* data, uint32_t num_samples, int32_t coef_shift);
 void SLAEmphasisFilter_PreEmphasisDouble(double* data, uint32_t num_samples, int32_t coef_shift);
+/* de-emphasis y[n] = x[n] + ((y[n-1] * (2^s - 1)) >> s), in place; y[-1] = last output of the previous call */
+SLAPredictorApiResult SLAEmphasisFilter_DeEmphasisInt32(
+    struct SLAEmphasisFilter* emp,
+    int32_t* data, uint32_t num_samples, int32_t coef_shift);
 
 #ifdef __cplusplus
 }

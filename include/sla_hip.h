@@ -270,7 +270,7 @@ int sla_hip_launch_unpack16(const int16_t* d_in, int32_t* d_out, uint64_t count,
  *   dec_lms     : SLALMSFilter_SynthesizeInt32              src/SLAPredictor.c:1334-1463
  *   dec_ltm     : SLALongTermSynthesizer_SynthesizeInt32    src/SLAPredictor.c:1034-1119
  *   dec_lattice : SLALPCSynthesizer_SynthesizeByParcorCoefInt32 src/SLAPredictor.c:610-740
- *                 + SLAEmphasisFilter_DeEmphasisInt32       src/SLAPredictor.c:1768-1791
+ *                 + SLAEmphasisFilter_DeEmphasisInt32       src/SLAPredictor.c:1768-1791 (deemphasis != 0)
  *   dec_finish  : SLAUtility_MStoLRInt32 src/SLAUtility.c:415-433 + left-justification src/SLADecoder.c:540-547
  * The synthesis kernels skip blocks whose decoded type is not "compressed". */
 #define SLA_HIP_DEC_HEADER_ONLY 1u       /* sla_hip_dec_block.flags: parse the header (and CRC), decode no samples */
@@ -309,7 +309,10 @@ int sla_hip_launch_dec_ltm(int32_t* d_planes, uint64_t plane_stride, const sla_h
                            uint32_t max_block_samples, sla_hip_stream_t stream);
 int sla_hip_launch_dec_lattice(int32_t* d_planes, uint64_t plane_stride, const sla_hip_dec_block* d_blocks,
                                const sla_hip_dec_info* d_info, uint32_t num_blocks, uint32_t num_channels,
-                               const int32_t* d_kint, uint32_t parcor_order, sla_hip_stream_t stream);
+                               const int32_t* d_kint, uint32_t parcor_order, uint32_t deemphasis, sla_hip_stream_t stream);
+/* de-emphasis alone (per-call API): in place, y[-1] = previous */
+int sla_hip_launch_dec_deemphasis(int32_t* d_data, uint32_t num_samples, int32_t previous, uint32_t coef_shift,
+                                  sla_hip_stream_t stream);
 int sla_hip_launch_dec_finish(int32_t* d_planes, uint64_t plane_stride, uint32_t num_channels,
                               uint32_t num_samples, uint32_t mid_side, uint32_t shift, sla_hip_stream_t stream);
 

@@ -195,6 +195,9 @@ EXPORTED_SYMBOLS = [
     "SLAStreamingDecoder_EstimateDecodableNumSamples", "SLAStreamingDecoder_GetOutputNumSamplesPerDecode",
     "SLAStreamingDecoder_AppendDataFragment", "SLAStreamingDecoder_CollectDataFragment",
     "SLAStreamingDecoder_GetRemainDataSize", "SLAStreamingDecoder_Decode",
+    # decode side of include/SLAPredictor.h
+    "SLALPCSynthesizer_SynthesizeByParcorCoefInt32", "SLALongTermSynthesizer_SynthesizeInt32", "SLALMSFilter_SynthesizeInt32",
+    "SLAEmphasisFilter_DeEmphasisInt32", "sla_hip_launch_dec_deemphasis",
 ]
 
 

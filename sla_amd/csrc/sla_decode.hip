@@ -518,7 +518,7 @@ template <int G, int R>
 __global__ __launch_bounds__(256)
 void k_dec_lattice(int32_t* __restrict__ planes, uint64_t stride, const sla_hip_dec_block* __restrict__ blocks,
                    const sla_hip_dec_info* __restrict__ info, uint32_t num_blocks, uint32_t num_channels,
-                   const int32_t* __restrict__ kint, uint32_t order)
+                   const int32_t* __restrict__ kint, uint32_t order, uint32_t deemphasis)
 {
   constexpr int JPW = 64 / G;
   // the output lane parks its 16 samples here; the group then stores them side by side (a 4-byte store per
@@ -579,7 +579,7 @@ void k_dec_lattice(int32_t* __restrict__ planes, uint64_t stride, const sla_hip_
         for (int r = 0; r < R - 1; r++) { bw[r] = nb[r + 1]; }
         bw[R - 1] = from_next;
         // de-emphasis on the output lane: y[n] = x[n] + ((y[n-1] * 31) >> 5)     src/SLAPredictor.c:1781-1786
-        const int32_t y = (int32_t)((uint32_t)f[R - 1] + (uint32_t)((int32_t)((uint32_t)yprev * 31u) >> 5));
+        const int32_t y = deemphasis ? (int32_t)((uint32_t)f[R - 1] + (uint32_t)((int32_t)((uint32_t)yprev * 31u) >> 5)) : f[R - 1];
         yprev = y;
         if (is_last) { park[u] = y; }
       }
@@ -611,6 +611,20 @@ void k_dec_finish(int32_t* __restrict__ planes, uint64_t stride, uint32_t num_ch
     for (uint32_t c = 2; c < num_channels; c++) { planes[(uint64_t)c * stride + i] = (int32_t)((uint32_t)planes[(uint64_t)c * stride + i] << shift); }
   } else {
     for (uint32_t c = 0; c < num_channels; c++) { planes[(uint64_t)c * stride + i] = (int32_t)((uint32_t)planes[(uint64_t)c * stride + i] << shift); }
+  }
+}
+
+// De-emphasis as a pass of its own (per-call API): y[n] = x[n] + ((y[n-1] * (2^s - 1)) >> s), y[-1] = previous.
+// A one-tap recurrence through a truncating shift: strictly serial, one lane.
+__global__ __launch_bounds__(64)
+void k_dec_deemphasis(int32_t* __restrict__ data, uint32_t n, int32_t previous, uint32_t shift)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) { return; }
+  const uint32_t numer = (1u << shift) - 1u;
+  int32_t y = previous;
+  for (uint32_t i = 0; i < n; i++) {
+    y = (int32_t)((uint32_t)data[i] + (uint32_t)((int32_t)((uint32_t)y * numer) >> shift));
+    data[i] = y;
   }
 }
 
@@ -704,7 +718,7 @@ extern "C" int sla_hip_launch_dec_ltm(int32_t* d_planes, uint64_t plane_stride, 
 
 extern "C" int sla_hip_launch_dec_lattice(int32_t* d_planes, uint64_t plane_stride, const sla_hip_dec_block* d_blocks,
                                           const sla_hip_dec_info* d_info, uint32_t num_blocks, uint32_t num_channels,
-                                          const int32_t* d_kint, uint32_t parcor_order, sla_hip_stream_t stream)
+                                          const int32_t* d_kint, uint32_t parcor_order, uint32_t deemphasis, sla_hip_stream_t stream)
 {
   if (d_planes == nullptr || d_blocks == nullptr || d_info == nullptr || d_kint == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (num_channels == 0 || num_channels > 8 || parcor_order > 255) { return SLA_APIRESULT_INVALID_ARGUMENT; }
@@ -713,7 +727,7 @@ extern "C" int sla_hip_launch_dec_lattice(int32_t* d_planes, uint64_t plane_stri
   const uint32_t jobs = num_blocks * num_channels;
 #define SLA_DEC_LATTICE(G, R)                                                                                          \
   hipLaunchKernelGGL((k_dec_lattice<G, R>), dim3(((jobs + (64 / G) - 1) / (64 / G) + 3) / 4), dim3(256), 0, st, d_planes, \
-                     plane_stride, d_blocks, d_info, num_blocks, num_channels, d_kint, parcor_order)
+                     plane_stride, d_blocks, d_info, num_blocks, num_channels, d_kint, parcor_order, deemphasis)
   if (parcor_order <= 16) { SLA_DEC_LATTICE(16, 1); }
   else if (parcor_order <= 32) { SLA_DEC_LATTICE(32, 1); }
   else if (parcor_order <= 64) { SLA_DEC_LATTICE(64, 1); }
@@ -733,5 +747,14 @@ extern "C" int sla_hip_launch_dec_finish(int32_t* d_planes, uint64_t plane_strid
   if (num_samples == 0) { return 0; }
   hipLaunchKernelGGL(k_dec_finish, dim3((num_samples + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_planes, plane_stride,
                      num_channels, num_samples, mid_side, shift);
+  return hip_rc(hipGetLastError());
+}
+
+extern "C" int sla_hip_launch_dec_deemphasis(int32_t* d_data, uint32_t num_samples, int32_t previous, uint32_t coef_shift,
+                                             sla_hip_stream_t stream)
+{
+  if (d_data == nullptr || coef_shift < 1 || coef_shift > 30) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (num_samples == 0) { return 0; }
+  hipLaunchKernelGGL(k_dec_deemphasis, dim3(1), dim3(64), 0, (hipStream_t)stream, d_data, num_samples, previous, coef_shift);
   return hip_rc(hipGetLastError());
 }

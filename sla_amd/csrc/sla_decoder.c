@@ -274,7 +274,7 @@ static SLAApiResult decode_run(struct SLADecoder* d, const uint8_t* data, uint32
         RCCHK(sla_hip_launch_dec_ltm(d_planes, stride, (const sla_hip_dec_block*)d->d_blocks.ptr, (const sla_hip_dec_info*)d->d_info.ptr,
                                      (const sla_hip_dec_chan*)d->d_chan.ptr, nb, C, ntaps, cap_n, d->stream));
         RCCHK(sla_hip_launch_dec_lattice(d_planes, stride, (const sla_hip_dec_block*)d->d_blocks.ptr, (const sla_hip_dec_info*)d->d_info.ptr,
-                                         nb, C, (const int32_t*)d->d_kint.ptr, order, d->stream));
+                                         nb, C, (const int32_t*)d->d_kint.ptr, order, 1, d->stream));
       }
       HIPCHK(hipEventRecord(d->ev[1], d->stream));
       HIPCHK(hipStreamSynchronize(d->stream));

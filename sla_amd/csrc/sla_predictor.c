@@ -370,6 +370,87 @@ SLAPredictorApiResult SLALMSFilter_PredictInt32(
              ? SLAPREDICTOR_APIRESULT_OK : SLAPREDICTOR_APIRESULT_NG;
 }
 
+/* ------------------------------------------------------------------ decode side: one block through the synthesis kernels */
+
+/* `data` (n samples) through one stage of sla_decode.hip on a batch of one block: stage 0 = LMS synthesis, 1 = long-term
+ * synthesis, 2 = PARCOR synthesis lattice (no de-emphasis), 3 = de-emphasis */
+static int synth_once(int stage, const int32_t* data, uint32_t n, int32_t* out, uint32_t lms_order, uint32_t pitch,
+                      const int32_t* ltm_coef, uint32_t ntaps, const int32_t* kint, uint32_t order, int32_t previous, uint32_t shift)
+{
+  dbuf_t d_x = {NULL, 0}, d_blk = {NULL, 0}, d_info = {NULL, 0}, d_chan = {NULL, 0}, d_k = {NULL, 0};
+  sla_hip_dec_block blk;
+  sla_hip_dec_info info;
+  sla_hip_dec_chan chan;
+  uint32_t t;
+  int rc = -1;
+  memset(&blk, 0, sizeof(blk)); memset(&info, 0, sizeof(info)); memset(&chan, 0, sizeof(chan));
+  blk.num_samples = n;
+  chan.pitch = pitch;
+  for (t = 0; t < ntaps && t < 5; t++) { chan.ltm_coef[t] = ltm_coef[t]; }
+  if (up(&d_x, data, sizeof(int32_t) * n) != 0 || up(&d_blk, &blk, sizeof(blk)) != 0 || up(&d_info, &info, sizeof(info)) != 0
+      || up(&d_chan, &chan, sizeof(chan)) != 0) { goto done; }
+  if (stage == 0) {
+    rc = sla_hip_launch_dec_lms((int32_t*)d_x.ptr, n, (const sla_hip_dec_block*)d_blk.ptr, (const sla_hip_dec_info*)d_info.ptr, 1, 1, lms_order, NULL);
+  } else if (stage == 1) {
+    rc = sla_hip_launch_dec_ltm((int32_t*)d_x.ptr, n, (const sla_hip_dec_block*)d_blk.ptr, (const sla_hip_dec_info*)d_info.ptr,
+                                (const sla_hip_dec_chan*)d_chan.ptr, 1, 1, ntaps, n, NULL);
+  } else if (stage == 2) {
+    if (up(&d_k, kint, sizeof(int32_t) * (order + 1)) != 0) { goto done; }
+    rc = sla_hip_launch_dec_lattice((int32_t*)d_x.ptr, n, (const sla_hip_dec_block*)d_blk.ptr, (const sla_hip_dec_info*)d_info.ptr, 1, 1,
+                                    (const int32_t*)d_k.ptr, order, 0, NULL);
+  } else {
+    rc = sla_hip_launch_dec_deemphasis((int32_t*)d_x.ptr, n, previous, shift, NULL);
+  }
+  if (rc == 0) { rc = down(out, d_x.ptr, sizeof(int32_t) * n); }
+done:
+  dfree(&d_x); dfree(&d_blk); dfree(&d_info); dfree(&d_chan); dfree(&d_k);
+  return rc;
+}
+
+/* reference src/SLAPredictor.c:610-740 */
+SLAPredictorApiResult SLALPCSynthesizer_SynthesizeByParcorCoefInt32(
+    struct SLALPCSynthesizer* s, const int32_t* residual, uint32_t num_samples,
+    const int32_t* parcor_coef, uint32_t order, int32_t* output)
+{
+  if (s == NULL || residual == NULL || parcor_coef == NULL || output == NULL) { return SLAPREDICTOR_APIRESULT_INVALID_ARGUMENT; }
+  if (order > s->max_order) { return SLAPREDICTOR_APIRESULT_EXCEED_MAX_ORDER; }
+  if (s->used) { return SLAPREDICTOR_APIRESULT_NG; }             /* continuing a block is not supported: Reset first */
+  if (num_samples == 0) { return SLAPREDICTOR_APIRESULT_OK; }
+  s->used = 1;
+  if (order == 0) { memmove(output, residual, sizeof(int32_t) * num_samples); return SLAPREDICTOR_APIRESULT_OK; }
+  if (order > 255) { return SLAPREDICTOR_APIRESULT_NG; }
+  return (synth_once(2, residual, num_samples, output, 0, 0, NULL, 0, parcor_coef, order, 0, 0) == 0)
+             ? SLAPREDICTOR_APIRESULT_OK : SLAPREDICTOR_APIRESULT_NG;
+}
+
+/* reference src/SLAPredictor.c:1034-1119 */
+SLAPredictorApiResult SLALongTermSynthesizer_SynthesizeInt32(
+    struct SLALongTermSynthesizer* l, const int32_t* residual, uint32_t num_samples,
+    uint32_t pitch_period, const int32_t* ltm_coef, uint32_t num_taps, int32_t* output)
+{
+  if (l == NULL || residual == NULL || ltm_coef == NULL || output == NULL) { return SLAPREDICTOR_APIRESULT_INVALID_ARGUMENT; }
+  if (pitch_period == 0) { memmove(output, residual, sizeof(int32_t) * num_samples); return SLAPREDICTOR_APIRESULT_OK; }
+  if (num_taps > l->max_taps || !(num_taps & 1u)) { return SLAPREDICTOR_APIRESULT_EXCEED_MAX_ORDER; }
+  if (pitch_period > l->max_period || l->used || num_samples > 16384) { return SLAPREDICTOR_APIRESULT_NG; }
+  if (num_samples == 0) { return SLAPREDICTOR_APIRESULT_OK; }
+  l->used = 1;
+  return (synth_once(1, residual, num_samples, output, 0, pitch_period, ltm_coef, num_taps, NULL, 0, 0, 0) == 0)
+             ? SLAPREDICTOR_APIRESULT_OK : SLAPREDICTOR_APIRESULT_NG;
+}
+
+/* reference src/SLAPredictor.c:1334-1463 */
+SLAPredictorApiResult SLALMSFilter_SynthesizeInt32(
+    struct SLALMSFilter* f, uint32_t num_coef, const int32_t* residual, uint32_t num_samples, int32_t* output)
+{
+  if (f == NULL || residual == NULL || output == NULL) { return SLAPREDICTOR_APIRESULT_INVALID_ARGUMENT; }
+  if (num_coef > f->max_coef) { return SLAPREDICTOR_APIRESULT_EXCEED_MAX_ORDER; }
+  if (!(num_coef == 4 || num_coef == 8 || num_coef == 16 || num_coef == 32) || f->used) { return SLAPREDICTOR_APIRESULT_NG; }
+  if (num_samples == 0) { return SLAPREDICTOR_APIRESULT_OK; }
+  f->used = 1;
+  return (synth_once(0, residual, num_samples, output, num_coef, 0, NULL, 0, NULL, 0, 0, 0) == 0)
+             ? SLAPREDICTOR_APIRESULT_OK : SLAPREDICTOR_APIRESULT_NG;
+}
+
 /* ------------------------------------------------------------------ partition search */
 
 struct SLAOptimalBlockPartitionEstimator { uint32_t max_nodes; };
@@ -505,6 +586,18 @@ SLAPredictorApiResult SLAEmphasisFilter_PreEmphasisInt32(
   }
   dfree(&in); dfree(&out);
   return res;
+}
+
+/* in place; the last output sample is carried to the next call            reference src/SLAPredictor.c:1768-1791 */
+SLAPredictorApiResult SLAEmphasisFilter_DeEmphasisInt32(
+    struct SLAEmphasisFilter* e, int32_t* data, uint32_t num_samples, int32_t coef_shift)
+{
+  if (e == NULL || data == NULL) { return SLAPREDICTOR_APIRESULT_INVALID_ARGUMENT; }
+  if (num_samples == 0) { return SLAPREDICTOR_APIRESULT_OK; }
+  if (coef_shift < 1 || coef_shift > 30) { return SLAPREDICTOR_APIRESULT_NG; }
+  if (synth_once(3, data, num_samples, data, 0, 0, NULL, 0, NULL, 0, e->prev, (uint32_t)coef_shift) != 0) { return SLAPREDICTOR_APIRESULT_NG; }
+  e->prev = data[num_samples - 1];
+  return SLAPREDICTOR_APIRESULT_OK;
 }
 
 void SLAEmphasisFilter_PreEmphasisDouble(double* data, uint32_t num_samples, int32_t coef_shift)

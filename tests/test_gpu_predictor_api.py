@@ -166,3 +166,69 @@ def test_coder_initial_parameters(oracle, L):
     got = [L.sla_hip_coder_initial_parameter(C.c_void_p(c), ch) for ch in range(nch)]
     assert got == list(want)
     L.SLACoder_Destroy(C.c_void_p(c))
+
+
+# ------------------------------------------------------------------ decode side: Synthesize* / DeEmphasis
+
+@pytest.mark.parametrize("n,order", [(4096, 16), (5000, 32), (9000, 48), (100, 8), (5, 16), (1008, 1), (3000, 64), (2500, 100), (2048, 255)])
+def test_lattice_synthesize_inverts_predict(oracle, L, n, order):
+    rng = np.random.default_rng(n + order)
+    x = oracle.preemph_i32(W.music_like(1, n, 24, seed=order)[0] >> 8)
+    kint = (rng.integers(-32768, 32767, order + 1, dtype=np.int64) >> int(rng.integers(0, 3))).astype(np.int32)
+    kint[0] = 0
+    res = oracle.lattice_predict(x, kint)
+    h = L.SLALPCSynthesizer_Create(255)
+    out = np.zeros(n, np.int32)
+    assert L.SLALPCSynthesizer_SynthesizeByParcorCoefInt32(C.c_void_p(h), p(res, i32p), n, p(kint, i32p), order, p(out, i32p)) == 0
+    assert np.array_equal(out, oracle.lattice_synth(res, kint)) and np.array_equal(out, x)
+    assert L.SLALPCSynthesizer_SynthesizeByParcorCoefInt32(C.c_void_p(h), p(res, i32p), n, p(kint, i32p), order, p(out, i32p)) == 1   # no reset
+    assert L.SLALPCSynthesizer_Reset(C.c_void_p(h)) == 0
+    assert L.SLALPCSynthesizer_SynthesizeByParcorCoefInt32(C.c_void_p(h), None, n, p(kint, i32p), order, p(out, i32p)) == 2
+    assert L.SLALPCSynthesizer_SynthesizeByParcorCoefInt32(C.c_void_p(h), p(res, i32p), n, p(kint, i32p), 256, p(out, i32p)) == 3
+    L.SLALPCSynthesizer_Destroy(C.c_void_p(h))
+
+
+@pytest.mark.parametrize("n,pitch,taps", [(4096, 131, 3), (5000, 37, 5), (4096, 3, 1), (8192, 255, 3), (300, 40, 5), (4096, 5, 5), (16384, 100, 1)])
+def test_longterm_synthesize_inverts_predict(oracle, L, n, pitch, taps):
+    rng = np.random.default_rng(pitch)
+    x = W.music_like(1, n, 16, seed=pitch)[0] >> 16
+    coef = (rng.integers(-20000, 20000, taps).astype(np.int64) << 16).astype(np.int32)
+    res = oracle.ltm_predict(x, pitch, coef)
+    h = L.SLALongTermSynthesizer_Create(5, 256)
+    out = np.zeros(n, np.int32)
+    assert L.SLALongTermSynthesizer_SynthesizeInt32(C.c_void_p(h), p(res, i32p), n, pitch, p(coef, i32p), taps, p(out, i32p)) == 0
+    assert np.array_equal(out, oracle.ltm_synth(res, pitch, coef)) and np.array_equal(out, x)
+    assert L.SLALongTermSynthesizer_SynthesizeInt32(C.c_void_p(h), p(res, i32p), n, pitch, p(coef, i32p), taps, p(out, i32p)) == 1
+    assert L.SLALongTermSynthesizer_Reset(C.c_void_p(h)) == 0
+    out0 = np.zeros(n, np.int32)
+    assert L.SLALongTermSynthesizer_SynthesizeInt32(C.c_void_p(h), p(res, i32p), n, 0, p(coef, i32p), taps, p(out0, i32p)) == 0   # pitch 0: copy
+    assert np.array_equal(out0, res)
+    L.SLALongTermSynthesizer_Destroy(C.c_void_p(h))
+
+
+@pytest.mark.parametrize("n,order", [(4096, 8), (5000, 4), (3000, 16), (2049, 32), (7, 8), (3, 4)])
+def test_lms_synthesize_inverts_predict(oracle, L, n, order):
+    x = W.music_like(1, n, 16, seed=n)[0] >> 16
+    res = oracle.lms_predict(x, order)
+    h = L.SLALMSFilter_Create(32)
+    out = np.zeros(n, np.int32)
+    assert L.SLALMSFilter_SynthesizeInt32(C.c_void_p(h), order, p(res, i32p), n, p(out, i32p)) == 0
+    assert np.array_equal(out, oracle.lms_synth(res, order)) and np.array_equal(out, x)
+    assert L.SLALMSFilter_SynthesizeInt32(C.c_void_p(h), order, p(res, i32p), n, p(out, i32p)) == 1
+    assert L.SLALMSFilter_Reset(C.c_void_p(h)) == 0
+    assert L.SLALMSFilter_SynthesizeInt32(C.c_void_p(h), 64, p(res, i32p), n, p(out, i32p)) == 3
+    L.SLALMSFilter_Destroy(C.c_void_p(h))
+
+
+def test_deemphasis_inverts_preemphasis_across_calls(oracle, L):
+    x = W.music_like(1, 9000, 16, seed=4)[0] >> 16
+    pre = oracle.preemph_i32(x)
+    assert np.array_equal(oracle.deemph_i32(pre), x)
+    h = L.SLAEmphasisFilter_Create()
+    got = pre.copy()
+    a, b = got[:4000], got[4000:]                      # two calls: the filter carries its last output over
+    assert L.SLAEmphasisFilter_DeEmphasisInt32(C.c_void_p(h), p(a, i32p), 4000, 5) == 0
+    assert L.SLAEmphasisFilter_DeEmphasisInt32(C.c_void_p(h), p(b, i32p), 5000, 5) == 0
+    assert np.array_equal(got, x)
+    assert L.SLAEmphasisFilter_DeEmphasisInt32(C.c_void_p(h), None, 10, 5) == 2
+    L.SLAEmphasisFilter_Destroy(C.c_void_p(h))
