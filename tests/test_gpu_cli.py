@@ -48,6 +48,26 @@ def test_reference_cli_encodes_the_known_answers_and_decodes_them_back(cli, tmp_
         assert open(wav, "rb").read() == want, extra
 
 
+CLI_PRED = os.path.join(ROOT, "oracle", "_ref", "sla_cli_ref_codec_on_hip_predictor")
+
+
+@pytest.mark.parametrize("mode", sorted(KNOWN))
+def test_reference_encoder_and_decoder_on_the_hip_predictor_api(tmp_path, mode):
+    """BASELINE's north star, literally: the reference's own SLAEncoder.c / SLADecoder.c (and coder, bit stream, CLI) with
+    src/SLAPredictor.c replaced by libsla_hip.so's per-call API -- one block per call -- reproduce the known answers"""
+    if not os.path.exists(CLI_PRED):
+        pytest.skip("oracle/_ref/sla_cli_ref_codec_on_hip_predictor not built (needs the reference sources at build time)")
+    sla = str(tmp_path / ("a_m%d.sla" % mode))
+    r = subprocess.run([CLI_PRED, "-e", "-m", str(mode), A_WAV, sla], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")
+    data = open(sla, "rb").read()
+    assert (hashlib.md5(data).hexdigest(), len(data)) == KNOWN[mode]
+    wav = str(tmp_path / ("back_m%d.wav" % mode))
+    r = subprocess.run([CLI_PRED, "-d", sla, wav], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")
+    assert open(wav, "rb").read() == open(A_WAV, "rb").read()
+
+
 def test_reference_cli_reports_a_damaged_file(cli, tmp_path):
     sla = str(tmp_path / "a.sla")
     assert run("-e", A_WAV, sla).returncode == 0
