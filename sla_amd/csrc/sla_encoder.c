@@ -464,7 +464,7 @@ static int blocks_push(struct SLAEncoder* e, uint32_t start, uint32_t nsmpl, uin
 
 #define MAX_CHUNKS 8
 enum { EV_SEARCH_S, EV_SEARCH_E, EV_SEARCH_DONE, EV_LPCB_S, EV_LPCB_E, EV_LAT_E, EV_ACF_S, EV_ACF_E, EV_BLOCK_DONE,
-       EV_TAIL_S, EV_TAIL_E, EV_TAIL_DONE, EV_UPLOADED, EV_PLANNED, EV_PLAN_DOWN, EV_LPC_DOWN, EV_PER_CHUNK };
+       EV_TAIL_S, EV_TAIL_E, EV_TAIL_DONE, EV_UPLOADED, EV_PLANNED, EV_UPLOADED2, EV_LPC_DOWN, EV_PER_CHUNK };
 
 typedef struct { uint32_t start, window, min_blk, shape, slot_base, grp_lo, grp_hi, xg; } sframe_t;
 typedef struct { uint32_t window, min_blk, nodes, ncand, cand_first; uint32_t pair[SLAI_MAX_NODES * SLAI_MAX_NODES]; } shape_t;
@@ -1051,10 +1051,12 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
   const int fused = (e->fuse_lattice && order <= 64);
   const size_t slot_lo = (size_t)k->blk_lo * C, nsl = (size_t)(k->blk_hi - k->blk_lo) * C;
 
+  /* pass 1: what k_lpc_blocks needs (one group per block and channel).  The descriptors of the lattice and FFT
+   * launches are built in pass 2, while k_lpc_blocks is already running. */
   k->bg_lo = a->nbg; k->lc_lo = a->nlc;
   for (b = k->blk_lo; b < k->blk_hi; b++) {
     const blk_t* blk = &e->blk[b];
-    uint32_t woff = 0, at;
+    uint32_t woff = 0;
     if (blk->type == SLAI_BLK_SILENT) { continue; }
     if (blk->nsmpl > MAX_ANALYSIS_WINDOW) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
     RCCHK(window_offset(e, blk->nsmpl, &woff));
@@ -1065,23 +1067,14 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
       gr->pcm_off = blk->start; gr->num_samples = blk->nsmpl; gr->channel = ch; gr->win_off = woff; gr->int_shift = shift;
       gr->cand_first = g; gr->cand_count = 1; gr->slot_first = b * C + ch; gr->pad_ = 0;
       cands[g].start = 0; cands[g].len = blk->nsmpl;
-      acf_jobs[g].blk_off = blk->start; acf_jobs[g].blk_len = blk->nsmpl; acf_jobs[g].channel = ch;
       a->grp_of_slot[(size_t)b * C + ch] = g;
-      for (at = 0; !fused && at < blk->nsmpl; at += chunk_samples) {
-        sla_hip_lattice_chunk* lc;
-        if (a->nlc >= a->lchunks_bound) { return SLA_APIRESULT_NG; }
-        lc = &lch[a->nlc++];
-        lc->blk_off = blk->start; lc->blk_len = blk->nsmpl; lc->chunk_start = at;
-        lc->count = (blk->nsmpl - at < chunk_samples) ? (blk->nsmpl - at) : chunk_samples;
-        lc->channel = ch; lc->slot = b * C + ch; lc->int_shift = shift;
-      }
     }
     if (blk->nsmpl > max_window) { max_window = blk->nsmpl; }
   }
-  k->bg_hi = a->nbg; k->lc_hi = a->nlc;
-  ng = k->bg_hi - k->bg_lo; nl = k->lc_hi - k->lc_lo;
+  k->bg_hi = a->nbg;
+  ng = k->bg_hi - k->bg_lo;
 
-  if (ng == 0) { HIPCHK(hipEventRecord(ev[EV_LPCB_S], e->stream2)); }
+  if (ng == 0) { k->lc_hi = a->nlc; HIPCHK(hipEventRecord(ev[EV_LPCB_S], e->stream2)); }
   if (ng > 0) {
     sla_hip_lpc_group* dg = (sla_hip_lpc_group*)e->d_bgroups.ptr + k->bg_lo;
     sla_hip_lattice_chunk* dl = (sla_hip_lattice_chunk*)e->d_chunks.ptr + k->lc_lo;
@@ -1089,8 +1082,6 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     uint32_t slots = 0;
     HIPCHK(hipMemcpyAsync(dg, groups + k->bg_lo, sizeof(sla_hip_lpc_group) * ng, hipMemcpyHostToDevice, e->stream_up));
     HIPCHK(hipMemcpyAsync((sla_hip_lpc_cand*)e->d_bcands.ptr + k->bg_lo, cands + k->bg_lo, sizeof(sla_hip_lpc_cand) * ng, hipMemcpyHostToDevice, e->stream_up));
-    if (nl > 0) { HIPCHK(hipMemcpyAsync(dl, lch + k->lc_lo, sizeof(sla_hip_lattice_chunk) * nl, hipMemcpyHostToDevice, e->stream_up)); }
-    HIPCHK(hipMemcpyAsync(da, acf_jobs + k->bg_lo, sizeof(sla_hip_acf_job) * ng, hipMemcpyHostToDevice, e->stream_up));
     /* (k_lpc_blocks writes every output slot of its groups; slots of silent blocks are never read) */
     /* uploads and result downloads travel on their own streams: the kernel stream runs kernel after kernel */
     HIPCHK(hipEventRecord(ev[EV_UPLOADED], e->stream_up));
@@ -1116,6 +1107,32 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     HIPCHK(hipMemcpyAsync((int32_t*)e->h_kint.ptr + slot_lo * O1, (int32_t*)e->d_kint.ptr + slot_lo * O1, sizeof(int32_t) * nsl * O1, hipMemcpyDeviceToHost, e->stream_down));
     HIPCHK(hipMemcpyAsync((uint32_t*)e->h_rshift.ptr + slot_lo, (uint32_t*)e->d_rshift.ptr + slot_lo, sizeof(uint32_t) * nsl, hipMemcpyDeviceToHost, e->stream_down));
     HIPCHK(hipEventRecord(ev[EV_LPC_DOWN], e->stream_down));
+    /* pass 2 (k_lpc_blocks is running): lattice chunks and FFT jobs */
+    {
+      uint32_t g = k->bg_lo;
+      for (b = k->blk_lo; b < k->blk_hi; b++) {
+        const blk_t* blk = &e->blk[b];
+        uint32_t at;
+        if (blk->type == SLAI_BLK_SILENT) { continue; }
+        for (ch = 0; ch < C; ch++, g++) {
+          acf_jobs[g].blk_off = blk->start; acf_jobs[g].blk_len = blk->nsmpl; acf_jobs[g].channel = ch;
+          for (at = 0; !fused && at < blk->nsmpl; at += chunk_samples) {
+            sla_hip_lattice_chunk* lc;
+            if (a->nlc >= a->lchunks_bound) { return SLA_APIRESULT_NG; }
+            lc = &lch[a->nlc++];
+            lc->blk_off = blk->start; lc->blk_len = blk->nsmpl; lc->chunk_start = at;
+            lc->count = (blk->nsmpl - at < chunk_samples) ? (blk->nsmpl - at) : chunk_samples;
+            lc->channel = ch; lc->slot = b * C + ch; lc->int_shift = shift;
+          }
+        }
+      }
+      k->lc_hi = a->nlc;
+      nl = k->lc_hi - k->lc_lo;
+      if (nl > 0) { HIPCHK(hipMemcpyAsync(dl, lch + k->lc_lo, sizeof(sla_hip_lattice_chunk) * nl, hipMemcpyHostToDevice, e->stream_up)); }
+      HIPCHK(hipMemcpyAsync(da, acf_jobs + k->bg_lo, sizeof(sla_hip_acf_job) * ng, hipMemcpyHostToDevice, e->stream_up));
+      HIPCHK(hipEventRecord(ev[EV_UPLOADED2], e->stream_up));
+      HIPCHK(hipStreamWaitEvent(e->stream2, ev[EV_UPLOADED2], 0));
+    }
     if (!fused) {
       slai_next_launch_span(SPAN_SLOT(e, c, 1));
       RCCHK(sla_hip_launch_lattice(e->pcm_dev, e->stride, ms, order, dl, nl, (const int32_t*)e->d_kint.ptr, RES1(e), e->stream2));
