@@ -17,7 +17,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsla_hip.so")
+LIB_PATH = os.environ.get("SLA_HIP_LIB") or os.path.join(_HERE, "libsla_hip.so")     # SLA_HIP_LIB: A/B runs against another build
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)

@@ -80,6 +80,7 @@ struct SLAEncoder {
   uint32_t* h_or;
   size_t nz_ones_cap; uint64_t nz_ones_words;    /* h_nz words [0, nz_ones_words) are known to be all ones (h_nz.cap == nz_ones_cap) */
   pinbuf_t h_stage[2]; devbuf_t d_stage[2]; hipEvent_t ev_stage[2];
+  hipEvent_t ev_prep;               /* the prepass result has reached the host */
 
   /* window pool: tables for every block length seen so far */
   double*   win_host; size_t win_count, win_cap;
@@ -290,7 +291,8 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
     e->stream_up = e->stream2; e->stream_down = e->stream2; e->own_copy_streams = 0;
   }
   for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { if (hipEventCreate(&e->ev[i]) != hipSuccess) { free(e); return NULL; } }
-  if (hipEventCreate(&e->ev_stage[0]) != hipSuccess || hipEventCreate(&e->ev_stage[1]) != hipSuccess) { free(e); return NULL; }
+  if (hipEventCreate(&e->ev_stage[0]) != hipSuccess || hipEventCreate(&e->ev_stage[1]) != hipSuccess
+      || hipEventCreate(&e->ev_prep) != hipSuccess) { free(e); return NULL; }
   e->chunks = 2;
   env = getenv("SLA_HIP_CHUNKS");
   if (env != NULL && atoi(env) > 0) { e->chunks = (uint32_t)atoi(env); }
@@ -372,6 +374,7 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
     (void)hipEventDestroy(e->ev_stage[i]);
   }
   for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { (void)hipEventDestroy(e->ev[i]); }
+  (void)hipEventDestroy(e->ev_prep);
   (void)hipStreamDestroy(e->stream); (void)hipStreamDestroy(e->stream2); (void)hipStreamDestroy(e->stream3);
   if (e->own_copy_streams) { (void)hipStreamDestroy(e->stream_up); (void)hipStreamDestroy(e->stream_down); }
   slai_fft_plan_destroy(e->fft);
@@ -741,6 +744,23 @@ static int build_tables(struct SLAEncoder* e, actx_t* a, const uint64_t* nz)
   return 0;
 }
 
+static int pipeline_reserve(struct SLAEncoder* e, const actx_t* a);
+
+/* candidate and group tables of the partition search -> device (in order on the search stream) */
+static int upload_search_tables(struct SLAEncoder* e, const actx_t* a)
+{
+  if (a->ncands > 0) {
+    HIPCHK(hipMemcpyAsync(e->d_cands.ptr, e->h_cands.ptr, sizeof(sla_hip_lpc_cand) * a->ncands, hipMemcpyHostToDevice, e->stream));
+  }
+  if (a->nxg > 0) {
+    HIPCHK(hipMemcpyAsync(e->d_xgroups.ptr, e->h_xgroups.ptr, sizeof(sla_hip_lpc_group) * a->nxg, hipMemcpyHostToDevice, e->stream));
+  }
+  if (a->nsgroups > 0) {
+    HIPCHK(hipMemcpyAsync(e->d_groups.ptr, e->h_groups.ptr, sizeof(sla_hip_lpc_group) * a->nsgroups, hipMemcpyHostToDevice, e->stream));
+  }
+  return 0;
+}
+
 static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
 {
   const uint32_t C = e->wave_format.num_channels, bps = e->wave_format.bit_per_sample;
@@ -759,6 +779,8 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
     RCCHK(build_tables(e, a, (const uint64_t*)e->h_nz.ptr));
     a->exact = (e->search_exact && SLAI_SEARCH_DELTA == SLA_HIP_XTILE && maxb <= SLA_HIP_XTILE * SLA_HIP_XTILES
                 && sla_hip_search_exact_lags(order) != 0 && e->h_or[0] != 0);
+    RCCHK(pipeline_reserve(e, a));
+    RCCHK(upload_search_tables(e, a));
     return 0;
   }
   RCCHK(dev_reserve(&e->d_or, 64));
@@ -776,9 +798,14 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
     const uint64_t head_words = nwords - tail_words;
     HIPCHK(hipMemcpyAsync(e->h_or, e->d_or.ptr, 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync((uint64_t*)e->h_nz.ptr + head_words, (uint64_t*)e->d_nz.ptr + head_words, (size_t)tail_words * 8, hipMemcpyDeviceToHost, e->stream));
-    /* while the prepass runs: the tables of a file without silence (the usual case; checked below) */
+    HIPCHK(hipEventRecord(e->ev_prep, e->stream));
+    /* while the prepass runs: the tables of a file without silence (the usual case; checked below), every buffer of
+     * the pipeline, and the tables on their way to the device behind the prepass -- so that the first search kernel
+     * can follow the host's look at the prepass result without further copies in between */
     RCCHK(build_tables(e, a, NULL));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    RCCHK(pipeline_reserve(e, a));
+    RCCHK(upload_search_tables(e, a));
+    HIPCHK(hipEventSynchronize(e->ev_prep));
     if (e->h_or[1] != 0) {
       HIPCHK(hipMemcpyAsync(e->h_nz.ptr, e->d_nz.ptr, (size_t)head_words * 8, hipMemcpyDeviceToHost, e->stream));
       HIPCHK(hipStreamSynchronize(e->stream));
@@ -822,6 +849,8 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
     a->nsf = 0; a->nshapes = 0; a->ncands = 0; a->nsgroups = 0; a->nslots = 0; a->nxg = 0;
     a->blocks_bound = 0; a->lchunks_bound = 0;
     RCCHK(build_tables(e, a, nz));
+    RCCHK(pipeline_reserve(e, a));
+    RCCHK(upload_search_tables(e, a));
   }
   a->exact = (e->search_exact && SLAI_SEARCH_DELTA == SLA_HIP_XTILE && maxb <= SLA_HIP_XTILE * SLA_HIP_XTILES
               && sla_hip_search_exact_lags(order) != 0 && e->h_or[0] != 0);
@@ -849,7 +878,7 @@ static int pipeline_reserve(struct SLAEncoder* e, const actx_t* a)
     RCCHK(pin_reserve(&e->h_nparts, sizeof(uint32_t) * live));
     RCCHK(pin_reserve(&e->h_pstatus, sizeof(uint32_t) * live));
   }
-  if (a->exact) {
+  if (e->search_exact && sla_hip_search_exact_lags(order) != 0) {      /* (whether the search may use them is decided once the prepass is in) */
     RCCHK(dev_reserve(&e->d_tile_sums, sizeof(double) * ((size_t)a->nxg + 1) * SLA_HIP_XTILES * 2 * sla_hip_search_exact_lags(order)));
   }
   /* blocks */
@@ -898,8 +927,11 @@ static int pipeline_reserve(struct SLAEncoder* e, const actx_t* a)
   memset(e->bc, 0, sizeof(blkch_t) * nslots);
   /* tables that never change while kernels are in flight */
   if (e->win_dirty) {
+    /* (new block lengths since the last file: rare.  win_host is ordinary memory that the next file may realloc, so the
+     * copy is waited for -- together with whatever else the search stream is doing) */
     RCCHK(dev_reserve(&e->d_winpool, sizeof(double) * (e->win_count + 1)));
     HIPCHK(hipMemcpyAsync(e->d_winpool.ptr, e->win_host, sizeof(double) * e->win_count, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     e->win_dirty = 0;
   }
   if (!e->twiddle_ready) {
@@ -911,7 +943,6 @@ static int pipeline_reserve(struct SLAEncoder* e, const actx_t* a)
     free(tw);
     e->twiddle_ready = 1;
   }
-  HIPCHK(hipStreamSynchronize(e->stream));
   return 0;
 }
 
@@ -1316,10 +1347,12 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
     if (!a.job_blk || !a.job_ch || !a.job_grp || !a.grp_of_slot || !a.parts || !a.nparts || !a.status) { actx_free(&a); return SLA_APIRESULT_NG; }
   }
   TRACE("prepared (prepass + tables)", a.nsf);
-  if ((rc = pipeline_reserve(e, &a)) != 0) { actx_free(&a); return rc; }
+  if (preset_blocks && (rc = pipeline_reserve(e, &a)) != 0) { actx_free(&a); return rc; }      /* (otherwise done while the prepass ran) */
+  /* the span slots are cleared on the search stream: every kernel that writes one is launched after the host has seen a
+   * search of this run complete, i.e. behind this memset */
   if (dev_reserve(&e->d_spans, sizeof(unsigned long long) * MAX_CHUNKS * 4 * 2) != 0
       || hipMemsetAsync(e->d_spans.ptr, 0, sizeof(unsigned long long) * MAX_CHUNKS * 4 * 2, e->stream) != hipSuccess
-      || hipStreamSynchronize(e->stream) != hipSuccess) { actx_free(&a); return SLA_APIRESULT_NG; }
+      || (preset_blocks && hipStreamSynchronize(e->stream) != hipSuccess)) { actx_free(&a); return SLA_APIRESULT_NG; }
   TRACE("reserved", 0);
 
   /* chunking: equal runs of super-frames */
@@ -1361,15 +1394,6 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   }
 
   if (!preset_blocks) {
-    if (a.ncands > 0) {
-      HIPCHK(hipMemcpyAsync(e->d_cands.ptr, e->h_cands.ptr, sizeof(sla_hip_lpc_cand) * a.ncands, hipMemcpyHostToDevice, e->stream));
-    }
-    if (a.nxg > 0) {
-      HIPCHK(hipMemcpyAsync(e->d_xgroups.ptr, e->h_xgroups.ptr, sizeof(sla_hip_lpc_group) * a.nxg, hipMemcpyHostToDevice, e->stream));
-    }
-    if (a.nsgroups > 0) {
-      HIPCHK(hipMemcpyAsync(e->d_groups.ptr, e->h_groups.ptr, sizeof(sla_hip_lpc_group) * a.nsgroups, hipMemcpyHostToDevice, e->stream));
-    }
     HIPCHK(hipMemsetAsync((uint32_t*)e->d_or.ptr + 2, 0, sizeof(uint32_t), e->stream));      /* groups rerun as serial chains */
     for (c = 0; c < a.nchunks && rc == 0; c++) { rc = search_launch(e, &a, c); }
     TRACE("search launched", a.nchunks);
