@@ -288,7 +288,7 @@ __device__ __forceinline__ void levinson_out(const double* rc, double* a, double
 // (candidate, lag) chains are numbered through, so that one wave-instruction of the chain loop carries
 // up to 64 busy lanes even when a single group has only a few chains (chosen blocks: `order` chains).
 // The chain loop is bound by FP64 / LDS issue per WAVE, not per lane, so lanes are what has to be filled.
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(512)
 void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
            const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, uint32_t pack,
            const sla_hip_lpc_cand* __restrict__ cands,
@@ -369,9 +369,9 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
   // two loop bodies back to back in the idle lanes of one wave is 1.1-1.4x slower than this split.)
   if (dbg_skip & 1) {
     for (uint32_t q = threadIdx.x; q < nc * O1; q += blockDim.x) { r[q] = 1.0 / (1.0 + q); }
-  } else if (threadIdx.x < 192) {
+  } else if (threadIdx.x < blockDim.x - 64) {
     const uint32_t nchains = nc * order;
-    for (uint32_t q = threadIdx.x; q < nchains; q += 192) {
+    for (uint32_t q = threadIdx.x; q < nchains; q += blockDim.x - 64) {
       const uint32_t cidx = q / order, lag = 1 + (q - cidx * order);
       uint32_t k;
       const sla_hip_lpc_cand* cd = locate(cidx, k);
@@ -380,7 +380,7 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
       r[cidx * O1 + lag] = (dbg_skip & 8) ? 0.0 : ((lag < n) ? chain_lag(xs, n, lag) : 0.0);
     }
   } else {
-    for (uint32_t cidx = threadIdx.x - 192; cidx < nc; cidx += 64) {
+    for (uint32_t cidx = threadIdx.x - (blockDim.x - 64); cidx < nc; cidx += 64) {
       uint32_t k;
       const sla_hip_lpc_cand* cd = locate(cidx, k);
       r[cidx * O1] = (dbg_skip & 4) ? 1.0 : chain_lag0(lds + (size_t)k * x_region + cd->start, cd->len);
@@ -1720,7 +1720,14 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
   if (lds > SLA_HIP_LDS_BUDGET) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
   hipError_t e = ensure_dynamic_lds((const void*)k_lpc, lds);
   if (e != hipSuccess) { return hip_rc(e); }
-  hipLaunchKernelGGL(k_lpc, dim3((num_groups + pack - 1) / pack), dim3(256), lds, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
+  // a group with many chains (the partition search: candidates x lags) gets 7 chain waves instead of 3: the window
+  // owns the LDS, so the workgroups per CU are few and more waves per workgroup are what hides the LDS gathers
+  // (C5: 14.4 -> 13.3 ms of search per minute of audio)
+  uint32_t lpc_threads = ((size_t)pack * max_cands_per_group * order >= 448) ? 512u : 256u;
+  if (getenv("SLA_HIP_LPC_THREADS") != nullptr && (atoi(getenv("SLA_HIP_LPC_THREADS")) == 256 || atoi(getenv("SLA_HIP_LPC_THREADS")) == 512)) {
+    lpc_threads = (uint32_t)atoi(getenv("SLA_HIP_LPC_THREADS"));
+  }
+  hipLaunchKernelGGL(k_lpc, dim3((num_groups + pack - 1) / pack), dim3(lpc_threads), lds, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
                      d_groups, num_groups, pack, d_cands, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)x_region,
                      (uint32_t)(getenv("SLA_HIP_LPC_SKIP") ? (atoi(getenv("SLA_HIP_LPC_SKIP")) & 127) : 0) | mode_flags, d_rerun_counter);
   return hip_rc(hipGetLastError());
