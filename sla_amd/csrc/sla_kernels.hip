@@ -1250,7 +1250,7 @@ void k_tail(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, u
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t t = lane & (G - 1);
   const uint32_t grp_base = lane - t;
-  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const uint32_t j = wave * JPW + (lane / G);
   const bool have = (j < num_jobs);
   const sla_hip_tail_job job = jobs[have ? j : 0];
@@ -1872,8 +1872,9 @@ static int launch_tail_impl(const int32_t* d_res_in, int32_t* d_res_out, uint64_
   if (longterm_order > 5 || !(longterm_order & 1)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (!(lms_order == 4 || lms_order == 8 || lms_order == 16 || lms_order == 32)) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
   if (num_jobs == 0) { return 0; }
-  const uint32_t jobs_per_block = 4 * (64 / (2 * lms_order));     // 4 waves, 64/(2*order) jobs per wave
-  dim3 grid((num_jobs + jobs_per_block - 1) / (jobs_per_block ? jobs_per_block : 1)), block(256);
+  const uint32_t tail_waves = (getenv("SLA_HIP_TAIL_WAVES") != nullptr && atoi(getenv("SLA_HIP_TAIL_WAVES")) >= 1 && atoi(getenv("SLA_HIP_TAIL_WAVES")) <= 4) ? (uint32_t)atoi(getenv("SLA_HIP_TAIL_WAVES")) : 1u;     /* one wave per workgroup: the dispatcher spreads the (few, long-running) waves over all CUs */
+  const uint32_t jobs_per_block = tail_waves * (64 / (2 * lms_order));     // 64/(2*order) jobs per wave
+  dim3 grid((num_jobs + jobs_per_block - 1) / (jobs_per_block ? jobs_per_block : 1)), block(64 * tail_waves);
   hipStream_t st = (hipStream_t)stream;
   unsigned long long* span = take_span();
   switch (lms_order) {
