@@ -120,6 +120,19 @@ typedef struct sla_hip_pack_block {
 
 /* ---- (1) kernel launchers ----------------------------------------------- */
 
+/* Tuning knobs of the launchers.  Nothing on the launch path reads the environment: an encoder handle owns one of
+ * these (filled once in SLAEncoder_Create, changed through sla_hip_encoder_set_option) and names it to the
+ * launchers of the calling host thread before it launches; a thread that never called sla_hip_use_tuning (or
+ * passed NULL) gets the defaults = all zeros.  None of the knobs changes a result, only how the work is laid out. */
+typedef struct sla_hip_tuning {
+  uint32_t lpc_pack;            /* windows per workgroup of k_lpc / k_lpc_blocks, 0 = automatic                      */
+  uint32_t lpc_threads;         /* 256 or 512 threads per k_lpc workgroup, 0 = automatic                             */
+  uint32_t lpc_blocks_chains;   /* 1: chosen blocks through k_lpc's serial chains instead of k_lpc_blocks            */
+  uint32_t tail_waves;          /* waves per k_tail workgroup (1..4), 0 = automatic (1)                              */
+  double   plan_margin;         /* certification margin of k_plan, 0 = 1e-4 (tests raise it to force the host plan)  */
+} sla_hip_tuning;
+void sla_hip_use_tuning(const sla_hip_tuning* tuning);
+
 /* d_or_mask[0] = OR of every input word, d_or_mask[1] = number of all-zero words of the mask; d_nz_mask: one
  * bit per sample "any channel non-zero after right-justify / mid-side", ceil(num_samples/64) words. */
 int sla_hip_launch_prepass(const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_channels,
@@ -169,8 +182,14 @@ int sla_hip_launch_lpc_rerun(const int32_t* d_pcm, uint64_t plane_stride, uint32
  * the result is bit-identical to the serial order.  Groups: one per (super-frame, channel) listing ALL its
  * candidates; candidates must start on a tile boundary and end on one or at the end of the window.
  * d_tile_sums: num_groups * SLA_HIP_XTILES * 2 * sla_hip_search_exact_lags(order) doubles of scratch.
- * A group whose energy reaches the limit gets NaN in r[0] of every candidate: the caller reruns those
- * groups through sla_hip_launch_lpc_rerun. */
+ * A group whose energy reaches the limit: with cert_safety <= 0 it gets NaN in r[0] of every candidate and the
+ * caller reruns it through sla_hip_launch_lpc_rerun.  With cert_safety > 0 (the encoder passes 64) its candidates
+ * keep their tile-sum results -- close to, but no longer bit-identical with, the reference's serially rounded sums --
+ * and carry in parcor[0] (0 for every exact candidate) the half width w of log2(e_p), e_p = r0 * prod(1 - k_j^2):
+ * the reference's own value of log2(e_p) provably lies within +-w (Loewner-order bracket of the prediction error over
+ * every Toeplitz matrix within cert_safety x the summation error bounds of both sides; see k_search_finish), or
+ * +inf when no such bracket exists.  The code-length estimate depends on the autocorrelation only through e_p, so
+ * sla_hip_launch_plan can decide whether the partition is certain. */
 #define SLA_HIP_XTILE  1024u
 #define SLA_HIP_XTILES 16u
 uint32_t sla_hip_search_exact_lags(uint32_t order);      /* padded lag count, 0: order not supported */
@@ -178,7 +197,7 @@ int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_stride, uin
                                 const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
                                 uint32_t max_cands_per_group,
                                 const sla_hip_lpc_cand* d_cands, double* d_tile_sums, double* d_out,
-                                double exact_limit, sla_hip_stream_t stream);
+                                double exact_limit, double cert_safety, sla_hip_stream_t stream);
 
 /* The scalar tail of the partition search on the device: estimated code length per candidate, adjacency
  * matrix, shortest path (reference src/SLAPredictor.c:416-468, 1521-1581, 1615-1692).  d_groups: the groups of
@@ -186,11 +205,14 @@ int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_stride, uin
  * sla_hip_launch_lpc's) output.  Per super-frame: d_status 0 = d_num_parts block lengths in d_parts
  * (SLA_HIP_PLAN_NODES entries per super-frame) are exactly what the reference's host arithmetic decides;
  * 1 = a comparison came closer than the device logarithm can be trusted (or the input was flagged / not
- * finite): the caller must redo this super-frame on the host. */
+ * finite): the caller must redo this super-frame on the host from the candidates' doubles; 2 = the super-frame's
+ * candidates were certified tile sums (parcor[0] = width > 0) and some comparison came closer than the widths allow:
+ * every candidate of the super-frame has been flagged (NaN in r[0]) -- the caller reruns them as serial chains
+ * (sla_hip_launch_lpc_rerun) and decides on the host. */
 #define SLA_HIP_PLAN_NODES 17u
 int sla_hip_launch_plan(const sla_hip_lpc_group* d_groups, uint32_t num_superframes, uint32_t num_channels,
                         uint32_t order, uint32_t bits_per_sample, const sla_hip_lpc_cand* d_cands,
-                        const double* d_lpc_out, uint32_t* d_parts, uint32_t* d_num_parts, uint32_t* d_status,
+                        double* d_lpc_out, uint32_t* d_parts, uint32_t* d_num_parts, uint32_t* d_status,
                         sla_hip_stream_t stream);
 
 /* Building blocks of the per-call predictor API (include/SLAPredictor.h), also usable on their own:
@@ -387,6 +409,18 @@ int sla_hip_bind_residual_planes(struct SLAEncoder* encoder, int32_t* d_lattice,
 
 /* Copy the last analysis into caller arrays. */
 int sla_hip_get_trace(struct SLAEncoder* encoder, sla_hip_trace* trace);
+
+/* Options of one encoder handle, by name (the environment variable of the same meaning, read once in
+ * SLAEncoder_Create, is given in brackets).  Layout knobs: "lpc_pack" [SLA_HIP_LPC_PACK], "lpc_threads"
+ * [SLA_HIP_LPC_THREADS], "tail_waves" [SLA_HIP_TAIL_WAVES], "chunks" [SLA_HIP_CHUNKS],
+ * "threads" (host pool) [SLA_HIP_THREADS].  Route switches -- every route gives the same bytes; tests force the
+ * slower exact ones through these: "search_exact" (0: no tile-sum search) [SLA_HIP_SEARCH=chain], "exact_bits"
+ * (log2 of the tile-sum energy limit, 1..53) [SLA_HIP_EXACT_BITS], "cert_safety" (safety factor of the certificate for
+ * windows over that limit, default 64; 0: no certificate, such windows are rerun as serial chains) [SLA_HIP_CERT],
+ * "device_plan" (0: partitions decided on the host) [SLA_HIP_PLAN=host],
+ * "plan_margin" [SLA_HIP_PLAN_MARGIN], "lpc_blocks_chains" [SLA_HIP_LPC_BLOCKS=chains], "fuse_lattice"
+ * [SLA_HIP_LATTICE=fused].  Returns SLA_APIRESULT_INVALID_ARGUMENT for an unknown name or a value out of range. */
+int sla_hip_encoder_set_option(struct SLAEncoder* encoder, const char* name, double value);
 
 /* Name of the device the library bound to ("" when none). */
 const char* sla_hip_device_name(void);

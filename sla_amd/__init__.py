@@ -133,6 +133,7 @@ def lib():
         L.sla_hip_last_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.sla_hip_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.sla_hip_search_exact_lags.restype = C.c_uint32
+        L.sla_hip_encoder_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         L.sla_hip_encode_batch.argtypes = [C.c_void_p, C.POINTER(BatchItem), C.c_uint32]
         L.sla_hip_analyze_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, u32p, u32p, C.c_uint32,
                                                    u32p, C.POINTER(C.c_float)]
@@ -173,7 +174,8 @@ EXPORTED_SYMBOLS = [
     "sla_hip_get_trace", "sla_hip_device_name", "sla_hip_last_timing", "sla_hip_launch_search_exact",
     "sla_hip_search_exact_lags", "sla_hip_launch_plan", "sla_hip_last_counters", "sla_hip_launch_lpc_rerun", "sla_hip_last_kernel_ms", "sla_hip_launch_lpc_blocks",
     "sla_hip_launch_lpc_f64", "sla_hip_launch_lattice_raw", "sla_hip_launch_tail_stages", "sla_hip_launch_emphasis_i32",
-    "sla_hip_launch_emphasis_f64",
+    "sla_hip_launch_emphasis_f64", "sla_hip_use_tuning",
+    "sla_hip_encoder_set_option",
     # include/SLAPredictor.h, include/SLACoder.h (per-call API of the reference, encode side)
     "SLALPCCalculator_Create", "SLALPCCalculator_Destroy", "SLALPCCalculator_CalculatePARCORCoefDouble",
     "SLALPCCalculator_EstimateCodeLength", "SLALPCSynthesizer_Create", "SLALPCSynthesizer_Destroy", "SLALPCSynthesizer_Reset",
@@ -269,6 +271,10 @@ class Encoder:
     def _check(self, rc, where):
         if rc != 0:
             raise SlaError(rc, where)
+
+    def set_option(self, name, value):
+        """sla_hip_encoder_set_option: layout knobs and route switches of this handle (include/sla_hip.h)"""
+        self._check(self._lib.sla_hip_encoder_set_option(self._h, name.encode(), float(value)), "sla_hip_encoder_set_option(%s)" % name)
 
     def set_wave_format(self, num_channels, bit_per_sample, sampling_rate, offset_lshift=0):
         wf = SLAWaveFormat(num_channels, bit_per_sample, sampling_rate, offset_lshift)

@@ -62,7 +62,11 @@ struct SLAEncoder {
   int      fuse_lattice;            /* 1: the lattice runs inside k_lpc_blocks (SLA_HIP_LATTICE=fused), 0: separate k_lattice launch */
   int      device_plan;             /* 1: code lengths + Dijkstra on the device where certified (default), 0: host only */
   int      search_exact;            /* 1: tile-sum search where it is provably bit-exact (default), 0: chains only */
-  int      exact_bits;              /* log2 of the energy limit in units^2 (51; lowered by tests to force the fallback) */
+  int      exact_bits;              /* log2 of the energy limit in units^2 (53; lowered by tests to force the fallback) */
+  double   cert_safety;             /* windows over the limit: safety factor of the partition certificate (64); 0: always rerun them as serial chains */
+  int      plan_copy_down;          /* 1: plan results travel on the download stream (debugging; default: search stream) */
+  int      trace;                   /* host-side timeline on stderr (SLA_HIP_TRACE) */
+  sla_hip_tuning tune;              /* launcher knobs, named to the launchers at every API entry */
   uint32_t host_planned;            /* last analysis: super-frames whose partition the host had to decide */
   uint32_t fallback_groups;         /* last analysis: search groups that had to take the chain kernel */
   slai_fft_plan* fft;
@@ -258,6 +262,8 @@ static void parallel_for(struct slai_pool* p, uint32_t count, void (*fn)(void*, 
 /* ------------------------------------------------------------- create / destroy */
 
 static char g_device_name[256] = "";
+static int g_trace_on = 0;              /* SLA_HIP_TRACE, read in SLAEncoder_Create */
+void SLAEncoder_Destroy(struct SLAEncoder* e);
 const char* sla_hip_device_name(void) { return g_device_name; }
 
 struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
@@ -273,26 +279,33 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
     fprintf(stderr, "libsla_hip: no HIP device available -- the encode path has no CPU fallback\n");
     return NULL;
   }
+  if (slai_host_check() != 0) {
+    fprintf(stderr, "libsla_hip: this host does not evaluate long double / libm the way the reference's x86-64 glibc build does -- "
+                    "bit-identical output cannot be guaranteed, refusing to create an encoder\n");
+    return NULL;
+  }
   e = (struct SLAEncoder*)calloc(1, sizeof(*e));
   if (e == NULL) { return NULL; }
   e->cfg = *config;
-  if (hipGetDevice(&e->device) != hipSuccess) { free(e); return NULL; }
+  /* the handle is bound to the device that is current now; every API entry makes it current again */
+  if (hipGetDevice(&e->device) != hipSuccess) { goto fail; }
   if (hipGetDeviceProperties(&prop, e->device) == hipSuccess) {
     snprintf(g_device_name, sizeof(g_device_name), "%.160s (%.80s)", prop.name, prop.gcnArchName);
   }
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess
       || hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess
-      || hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess
-      || hipStreamCreateWithFlags(&e->stream_up, hipStreamNonBlocking) != hipSuccess
-      || hipStreamCreateWithFlags(&e->stream_down, hipStreamNonBlocking) != hipSuccess) { free(e); return NULL; }
-  e->own_copy_streams = 1;
+      || hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess) { goto fail; }
   if (getenv("SLA_HIP_COPY_STREAMS") != NULL && atoi(getenv("SLA_HIP_COPY_STREAMS")) == 0) {   /* debugging: copies back on the kernel stream */
-    (void)hipStreamDestroy(e->stream_up); (void)hipStreamDestroy(e->stream_down);
     e->stream_up = e->stream2; e->stream_down = e->stream2; e->own_copy_streams = 0;
+  } else {
+    if (hipStreamCreateWithFlags(&e->stream_up, hipStreamNonBlocking) != hipSuccess
+        || hipStreamCreateWithFlags(&e->stream_down, hipStreamNonBlocking) != hipSuccess) { goto fail; }
+    e->own_copy_streams = 1;
   }
-  for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { if (hipEventCreate(&e->ev[i]) != hipSuccess) { free(e); return NULL; } }
+  for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { if (hipEventCreate(&e->ev[i]) != hipSuccess) { goto fail; } }
   if (hipEventCreate(&e->ev_stage[0]) != hipSuccess || hipEventCreate(&e->ev_stage[1]) != hipSuccess
-      || hipEventCreate(&e->ev_prep) != hipSuccess) { free(e); return NULL; }
+      || hipEventCreate(&e->ev_prep) != hipSuccess) { goto fail; }
+  /* every knob is read here, once; sla_hip_encoder_set_option changes them afterwards */
   e->chunks = 2;
   env = getenv("SLA_HIP_CHUNKS");
   if (env != NULL && atoi(env) > 0) { e->chunks = (uint32_t)atoi(env); }
@@ -307,39 +320,63 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
     }
     if (e->split_count > 0) { e->chunks = e->split_count; }
   }
-  e->search_exact = 1; e->exact_bits = 51; e->device_plan = 1;
+  e->search_exact = 1; e->exact_bits = 53; e->device_plan = 1; e->cert_safety = 64.0;
   /* measured on C2: the lattice inside k_lpc_blocks costs 0.6 ms per step (9 wave-chunks on the 8 waves of a workgroup
    * that has nothing else left to overlap them with), its own launch 0.27 ms: separate by default */
   e->fuse_lattice = 0;
   env = getenv("SLA_HIP_LATTICE");
   if (env != NULL && strcmp(env, "fused") == 0) { e->fuse_lattice = 1; }
   env = getenv("SLA_HIP_LPC_BLOCKS");
-  if (env != NULL && strcmp(env, "chains") == 0) { e->fuse_lattice = 0; }
+  if (env != NULL && strcmp(env, "chains") == 0) { e->fuse_lattice = 0; e->tune.lpc_blocks_chains = 1; }
   env = getenv("SLA_HIP_PLAN");
   if (env != NULL && strcmp(env, "host") == 0) { e->device_plan = 0; }
   env = getenv("SLA_HIP_SEARCH");
   if (env != NULL && strcmp(env, "chain") == 0) { e->search_exact = 0; }
+  env = getenv("SLA_HIP_CERT");
+  if (env != NULL && atof(env) >= 0.0) { e->cert_safety = atof(env); }
   env = getenv("SLA_HIP_EXACT_BITS");
-  if (env != NULL && atoi(env) > 0 && atoi(env) < 51) { e->exact_bits = atoi(env); }
-  if (hipHostMalloc((void**)&e->h_or, 4096, hipHostMallocDefault) != hipSuccess) { free(e); return NULL; }   /* [0,1] prepass words, [2] rerun counter, +64 B: kernel spans */
+  if (env != NULL && atoi(env) > 0 && atoi(env) <= 53) { e->exact_bits = atoi(env); }
+  env = getenv("SLA_HIP_PLAN_COPY");
+  e->plan_copy_down = (env != NULL && strcmp(env, "down") == 0);
+  e->trace = (getenv("SLA_HIP_TRACE") != NULL);
+  g_trace_on = e->trace;
+  env = getenv("SLA_HIP_LPC_PACK");
+  if (env != NULL && atoi(env) >= 1) { e->tune.lpc_pack = (uint32_t)atoi(env); }
+  env = getenv("SLA_HIP_LPC_THREADS");
+  if (env != NULL && (atoi(env) == 256 || atoi(env) == 512)) { e->tune.lpc_threads = (uint32_t)atoi(env); }
+  env = getenv("SLA_HIP_TAIL_WAVES");
+  if (env != NULL && atoi(env) >= 1 && atoi(env) <= 4) { e->tune.tail_waves = (uint32_t)atoi(env); }
+  env = getenv("SLA_HIP_PLAN_MARGIN");
+  if (env != NULL && atof(env) > 0.0) { e->tune.plan_margin = atof(env); }
+  if (hipHostMalloc((void**)&e->h_or, 4096, hipHostMallocDefault) != hipSuccess) { e->h_or = NULL; goto fail; }   /* [0,1] prepass words, [2] rerun counter, +64 B: kernel spans */
   {
     uint32_t fft = 1;
     while (fft < config->max_num_block_samples * 2) { fft <<= 1; }    /* src/SLAEncoder.c:110 */
     if (fft < 8) { fft = 8; }
     e->fft = slai_fft_plan_create(fft);
+    if (e->fft == NULL) { goto fail; }
   }
   {
+    /* host pool: the CPUs this process may use, shared with the other ranks of a one-process-per-GPU launch */
     cpu_set_t set;
+    uint32_t ranks = 1;
     e->threads = (uint32_t)sysconf(_SC_NPROCESSORS_ONLN);
     if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0 && (uint32_t)CPU_COUNT(&set) < e->threads) { e->threads = (uint32_t)CPU_COUNT(&set); }
+    env = getenv("LOCAL_WORLD_SIZE");
+    if (env != NULL && atoi(env) > 1) { ranks = (uint32_t)atoi(env); }
+    e->threads /= ranks;
   }
   if (e->threads < 1) { e->threads = 1; }
   if (e->threads > 10) { e->threads = 10; }       /* the loops are short: more workers only add wake-up and join time */
   env = getenv("SLA_HIP_THREADS");
   if (env != NULL && atoi(env) > 0) { e->threads = (uint32_t)atoi(env); }
   e->pool = pool_create(e->threads);
+  if (e->pool == NULL) { goto fail; }
   e->win_type = (SLAWindowFunctionType)-1;
   return e;
+fail:
+  SLAEncoder_Destroy(e);            /* copes with a half-built handle: everything it releases is checked for NULL */
+  return NULL;
 }
 
 void SLAEncoder_Destroy(struct SLAEncoder* e)
@@ -348,8 +385,12 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   pinbuf_t* h[25];
   int i;
   if (e == NULL) { return; }
-  (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream2); (void)hipStreamSynchronize(e->stream3);
-  (void)hipStreamSynchronize(e->stream_up); (void)hipStreamSynchronize(e->stream_down);
+  (void)hipSetDevice(e->device);
+  if (e->stream != NULL) { (void)hipStreamSynchronize(e->stream); }
+  if (e->stream2 != NULL) { (void)hipStreamSynchronize(e->stream2); }
+  if (e->stream3 != NULL) { (void)hipStreamSynchronize(e->stream3); }
+  if (e->stream_up != NULL) { (void)hipStreamSynchronize(e->stream_up); }
+  if (e->stream_down != NULL) { (void)hipStreamSynchronize(e->stream_down); }
   d[0] = &e->d_pcm; d[1] = &e->d_res1; d[2] = &e->d_res2; d[3] = &e->d_or; d[4] = &e->d_nz; d[5] = &e->d_groups;
   d[6] = &e->d_cands; d[7] = &e->d_lpc_out; d[8] = &e->d_code; d[9] = &e->d_kint; d[10] = &e->d_rshift;
   d[11] = &e->d_winpool; d[12] = &e->d_chunks; d[13] = &e->d_jobs; d[14] = &e->d_fold;
@@ -371,13 +412,18 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   for (i = 0; i < 2; i++) {
     if (e->h_stage[i].ptr != NULL) { (void)hipHostFree(e->h_stage[i].ptr); }
     if (e->d_stage[i].ptr != NULL) { (void)hipFree(e->d_stage[i].ptr); }
-    (void)hipEventDestroy(e->ev_stage[i]);
+    if (e->ev_stage[i] != NULL) { (void)hipEventDestroy(e->ev_stage[i]); }
   }
-  for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { (void)hipEventDestroy(e->ev[i]); }
-  (void)hipEventDestroy(e->ev_prep);
-  (void)hipStreamDestroy(e->stream); (void)hipStreamDestroy(e->stream2); (void)hipStreamDestroy(e->stream3);
-  if (e->own_copy_streams) { (void)hipStreamDestroy(e->stream_up); (void)hipStreamDestroy(e->stream_down); }
-  slai_fft_plan_destroy(e->fft);
+  for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { if (e->ev[i] != NULL) { (void)hipEventDestroy(e->ev[i]); } }
+  if (e->ev_prep != NULL) { (void)hipEventDestroy(e->ev_prep); }
+  if (e->own_copy_streams) {
+    if (e->stream_up != NULL) { (void)hipStreamDestroy(e->stream_up); }
+    if (e->stream_down != NULL) { (void)hipStreamDestroy(e->stream_down); }
+  }
+  if (e->stream != NULL) { (void)hipStreamDestroy(e->stream); }
+  if (e->stream2 != NULL) { (void)hipStreamDestroy(e->stream2); }
+  if (e->stream3 != NULL) { (void)hipStreamDestroy(e->stream3); }
+  if (e->fft != NULL) { slai_fft_plan_destroy(e->fft); }
   pool_destroy(e->pool);
   free(e->win_host); free(e->win_len); free(e->win_off);
   free(e->blk); free(e->bc); free(e->parcor); free(e->code); free(e->kint);
@@ -596,7 +642,7 @@ static void actx_free(actx_t* a)
 
 /* prepass + whole-file tables: offset_lshift, super-frames, candidate shapes, search groups */
 static double g_trace_t0;
-#define PTRACE(label) do { if (getenv("SLA_HIP_TRACE") != NULL) { fprintf(stderr, "[sla_hip]   prepare +%7.3f ms  %s\n", now_ms() - g_trace_t0, (label)); } } while (0)
+#define PTRACE(label) do { if (g_trace_on) { fprintf(stderr, "[sla_hip]   prepare +%7.3f ms  %s\n", now_ms() - g_trace_t0, (label)); } } while (0)
 
 /* whole-file tables: super-frames (hop over silence runs), candidate shapes, search groups.  nz == NULL: no
  * sample is silent (the speculative pass that runs while the prepass is still on the device) */
@@ -964,11 +1010,15 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
       const int ntz = __builtin_ctz(e->h_or[0]);
       const double limit = ldexp(1.0, e->exact_bits + 2 * (ntz - 31 - (int)ms));
       HIPCHK(hipEventRecord(ev[EV_SEARCH_S], e->stream));
+      /* windows over the exactness limit (loud material wider than 16 bits): with the device plan their tile sums are
+       * kept and carry a certificate (sla_hip.h), k_plan accepts a partition no admissible rounding could change and
+       * flags the rest, which plan_chunk reruns as serial chains.  Without the device plan (or with the certificate
+       * switched off) they are flagged at once and take the chains here, without a host round trip. */
+      const double cert = e->device_plan ? e->cert_safety : 0.0;
       RCCHK(sla_hip_launch_search_exact(e->pcm_dev, e->stride, ms, order, dx, nx, a->max_window, a->max_xcands, (const sla_hip_lpc_cand*)e->d_cands.ptr,
                                         (double*)e->d_tile_sums.ptr + (size_t)k->xg_lo * SLA_HIP_XTILES * 2 * sla_hip_search_exact_lags(order),
-                                        (double*)e->d_lpc_out.ptr, limit, e->stream));
-      /* windows over the exactness limit (loud material wider than 16 bits) were flagged: their groups take the
-       * serial chains now, on the device, without a host round trip; the others return at once */
+                                        (double*)e->d_lpc_out.ptr, limit, cert, e->stream));
+      if (!(cert > 0.0))
       RCCHK(sla_hip_launch_lpc_rerun(e->pcm_dev, e->stride, ms, order, (const sla_hip_lpc_group*)e->d_groups.ptr + k->grp_lo, ng,
                                      a->max_window, a->max_cpg, (const sla_hip_lpc_cand*)e->d_cands.ptr, (double*)e->d_lpc_out.ptr,
                                      (uint32_t*)e->d_or.ptr + 2, e->stream));
@@ -983,7 +1033,7 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
       /* plan on the device; only the block lengths come back (the candidates' doubles follow on demand) */
       const uint32_t live_lo = k->xg_lo / C, live = nx / C;
       RCCHK(sla_hip_launch_plan(dx, live, C, order, e->wave_format.bit_per_sample, (const sla_hip_lpc_cand*)e->d_cands.ptr,
-                                (const double*)e->d_lpc_out.ptr, (uint32_t*)e->d_parts.ptr + (size_t)live_lo * SLA_HIP_PLAN_NODES,
+                                (double*)e->d_lpc_out.ptr, (uint32_t*)e->d_parts.ptr + (size_t)live_lo * SLA_HIP_PLAN_NODES,
                                 (uint32_t*)e->d_nparts.ptr + live_lo, (uint32_t*)e->d_pstatus.ptr + live_lo, e->stream));
       HIPCHK(hipEventRecord(ev[EV_PLANNED], e->stream));
       {
@@ -991,7 +1041,7 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
          * they would sit there waiting for every chunk's search in turn, in front of whatever shares that stream's
          * hardware queue (measured with one queue per stream: 2.9 instead of 3.05 ms per C2 step;
          * SLA_HIP_PLAN_COPY=down restores the download stream). */
-        const hipStream_t st = (getenv("SLA_HIP_PLAN_COPY") != NULL && strcmp(getenv("SLA_HIP_PLAN_COPY"), "down") == 0) ? e->stream_down : e->stream;
+        const hipStream_t st = e->plan_copy_down ? e->stream_down : e->stream;
         if (st != e->stream) { HIPCHK(hipStreamWaitEvent(st, ev[EV_PLANNED], 0)); }
         HIPCHK(hipMemcpyAsync((uint32_t*)e->h_parts.ptr + (size_t)live_lo * SLA_HIP_PLAN_NODES, (uint32_t*)e->d_parts.ptr + (size_t)live_lo * SLA_HIP_PLAN_NODES,
                               sizeof(uint32_t) * (size_t)live * SLA_HIP_PLAN_NODES, hipMemcpyDeviceToHost, st));
@@ -1025,12 +1075,21 @@ static int plan_chunk(struct SLAEncoder* e, actx_t* a, uint32_t c)
     /* super-frames the device could not certify (or whose search was flagged) need their candidates' doubles */
     const uint32_t C = e->wave_format.num_channels, O2 = e->encode_param.parcor_order + 2;
     const uint32_t* st = (const uint32_t*)e->h_pstatus.ptr;
-    uint32_t open_frames = 0;
+    uint32_t open_frames = 0, chain_frames = 0;
     for (i = k->sf_lo; i < k->sf_hi; i++) {
-      if (a->sf[i].shape != 0xFFFFFFFFu && st[a->sf[i].xg / C] != 0) { open_frames++; }
+      if (a->sf[i].shape != 0xFFFFFFFFu && st[a->sf[i].xg / C] != 0) { open_frames++; if (st[a->sf[i].xg / C] == 2) { chain_frames++; } }
     }
     e->host_planned += open_frames;
     certified_only = (open_frames == 0);
+    if (chain_frames != 0) {
+      /* certified tile sums that did not certify: k_plan flagged their candidates, the chain kernel redoes exactly those
+       * groups in the reference's order (the others return at once) before the doubles come home */
+      const uint32_t order = e->encode_param.parcor_order;
+      const uint32_t ms = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
+      RCCHK(sla_hip_launch_lpc_rerun(e->pcm_dev, e->stride, ms, order, (const sla_hip_lpc_group*)e->d_groups.ptr + k->grp_lo, k->grp_hi - k->grp_lo,
+                                     a->max_window, a->max_cpg, (const sla_hip_lpc_cand*)e->d_cands.ptr, (double*)e->d_lpc_out.ptr,
+                                     (uint32_t*)e->d_or.ptr + 2, e->stream));
+    }
     if (open_frames != 0) {
       HIPCHK(hipMemcpyAsync((double*)e->h_lpc_out.ptr + (size_t)k->slot_lo * O2, (double*)e->d_lpc_out.ptr + (size_t)k->slot_lo * O2,
                             sizeof(double) * (size_t)(k->slot_hi - k->slot_lo) * O2, hipMemcpyDeviceToHost, e->stream));
@@ -1310,7 +1369,7 @@ static float ev_ms(hipEvent_t s, hipEvent_t t) { float ms = 0.f; return (hipEven
 
 static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
 {
-  const int trace = (getenv("SLA_HIP_TRACE") != NULL);
+  const int trace = e->trace;
   const double t_begin = now_ms();
   const uint32_t C = e->wave_format.num_channels;
   actx_t a;
@@ -1333,7 +1392,7 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
       a.lchunks_bound += C * (e->blk[i].nsmpl / cs + 2);
       if (e->blk[i].type != SLAI_BLK_SILENT && (rc = window_offset(e, e->blk[i].nsmpl, &woff)) != 0) { actx_free(&a); return rc; }
     }
-    RCCHK(pin_reserve(&e->h_cands, 64)); RCCHK(pin_reserve(&e->h_groups, 64));
+    if ((rc = pin_reserve(&e->h_cands, 64)) != 0 || (rc = pin_reserve(&e->h_groups, 64)) != 0) { actx_free(&a); return rc; }
   }
   {
     const size_t nslots = (size_t)a.blocks_bound * C + 1;
@@ -1394,7 +1453,7 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   }
 
   if (!preset_blocks) {
-    HIPCHK(hipMemsetAsync((uint32_t*)e->d_or.ptr + 2, 0, sizeof(uint32_t), e->stream));      /* groups rerun as serial chains */
+    if (hipMemsetAsync((uint32_t*)e->d_or.ptr + 2, 0, sizeof(uint32_t), e->stream) != hipSuccess) { rc = SLA_APIRESULT_NG; }      /* groups rerun as serial chains */
     for (c = 0; c < a.nchunks && rc == 0; c++) { rc = search_launch(e, &a, c); }
     TRACE("search launched", a.nchunks);
   } else {
@@ -1492,6 +1551,47 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   return rc;
 }
 
+/* every entry point that touches the GPU: the handle's device becomes the calling thread's current device (a handle
+ * is bound to the device that was current at SLAEncoder_Create; a multi-GPU process holds one handle per device) and
+ * the handle's launcher knobs are the ones the launchers of this thread see */
+static int enter(struct SLAEncoder* e)
+{
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != e->device) { HIPCHK(hipSetDevice(e->device)); }
+  sla_hip_use_tuning(&e->tune);
+  return 0;
+}
+
+int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double value)
+{
+  const long iv = (long)value;
+  if (e == NULL || name == NULL || !(value == value)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+#define OPT_RANGE(lo, hi) do { if (value != (double)iv || iv < (lo) || iv > (hi)) { return SLA_APIRESULT_INVALID_ARGUMENT; } } while (0)
+  if (strcmp(name, "lpc_pack") == 0)               { OPT_RANGE(0, 4); e->tune.lpc_pack = (uint32_t)iv; }
+  else if (strcmp(name, "lpc_threads") == 0)       { if (iv != 0 && iv != 256 && iv != 512) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.lpc_threads = (uint32_t)iv; }
+  else if (strcmp(name, "tail_waves") == 0)        { OPT_RANGE(0, 4); e->tune.tail_waves = (uint32_t)iv; }
+  else if (strcmp(name, "lpc_blocks_chains") == 0) { OPT_RANGE(0, 1); e->tune.lpc_blocks_chains = (uint32_t)iv; if (iv) { e->fuse_lattice = 0; } }
+  else if (strcmp(name, "plan_margin") == 0)       { if (value < 0.0) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.plan_margin = value; }
+  else if (strcmp(name, "chunks") == 0)            { OPT_RANGE(1, 8); e->chunks = (uint32_t)iv; e->split_count = 0; }
+  else if (strcmp(name, "search_exact") == 0)      { OPT_RANGE(0, 1); e->search_exact = (int)iv; }
+  else if (strcmp(name, "exact_bits") == 0)        { OPT_RANGE(1, 53); e->exact_bits = (int)iv; }
+  else if (strcmp(name, "cert_safety") == 0)       { if (value < 0.0 || value > 1e30) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->cert_safety = value; }
+  else if (strcmp(name, "device_plan") == 0)       { OPT_RANGE(0, 1); e->device_plan = (int)iv; }
+  else if (strcmp(name, "fuse_lattice") == 0)      { OPT_RANGE(0, 1); e->fuse_lattice = (int)iv && !e->tune.lpc_blocks_chains; }
+  else if (strcmp(name, "threads") == 0) {
+    OPT_RANGE(1, 64);
+    if ((uint32_t)iv != e->threads) {
+      struct slai_pool* np = pool_create((uint32_t)iv);
+      if (np == NULL) { return SLA_APIRESULT_NG; }
+      pool_destroy(e->pool); e->pool = np; e->threads = (uint32_t)iv;
+    }
+  }
+  else { return SLA_APIRESULT_INVALID_ARGUMENT; }
+#undef OPT_RANGE
+  e->analysed = 0;
+  return 0;
+}
+
 static int check_ready(const struct SLAEncoder* e)
 {
   if (!(e->status_flag & STATUS_WAVE_FORMAT) || !(e->status_flag & STATUS_ENCODE_PARAM)) { return SLA_APIRESULT_PARAMETER_NOT_SET; }
@@ -1516,6 +1616,7 @@ int sla_hip_analyze_device(struct SLAEncoder* e, const int32_t* d_pcm, uint64_t 
   if (e == NULL || d_pcm == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   RCCHK(check_ready(e));
   if (plane_stride < num_samples) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  RCCHK(enter(e));
   if (stream != NULL) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); }   /* producer of d_pcm */
   e->analysed = 0;
   e->pcm_dev = d_pcm; e->stride = plane_stride; e->num_samples = num_samples;
@@ -1671,6 +1772,7 @@ static int pack_impl(struct SLAEncoder* e, const int32_t* const* host_pcm, uint8
 int sla_hip_pack(struct SLAEncoder* e, uint8_t* data, uint32_t data_size, uint32_t* output_size)
 {
   if (e == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  RCCHK(enter(e));
   return pack_impl(e, NULL, data, data_size, output_size);
 }
 
@@ -1840,6 +1942,7 @@ int sla_hip_pack_device(struct SLAEncoder* e, uint8_t* data, uint32_t data_size,
   if (!e->analysed) { return SLA_APIRESULT_PARAMETER_NOT_SET; }
   if (data == NULL || output_size == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (data_size < SLA_HEADER_SIZE) { return SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE; }
+  RCCHK(enter(e));
   memset(&seg, 0, sizeof(seg));
   seg.lo = 0; seg.hi = e->num_samples; seg.data = data; seg.data_size = data_size;
   rc = pack_device_core(e, &seg, 1);
@@ -1964,6 +2067,7 @@ SLAApiResult SLAEncoder_EncodeWhole(struct SLAEncoder* e, const int32_t* const* 
   if (e == NULL || input == NULL || data == NULL || output_size == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if ((rc = check_ready(e)) != 0) { return (SLAApiResult)rc; }
   if (data_size < SLA_HEADER_SIZE) { return SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE; }
+  if (enter(e) != 0) { return SLA_APIRESULT_NG; }
   if ((rc = upload_pcm(e, input, num_samples)) != 0) { return (rc > 0) ? (SLAApiResult)rc : SLA_APIRESULT_NG; }
   rc = sla_hip_analyze_device(e, e->pcm_dev, e->stride, num_samples, NULL, NULL);
   if (rc == 0) { rc = sla_hip_pack_device(e, data, data_size, output_size); }
@@ -2190,6 +2294,7 @@ int sla_hip_analyze_batch_device(struct SLAEncoder* e, const int32_t* d_pcm, uin
   }
   e->analysed = 0;
   if (num_files == 0 || span == 0) { return 0; }
+  RCCHK(enter(e));
   lsh = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)num_files * 4);
   if (lsh == NULL) { return SLA_APIRESULT_NG; }
   orv = lsh + num_files; seg_start = orv + num_files; seg_len = seg_start + num_files;
@@ -2231,6 +2336,7 @@ int sla_hip_encode_batch(struct SLAEncoder* e, sla_hip_batch_item* items, uint32
   int rc;
   if (e == NULL || (items == NULL && num_items != 0)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if ((rc = check_ready(e)) != 0) { return rc; }
+  RCCHK(enter(e));
   for (i = 0; i < num_items; i++) {
     if (items[i].input == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
     for (ch = 0; ch < e->wave_format.num_channels; ch++) { if (items[i].input[ch] == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; } }
@@ -2267,6 +2373,7 @@ SLAApiResult SLAEncoder_EncodeBlock(struct SLAEncoder* e, const int32_t* const* 
   if ((rc = check_ready(e)) != 0) { return (SLAApiResult)rc; }
   if (num_samples == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   C = e->wave_format.num_channels;
+  if (enter(e) != 0) { return SLA_APIRESULT_NG; }
   if ((rc = upload_pcm(e, input, num_samples)) != 0) { return (rc > 0) ? (SLAApiResult)rc : SLA_APIRESULT_NG; }
   e->analysed = 0;
   e->lshift = e->wave_format.offset_lshift;
@@ -2333,6 +2440,7 @@ int sla_hip_get_trace(struct SLAEncoder* e, sla_hip_trace* tr)
   uint32_t C, O1, b, ch, t;
   if (e == NULL || tr == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (!e->analysed) { return SLA_APIRESULT_PARAMETER_NOT_SET; }
+  RCCHK(enter(e));
   C = e->wave_format.num_channels; O1 = e->encode_param.parcor_order + 1;
   if (tr->max_blocks < e->num_blocks || tr->order_stride < O1 || tr->sample_stride < e->num_samples
       || (tr->ltm_stride < e->encode_param.longterm_order)) { return SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE; }

@@ -44,6 +44,7 @@ enum { SLAI_BLK_COMPRESS = 0, SLAI_BLK_SILENT = 1, SLAI_BLK_RAW = 2 };
 int      slai_make_window(SLAWindowFunctionType type, double* w, uint32_t n);
 double   slai_code_length(double sumsq, uint32_t n, uint32_t bps, const double* parcor, uint32_t order);
 int      slai_shortest_path(const double* adj, uint32_t nodes, uint32_t* path);
+int      slai_host_check(void);       /* 0: long double / double arithmetic of this host is the reference build's */
 /* sla_kernels.hip: the next k_lpc_blocks / k_lattice / k_ltm_acf / k_tail launch of this thread records its
  * execution span (2 x u64, zero-initialised device memory: ~min start, max end in 100 MHz ticks) */
 void slai_next_launch_span(unsigned long long* d_span);

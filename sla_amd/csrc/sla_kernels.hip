@@ -282,6 +282,31 @@ __device__ __forceinline__ void levinson_out(const double* rc, double* a, double
   }
 }
 
+// Final prediction error e_p = r0 * prod(1 - k_j^2) of the same recursion with r[0] replaced by r0 (no outputs);
+// NaN as soon as the recursion leaves the positive-definite range.  Used by the search's certificate (k_search_finish).
+__device__ __forceinline__ double levinson_error(const double* rc, double r0, double* a, double* v, uint32_t order)
+{
+  const double nan = __longlong_as_double(0x7FF8000000000000ll);
+  if (!(r0 > 0.0)) { return nan; }
+  for (uint32_t i = 0; i < order + 2; i++) { a[i] = 0.0; v[i] = 0.0; }
+  a[0] = 1.0;
+  a[1] = -rc[1] / r0;
+  double e = r0 + rc[1] * a[1];
+  if (!(e > 0.0)) { return nan; }
+  for (uint32_t d = 1; d < order; d++) {
+    double gamma = 0.0;
+    for (uint32_t i = 0; i < d + 1; i++) { gamma += a[i] * rc[d + 1 - i]; }
+    gamma /= (-e);
+    if (!(fabs(gamma) < 1.0)) { return nan; }
+    e = (1.0 - gamma * gamma) * e;
+    for (uint32_t i = 0; i < d; i++) { v[d - i] = a[i + 1]; }
+    v[0] = 0.0; v[d + 1] = 1.0;
+    a[0] = 1.0; a[d + 1] = 0.0;
+    for (uint32_t i = 0; i < d + 2; i++) { a[i] = a[i] + gamma * v[i]; }
+  }
+  return e;
+}
+
 #define LPC_MAX_PACK 4      // windows ("groups") one workgroup stages side by side
 
 // A workgroup takes `pack` consecutive groups: their windows sit next to each other in LDS and their
@@ -294,7 +319,7 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
            const sla_hip_lpc_cand* __restrict__ cands,
            const double* __restrict__ window_pool, double* __restrict__ out,
            int32_t* __restrict__ out_code, int32_t* __restrict__ out_kint, uint32_t* __restrict__ out_rshift,
-           uint32_t x_region, uint32_t dbg_skip, uint32_t* __restrict__ rerun_counter)
+           uint32_t x_region, uint32_t mode, uint32_t* __restrict__ rerun_counter)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ sla_hip_lpc_group s_g[LPC_MAX_PACK];
@@ -308,7 +333,7 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
     s_maxabs[threadIdx.x] = 0;
   }
   __syncthreads();
-  if (dbg_skip & 128u) {
+  if (mode & 128u) {
     // rerun mode (after k_search_finish): only groups whose window was over the exactness limit -- their first
     // output slot carries the NaN flag -- are analysed, everything else keeps its tile-sum result
     uint32_t flagged = 0;
@@ -336,7 +361,7 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
     uint32_t maxabs = 0;
     for (uint32_t s = threadIdx.x; s < g.num_samples; s += blockDim.x) {
       // mode bit 512 (per-call SLAPredictor API): `pcm` is an array of doubles the caller has already prepared
-      double cur = (dbg_skip & 512u) ? reinterpret_cast<const double*>(pcm)[g.pcm_off + s]
+      double cur = (mode & 512u) ? reinterpret_cast<const double*>(pcm)[g.pcm_off + s]
                                      : load_f64(pcm, stride, ms, g.channel, g.pcm_off + s);
       if (windowed) {
         cur *= win[s];
@@ -367,9 +392,7 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
   // ---- autocorrelation chains -----------------------------------------------------------------
   // waves 0..2 walk the lag >= 1 chains, wave 3 the lag-0 (energy) chains.  (Measured on C2: running the
   // two loop bodies back to back in the idle lanes of one wave is 1.1-1.4x slower than this split.)
-  if (dbg_skip & 1) {
-    for (uint32_t q = threadIdx.x; q < nc * O1; q += blockDim.x) { r[q] = 1.0 / (1.0 + q); }
-  } else if (threadIdx.x < blockDim.x - 64) {
+  if (threadIdx.x < blockDim.x - 64) {
     const uint32_t nchains = nc * order;
     for (uint32_t q = threadIdx.x; q < nchains; q += blockDim.x - 64) {
       const uint32_t cidx = q / order, lag = 1 + (q - cidx * order);
@@ -377,19 +400,19 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
       const sla_hip_lpc_cand* cd = locate(cidx, k);
       const uint32_t n = cd->len;
       const double* xs = lds + (size_t)k * x_region + cd->start;
-      r[cidx * O1 + lag] = (dbg_skip & 8) ? 0.0 : ((lag < n) ? chain_lag(xs, n, lag) : 0.0);
+      r[cidx * O1 + lag] = (lag < n) ? chain_lag(xs, n, lag) : 0.0;
     }
   } else {
     for (uint32_t cidx = threadIdx.x - (blockDim.x - 64); cidx < nc; cidx += 64) {
       uint32_t k;
       const sla_hip_lpc_cand* cd = locate(cidx, k);
-      r[cidx * O1] = (dbg_skip & 4) ? 1.0 : chain_lag0(lds + (size_t)k * x_region + cd->start, cd->len);
+      r[cidx * O1] = chain_lag0(lds + (size_t)k * x_region + cd->start, cd->len);
     }
   }
   __syncthreads();
 
   // ---- Levinson-Durbin (+ quantiser for chosen blocks), one thread per candidate ----------------
-  for (uint32_t cidx = threadIdx.x; cidx < nc && !(dbg_skip & 2); cidx += blockDim.x) {
+  for (uint32_t cidx = threadIdx.x; cidx < nc; cidx += blockDim.x) {
     uint32_t k;
     const sla_hip_lpc_cand* cd = locate(cidx, k);
     const uint32_t n = cd->len;
@@ -853,7 +876,7 @@ template <int NB>
 __global__ __launch_bounds__(256)
 void k_acf_tiles(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
                  const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, uint32_t tiles_per_group,
-                 double* __restrict__ tile_sums, uint32_t dbg)
+                 double* __restrict__ tile_sums)
 {
   constexpr uint32_t OL = 64 - NB;             // lanes of a pass that own samples
   constexpr uint32_t STEP = OL * 4, PASSES = (SLA_HIP_XTILE + STEP - 1) / STEP, LAGS = NB * 4;
@@ -885,7 +908,7 @@ void k_acf_tiles(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
 #pragma unroll
   for (uint32_t p = 0; p < PASSES; p++) {
     const uint32_t s0 = t0 + p * STEP;
-    if (s0 < t1 && !(dbg & 1)) {
+    if (s0 < t1) {
       double cur[4], own[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
@@ -922,10 +945,9 @@ void k_acf_tiles(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
 #pragma unroll
   for (int i = 0; i < (int)LAGS; i++) {
     double v = acc[i];
-    if (!(dbg & 2)) { v = wave_sum_f64(v); }
+    v = wave_sum_f64(v);
     if (lane == 0) { dst[i] = v; }
   }
-  if (dbg & 4) { return; }
   // pairs that straddle t1: lane = lag
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -940,11 +962,29 @@ void k_acf_tiles(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
 
 // k_search_finish: one wave per group.  r[lag] of candidate [start, end) = P of its tiles minus X of its
 // last tile, then Levinson-Durbin per candidate exactly as in k_lpc.
+//
+// Windows over the exactness limit (loud material wider than 16 bits): the tile sums no longer equal the reference's
+// serially rounded sums bit for bit -- but the search only has to deliver a PARTITION, and the reference's decision
+// can be certified from sums that are merely close (cert > 0):
+//   * the reference's r[lag] differs from the exact sum by at most n*2^-53 * sum|terms| <= n*2^-53 * r0 (recursive
+//     summation of n exactly representable terms), ours by at most 48*2^-53 * (energy of the window) (<= 48 roundings
+//     per lag: lane chain, wave tree, tiles), so the two Toeplitz matrices differ by a symmetric Toeplitz matrix whose
+//     2-norm is at most (2*order+1) * delta;
+//   * the estimated code length of a candidate depends on its autocorrelation only through the final prediction
+//     error e_p = r0 * prod(1 - k_j^2) = min over a, a_0 = 1, of a'Ra, which is monotone in the Loewner order:
+//     R~ - d*I <= R_ref <= R~ + d*I  implies  e_p(R~ - d*I) <= e_p(R_ref) <= e_p(R~ + d*I);
+//   * d = cert * (2*order+1) * delta with cert = 64: a factor 63 on top of the summation bounds for the rounding of the
+//     Levinson recursion itself on either side (measured: the reference's estimate sits within 1e-4 of the bracket's
+//     half width, tests/test_gpu_parity.py::test_search_certificate_brackets_the_reference).
+// The candidate's slot then carries the tile-sum result plus, in parcor[0] (always 0 otherwise), the half width of
+// log2(e_p); k_plan adds the widths up along the paths and only accepts a partition no width can change.  Anything
+// else (not positive definite, not finite, cert <= 0) is flagged -- NaN in r[0], or an infinite width -- and redone
+// as serial chains.
 #define XF_BATCH 64          // candidates one pass of the wave takes (at most)
 __global__ __launch_bounds__(64)
 void k_search_finish(uint32_t order, uint32_t lags, uint32_t batch,
                      const sla_hip_lpc_group* __restrict__ groups, const sla_hip_lpc_cand* __restrict__ cands,
-                     const double* __restrict__ tile_sums, double* __restrict__ out, double exact_limit)
+                     const double* __restrict__ tile_sums, double* __restrict__ out, double exact_limit, double cert)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const uint32_t O1 = order + 1, O2 = order + 2;
@@ -958,6 +998,7 @@ void k_search_finish(uint32_t order, uint32_t lags, uint32_t batch,
   double* r = lds;                                   // [batch][O1]
   double* av = lds + (size_t)batch * O1;             // [batch][O2]
   double* vv = av + (size_t)batch * O2;              // [batch][O2]
+  const double inf = __longlong_as_double(0x7FF0000000000000ll);
   for (uint32_t c0 = 0; c0 < g.cand_count; c0 += batch) {
     const uint32_t nb = (g.cand_count - c0 < batch) ? (g.cand_count - c0) : batch;
     for (uint32_t q = threadIdx.x; q < nb * O1; q += blockDim.x) {
@@ -976,8 +1017,30 @@ void k_search_finish(uint32_t order, uint32_t lags, uint32_t batch,
     for (uint32_t ci = threadIdx.x; ci < nb; ci += blockDim.x) {
       const sla_hip_lpc_cand cd = cands[g.cand_first + c0 + ci];
       double* o = out + ((uint64_t)g.slot_first + c0 + ci) * O2;
-      levinson_out(r + ci * O1, av + ci * O2, vv + ci * O2, o, order, cd.len);
-      if (!exact) { o[0] = __longlong_as_double(0x7FF8000000000000ll); }
+      const double* rc = r + ci * O1;
+      levinson_out(rc, av + ci * O2, vv + ci * O2, o, order, cd.len);
+      if (!exact) {
+        if (!(cert > 0.0)) {
+          o[0] = __longlong_as_double(0x7FF8000000000000ll);
+        } else {
+          const double u = 1.1102230246251565e-16;              // 2^-53
+          const double r0 = rc[0];
+          double w = inf;
+          if (cd.len >= order && r0 > 2.0 * (double)FLT_EPSILON) {       // the reference zeroes the coefficients below FLT_EPSILON (src/SLAPredictor.c:274)
+            const double delta = ((double)cd.len * u) * r0 + (48.0 * u) * energy;
+            const double d = cert * (double)(2 * order + 1) * delta;
+            double e_mid = r0;
+            for (uint32_t k = 1; k <= order; k++) { e_mid *= (1.0 - o[1 + k] * o[1 + k]); }
+            const double e_hi = levinson_error(rc, r0 + d, av + ci * O2, vv + ci * O2, order);
+            const double e_lo = (r0 - d > (double)FLT_EPSILON) ? levinson_error(rc, r0 - d, av + ci * O2, vv + ci * O2, order) : e_hi - e_hi + __longlong_as_double(0x7FF8000000000000ll);
+            if (e_mid > 0.0 && e_lo > 0.0 && e_hi >= e_mid && e_mid >= e_lo && e_hi < inf) {
+              const double up = log2(e_hi / e_mid), dn = log2(e_mid / e_lo);
+              w = ((up > dn) ? up : dn) * 1.000001 + 1e-12;       // (the device's log2 is good to a few ulp)
+            }
+          }
+          o[1] = (w == w) ? w : inf;
+        }
+      }
     }
     __syncthreads();
   }
@@ -998,24 +1061,25 @@ void k_search_finish(uint32_t order, uint32_t lags, uint32_t batch,
 #define PLAN_MARGIN 1e-4
 #define PLAN_BIG 16777216.0      // SLAOPTIMALENCODEESTIMATOR_DIJKSTRA_BIGWEIGHT
 
+// `width`: half width of log2(e_p) the candidate carries (0: its sums are the reference's, bit for bit)
 __device__ __forceinline__ double plan_code_length(double sumsq, uint32_t n, uint32_t bps, const double* __restrict__ parcor,
-                                                   uint32_t order, bool& sure)
+                                                   uint32_t order, double width, bool& sure)
 {
   const double l2e = 1.4426950408889634;                        // src/SLAUtility.c:442-447
   double power = sumsq * ldexp(1.0, (int)(2 * (bps - 1)));
-  if (fabs(power) <= (double)FLT_MIN) { return 0.0; }
+  if (fabs(power) <= (double)FLT_MIN) { if (width > 0.0) { sure = false; } return 0.0; }
   power = log(power) * l2e - log((double)n) * l2e;
   double gain = 0.0;
   for (uint32_t ord = 1; ord <= order; ord++) { gain += log(1.0 - parcor[ord] * parcor[ord]) * l2e; }
   double len = 1.9426950408889634 + 0.5 * (power + gain);
   len /= 8;
-  if (!(fabs(len) > 1e-9)) { sure = false; }                    // too close to the clamp (or NaN)
+  if (!(fabs(len) > 1e-9 + width / 16.0)) { sure = false; }     // too close to the clamp (or NaN)
   return (len <= 0) ? 0.125 : len;
 }
 
 __global__ __launch_bounds__(256)
 void k_plan(const sla_hip_lpc_group* __restrict__ groups, uint32_t num_sf, uint32_t nch, uint32_t order, uint32_t bps,
-            const sla_hip_lpc_cand* __restrict__ cands, const double* __restrict__ lpc_out,
+            const sla_hip_lpc_cand* __restrict__ cands, double* __restrict__ lpc_out,
             uint32_t* __restrict__ parts, uint32_t* __restrict__ nparts, uint32_t* __restrict__ status, double margin)
 {
   __shared__ double s_adj[4][PLAN_NODES * PLAN_NODES];
@@ -1027,18 +1091,24 @@ void k_plan(const sla_hip_lpc_group* __restrict__ groups, uint32_t num_sf, uint3
   const uint32_t window = g.num_samples, O2 = order + 2;
   const uint32_t nodes = (window + SLA_HIP_XTILE - 1) / SLA_HIP_XTILE + 1;
   double* adj = s_adj[wv];
-  bool sure = (nodes <= PLAN_NODES);
+  bool sure = (nodes <= PLAN_NODES), inexact = false;
+  double wmax = 0.0;
   if (!sure) { if (lane == 0) { status[sf] = 1; nparts[sf] = 0; } return; }
   for (uint32_t q = lane; q < nodes * nodes; q += 64) { adj[q] = PLAN_BIG; }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   for (uint32_t k = lane; k < g.cand_count; k += 64) {
     const sla_hip_lpc_cand cd = cands[g.cand_first + k];
     const uint32_t i = cd.start / SLA_HIP_XTILE, j = (cd.start + cd.len + SLA_HIP_XTILE - 1) / SLA_HIP_XTILE;
-    double est = 0.0;
+    double wedge = 0.0, est = 0.0;
     for (uint32_t ch = 0; ch < nch; ch++) {
       const double* o = lpc_out + ((uint64_t)g.slot_first + (uint64_t)ch * g.cand_count + k) * O2;
-      est += cd.len * plan_code_length(o[0], cd.len, bps, o + 1, order, sure);
+      const double width = o[1];                   // parcor[0]: 0, or the half width of log2(e_p) of a certified candidate
+      est += cd.len * plan_code_length(o[0], cd.len, bps, o + 1, order, width, sure);
+      wedge += cd.len * width / 16.0;              // bytes: length = n/8 * (const + log2(e_p * scale / n) / 2)
+      if (width != 0.0) { inexact = true; }
     }
+    if (!(wedge < PLAN_BIG / 2)) { sure = false; wedge = 0.0; }
+    wmax = (wedge > wmax) ? wedge : wmax;
     est += 50.0;                                   // SLAOPTIMALENCODEESTIMATOR_ESTIMATE_BLOCK_SIZE
     est += 300.0;                                  // ..._LONGPATH_PENALTY
     if (!(fabs(est) < PLAN_BIG / 2)) { sure = false; }          // NaN (also the "rerun as serial chains" flag), inf, absurd
@@ -1046,6 +1116,10 @@ void k_plan(const sla_hip_lpc_group* __restrict__ groups, uint32_t num_sf, uint3
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+  // a path has at most nodes-1 edges, each known to +-wmax: two path costs compare safely beyond 2*(nodes-1)*wmax
+  for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(wmax, off); wmax = (o > wmax) ? o : wmax; }
+  margin += 2.0 * (double)(nodes - 1) * wmax;
+  inexact = (__ballot(inexact) != 0ull);
   // Dijkstra, lane = node: first-minimum selection, strict-improvement relaxation (as slai_shortest_path)
   double cost = (lane == 0) ? 0.0 : PLAN_BIG;
   bool done = false, reached = false;
@@ -1095,7 +1169,16 @@ void k_plan(const sla_hip_lpc_group* __restrict__ groups, uint32_t num_sf, uint3
       }
     }
     nparts[sf] = ok ? count : 0;
-    status[sf] = ok ? 0u : 1u;
+    status[sf] = ok ? 0u : (inexact ? 2u : 1u);
+    s_path[wv][0] = (ok || !inexact) ? 0u : 1u;
+  }
+  // a super-frame whose tile sums were only certified, not exact, and that did not certify: flag every candidate for
+  // the serial-chain rerun (sla_hip_launch_lpc_rerun looks at r[0] of a group's first slot)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (s_path[wv][0] != 0u) {
+    for (uint32_t q = lane; q < g.cand_count * nch; q += 64) {
+      lpc_out[((uint64_t)g.slot_first + q) * O2] = __longlong_as_double(0x7FF8000000000000ll);
+    }
   }
 }
 
@@ -1444,7 +1527,7 @@ template <bool IN_LDS>
 __global__ __launch_bounds__(ACF_THREADS)
 void k_ltm_acf(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_acf_job* __restrict__ jobs,
                uint32_t njobs, uint32_t log2F, const double* __restrict__ tw, double* __restrict__ scratch,
-               double* __restrict__ out, uint32_t head, uint32_t dbg_skip, unsigned long long* span)
+               double* __restrict__ out, uint32_t head, unsigned long long* span)
 {
   extern __shared__ double2 lds2[];
   span_begin(span);
@@ -1469,8 +1552,8 @@ void k_ltm_acf(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_a
                                   (2 * k + 1 < n) ? (double)src[2 * k + 1] * scale : 0.0);
     }
     __syncthreads();
-    if (!(dbg_skip & 1)) { acf_stages(z, log2npts, twr_f, twi_f); }
-    if (!(dbg_skip & 8)) { acf_real_pass(z, npts, -0.5, rtr_f, rti_f); }
+    acf_stages(z, log2npts, twr_f, twi_f);
+    acf_real_pass(z, npts, -0.5, rtr_f, rti_f);
     __syncthreads();
     if (threadIdx.x == 0) {
       const double2 v = z[0];
@@ -1482,7 +1565,7 @@ void k_ltm_acf(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_a
       z[acf_sw(i)] = make_double2(v.x * v.x + v.y * v.y, 0.0);
     }
     __syncthreads();
-    if (!(dbg_skip & 8)) { acf_real_pass(z, npts, 0.5, rtr_i, rti_i); }
+    acf_real_pass(z, npts, 0.5, rtr_i, rti_i);
     __syncthreads();
     if (threadIdx.x == 0) {
       const double2 v = z[0];
@@ -1498,7 +1581,7 @@ void k_ltm_acf(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_a
       }
     }
     __syncthreads();
-    if (!(dbg_skip & 2)) { acf_stages(z, log2npts, twr_i, twi_i); }
+    acf_stages(z, log2npts, twr_i, twi_i);
     if (head == SLA_HIP_ACF_RECORD) {
       // compact record: {code, chosen lag, acf[0..4], acf[chosen-2..chosen+2]}; the Toeplitz solve (x87
       // long double in the reference) is left to the host
@@ -1517,7 +1600,7 @@ void k_ltm_acf(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_a
         double* o = out + (uint64_t)job * SLA_HIP_ACF_RECORD;
         uint32_t chosen = 0, ncand = 0;
         double code = 0.0;                                   // 0: silent block
-        if (fabs(s_acf[0]) > (double)FLT_MIN && !(dbg_skip & 4)) {
+        if (fabs(s_acf[0]) > (double)FLT_MIN) {
           acf_pick(s_acf, s_mask[0], s_mask[1], s_mask[2], chosen, ncand);
           code = (ncand == 0) ? 2.0 : 1.0;                   // 2: no pitch candidate
         }
@@ -1541,6 +1624,19 @@ void k_ltm_acf(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_a
 static thread_local unsigned long long* t_next_span = nullptr;
 extern "C" void slai_next_launch_span(unsigned long long* d_span) { t_next_span = d_span; }
 static inline unsigned long long* take_span() { unsigned long long* p = t_next_span; t_next_span = nullptr; return p; }
+
+// Tuning knobs of the launchers (include/sla_hip.h: sla_hip_tuning).  They belong to an encoder handle, which reads
+// them ONCE (environment at SLAEncoder_Create, sla_hip_encoder_set_option afterwards) and names its copy to the
+// launchers of its host thread; nothing on the launch path reads the environment.
+static thread_local const sla_hip_tuning* t_tuning = nullptr;
+extern "C" void sla_hip_use_tuning(const sla_hip_tuning* tuning) { t_tuning = tuning; }
+static inline sla_hip_tuning tuning()
+{
+  sla_hip_tuning t;
+  memset(&t, 0, sizeof(t));
+  if (t_tuning != nullptr) { t = *t_tuning; }
+  return t;
+}
 
 // hipFuncSetAttribute costs a driver call; the limit only ever has to grow (per kernel and device)
 static hipError_t ensure_dynamic_lds(const void* fn, size_t bytes)
@@ -1654,16 +1750,14 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
   if ((d_code != nullptr) != (d_kint != nullptr) || (d_code != nullptr) != (d_rshift != nullptr)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (d_code != nullptr && max_cands_per_group != 1) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (num_groups == 0) { return 0; }
-  if (d_code != nullptr && order <= 64 && !(getenv("SLA_HIP_LPC_BLOCKS") != nullptr && strcmp(getenv("SLA_HIP_LPC_BLOCKS"), "chains") == 0)) {
+  const sla_hip_tuning tune = tuning();
+  if (d_code != nullptr && order <= 64 && !tune.lpc_blocks_chains) {
     // chosen blocks: term tiles + lane-parallel Levinson (k_lpc_blocks)
     if (d_window_pool == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
     uint32_t pmax = 64 / order;
     if (pmax > LPC_MAX_PACK) { pmax = LPC_MAX_PACK; }
     if (pmax > 2) { pmax = 2; }
-    {
-      const char* env = getenv("SLA_HIP_LPC_PACK");
-      if (env != nullptr && atoi(env) >= 1 && (uint32_t)atoi(env) <= LPC_MAX_PACK && (uint32_t)atoi(env) * order <= 64) { pmax = (uint32_t)atoi(env); }
-    }
+    if (tune.lpc_pack >= 1 && tune.lpc_pack <= LPC_MAX_PACK && tune.lpc_pack * order <= 64) { pmax = tune.lpc_pack; }
     for (uint32_t p = pmax; p >= 1; p--) {
       uint32_t nch = 16;
       while (nch < p * order) { nch <<= 1; }
@@ -1676,7 +1770,11 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
       if (e != hipSuccess) { return hip_rc(e); }
       const dim3 grid((num_groups + p - 1) / p), block(LB_THREADS);
       unsigned long long* span = take_span();
+#ifdef SLA_HIP_DEBUG
       const uint32_t clk = (uint32_t)(getenv("SLA_HIP_LPC_CLK") != nullptr);
+#else
+      const uint32_t clk = 0;
+#endif
       if (spl == 12) {
         hipLaunchKernelGGL(k_lpc_blocks<12>, grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
                            d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span, d_lat_residual);
@@ -1684,7 +1782,8 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
         hipLaunchKernelGGL(k_lpc_blocks<6>, grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
                            d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span, d_lat_residual);
       }
-      if (getenv("SLA_HIP_LPC_CLK") != nullptr) {
+#ifdef SLA_HIP_DEBUG
+      if (clk) {
         unsigned long long h[8] = {0}, z[8] = {0};
         (void)hipStreamSynchronize((hipStream_t)stream);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lpc_clk), sizeof(h));
@@ -1696,6 +1795,7 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
                   h[3], p, h[0] / h[3], h[1] / h[3], h[4] / h[3], h[5] / h[3], h[6] / h[3], h[2] / h[3]);
         }
       }
+#endif
       return hip_rc(hipGetLastError());
     }
     return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY;
@@ -1711,10 +1811,7 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
     const size_t bytes = sizeof(double) * ((size_t)p * xr + (size_t)p * per_group_r);
     if (bytes <= SLA_HIP_LDS_BUDGET && ((size_t)(p - 1) * max_cands_per_group * order < 192 || p == 1)) { pack = p; x_region = xr; break; }
   }
-  {
-    const char* env = getenv("SLA_HIP_LPC_PACK");
-    if (env != nullptr && atoi(env) >= 1 && (uint32_t)atoi(env) < pack) { pack = (uint32_t)atoi(env); }
-  }
+  if (tune.lpc_pack >= 1 && tune.lpc_pack < pack) { pack = tune.lpc_pack; }
   if (x_region * pack < 2 * (size_t)pack * max_cands_per_group * (order + 2)) { x_region = 2 * (size_t)max_cands_per_group * (order + 2); }
   size_t lds = sizeof(double) * ((size_t)pack * x_region + (size_t)pack * per_group_r);
   if (lds > SLA_HIP_LDS_BUDGET) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
@@ -1724,12 +1821,10 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
   // owns the LDS, so the workgroups per CU are few and more waves per workgroup are what hides the LDS gathers
   // (C5: 14.4 -> 13.3 ms of search per minute of audio)
   uint32_t lpc_threads = ((size_t)pack * max_cands_per_group * order >= 448) ? 512u : 256u;
-  if (getenv("SLA_HIP_LPC_THREADS") != nullptr && (atoi(getenv("SLA_HIP_LPC_THREADS")) == 256 || atoi(getenv("SLA_HIP_LPC_THREADS")) == 512)) {
-    lpc_threads = (uint32_t)atoi(getenv("SLA_HIP_LPC_THREADS"));
-  }
+  if (tune.lpc_threads == 256 || tune.lpc_threads == 512) { lpc_threads = tune.lpc_threads; }
   hipLaunchKernelGGL(k_lpc, dim3((num_groups + pack - 1) / pack), dim3(lpc_threads), lds, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
                      d_groups, num_groups, pack, d_cands, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)x_region,
-                     (uint32_t)(getenv("SLA_HIP_LPC_SKIP") ? (atoi(getenv("SLA_HIP_LPC_SKIP")) & 127) : 0) | mode_flags, d_rerun_counter);
+                     mode_flags, d_rerun_counter);
   return hip_rc(hipGetLastError());
 }
 
@@ -1744,7 +1839,7 @@ extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_
                                            const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
                                            uint32_t max_cands_per_group,
                                            const sla_hip_lpc_cand* d_cands, double* d_tile_sums, double* d_out,
-                                           double exact_limit, sla_hip_stream_t stream)
+                                           double exact_limit, double cert_safety, sla_hip_stream_t stream)
 {
   if (d_pcm == nullptr || d_groups == nullptr || d_cands == nullptr || d_tile_sums == nullptr || d_out == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   const uint32_t lags = sla_hip_search_exact_lags(order);
@@ -1755,28 +1850,26 @@ extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_
   const uint32_t tiles = (max_window + SLA_HIP_XTILE - 1) / SLA_HIP_XTILE;       // waves per group
   const uint32_t waves = num_groups * tiles;
   const dim3 grid((waves + 3) / 4), block(256);
-  const uint32_t dbg = (uint32_t)(getenv("SLA_HIP_XDBG") ? atoi(getenv("SLA_HIP_XDBG")) : 0);
   switch (lags) {
-    case 12: hipLaunchKernelGGL(k_acf_tiles<3>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, dbg); break;
-    case 20: hipLaunchKernelGGL(k_acf_tiles<5>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, dbg); break;
-    case 36: hipLaunchKernelGGL(k_acf_tiles<9>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, dbg); break;
-    default: hipLaunchKernelGGL(k_acf_tiles<13>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, dbg); break;
+    case 12: hipLaunchKernelGGL(k_acf_tiles<3>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums); break;
+    case 20: hipLaunchKernelGGL(k_acf_tiles<5>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums); break;
+    case 36: hipLaunchKernelGGL(k_acf_tiles<9>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums); break;
+    default: hipLaunchKernelGGL(k_acf_tiles<13>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums); break;
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { return hip_rc(e); }
-  if (dbg & 8) { return 0; }
   const uint32_t batch = (max_cands_per_group < XF_BATCH) ? max_cands_per_group : XF_BATCH;
   const size_t lds = sizeof(double) * (size_t)batch * ((order + 1) + 2 * (size_t)(order + 2));
   e = ensure_dynamic_lds((const void*)k_search_finish, lds);
   if (e != hipSuccess) { return hip_rc(e); }
   hipLaunchKernelGGL(k_search_finish, dim3(num_groups), dim3(64), lds, st, order, lags, batch,
-                     d_groups, d_cands, d_tile_sums, d_out, exact_limit);
+                     d_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety);
   return hip_rc(hipGetLastError());
 }
 
 extern "C" int sla_hip_launch_plan(const sla_hip_lpc_group* d_groups, uint32_t num_superframes, uint32_t num_channels,
                                    uint32_t order, uint32_t bits_per_sample, const sla_hip_lpc_cand* d_cands,
-                                   const double* d_lpc_out, uint32_t* d_parts, uint32_t* d_num_parts, uint32_t* d_status,
+                                   double* d_lpc_out, uint32_t* d_parts, uint32_t* d_num_parts, uint32_t* d_status,
                                    sla_hip_stream_t stream)
 {
   if (d_groups == nullptr || d_cands == nullptr || d_lpc_out == nullptr || d_parts == nullptr || d_num_parts == nullptr
@@ -1785,7 +1878,7 @@ extern "C" int sla_hip_launch_plan(const sla_hip_lpc_group* d_groups, uint32_t n
   if (num_superframes == 0) { return 0; }
   hipLaunchKernelGGL(k_plan, dim3((num_superframes + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_groups, num_superframes, num_channels,
                      order, bits_per_sample, d_cands, d_lpc_out, d_parts, d_num_parts, d_status,
-                     (getenv("SLA_HIP_PLAN_MARGIN") != nullptr) ? atof(getenv("SLA_HIP_PLAN_MARGIN")) : PLAN_MARGIN);   /* tests raise it to force the host path */
+                     (tuning().plan_margin > 0.0) ? tuning().plan_margin : PLAN_MARGIN);   /* tests raise it to force the host path */
   return hip_rc(hipGetLastError());
 }
 
@@ -1872,7 +1965,8 @@ static int launch_tail_impl(const int32_t* d_res_in, int32_t* d_res_out, uint64_
   if (longterm_order > 5 || !(longterm_order & 1)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (!(lms_order == 4 || lms_order == 8 || lms_order == 16 || lms_order == 32)) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
   if (num_jobs == 0) { return 0; }
-  const uint32_t tail_waves = (getenv("SLA_HIP_TAIL_WAVES") != nullptr && atoi(getenv("SLA_HIP_TAIL_WAVES")) >= 1 && atoi(getenv("SLA_HIP_TAIL_WAVES")) <= 4) ? (uint32_t)atoi(getenv("SLA_HIP_TAIL_WAVES")) : 1u;     /* one wave per workgroup: the dispatcher spreads the (few, long-running) waves over all CUs */
+  const uint32_t tw = tuning().tail_waves;
+  const uint32_t tail_waves = (tw >= 1 && tw <= 4) ? tw : 1u;     /* one wave per workgroup: the dispatcher spreads the (few, long-running) waves over all CUs */
   const uint32_t jobs_per_block = tail_waves * (64 / (2 * lms_order));     // 64/(2*order) jobs per wave
   dim3 grid((num_jobs + jobs_per_block - 1) / (jobs_per_block ? jobs_per_block : 1)), block(64 * tail_waves);
   hipStream_t st = (hipStream_t)stream;
@@ -1898,19 +1992,18 @@ extern "C" int sla_hip_launch_ltm_acf(const int32_t* d_residual, uint64_t plane_
   uint32_t log2F = 0;
   while ((1u << log2F) < fft_size) { log2F++; }
   hipStream_t st = (hipStream_t)stream;
-  const uint32_t dbg = (uint32_t)(getenv("SLA_HIP_ACF_SKIP") ? atoi(getenv("SLA_HIP_ACF_SKIP")) : 0);
   const size_t lds = sizeof(double) * (size_t)fft_size;
   unsigned long long* span = take_span();
   if (lds <= SLA_HIP_LDS_BUDGET) {
     hipError_t e = ensure_dynamic_lds((const void*)k_ltm_acf<true>, lds);
     if (e != hipSuccess) { return hip_rc(e); }
     hipLaunchKernelGGL(k_ltm_acf<true>, dim3(num_jobs), dim3(ACF_THREADS), lds, st, d_residual, plane_stride, d_jobs, num_jobs,
-                       log2F, d_twiddles, (double*)nullptr, d_acf_head, head, dbg, span);
+                       log2F, d_twiddles, (double*)nullptr, d_acf_head, head, span);
   } else {
     if (d_scratch == nullptr || scratch_slots == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
     uint32_t grid = (num_jobs < scratch_slots) ? num_jobs : scratch_slots;
     hipLaunchKernelGGL(k_ltm_acf<false>, dim3(grid), dim3(ACF_THREADS), 0, st, d_residual, plane_stride, d_jobs, num_jobs,
-                       log2F, d_twiddles, d_scratch, d_acf_head, head, dbg, span);
+                       log2F, d_twiddles, d_scratch, d_acf_head, head, span);
   }
   return hip_rc(hipGetLastError());
 }

@@ -96,3 +96,22 @@ int slai_range_is_zero(const uint64_t* nz, uint64_t from, uint64_t count)
 {
   return slai_zero_run(nz, from, count) == count;
 }
+
+/* Bit-identical output leans on two host properties the reference's own x86-64 build has: the Toeplitz solve
+ * refines its residual in x87 extended precision (long double with a 64-bit significand, src/SLAUtility.c:627-657),
+ * and windows / code lengths come from the C library's sin(), cos(), log().  The second cannot be checked against
+ * fixed answers (the library may pick a different kernel per CPU and still be what the reference would get on this
+ * very host), the first can: 0 = this host evaluates long double the way the reference build does. */
+#include <float.h>
+int slai_host_check(void)
+{
+#if !defined(__x86_64__) || LDBL_MANT_DIG != 64
+  return 1;
+#else
+  volatile long double one = 1.0L, tiny = 0x1p-63L;
+  volatile long double sum = one + tiny;                 /* representable only with a 64-bit significand */
+  volatile double d = 1.0, dt = 0x1p-53;
+  volatile double dsum = d + dt;                         /* and plain doubles must round to 53 bits (no x87 double rounding) */
+  return (sum != one && dsum == d) ? 0 : 1;
+#endif
+}

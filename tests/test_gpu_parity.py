@@ -431,7 +431,7 @@ def test_search_exact_launcher_equals_serial_chains(oracle, hip, order, nch, bit
     def run(lim):
         rc = L.sla_hip_launch_search_exact(C.c_void_p(d_pcm.data_ptr()), C.c_uint64(stride), ms, order,
                                            C.c_void_p(d_g.data_ptr()), nch, W_, len(cand), C.c_void_p(d_c.data_ptr()),
-                                           C.c_void_p(d_ts.data_ptr()), C.c_void_p(d_out.data_ptr()), C.c_double(lim), None)
+                                           C.c_void_p(d_ts.data_ptr()), C.c_void_p(d_out.data_ptr()), C.c_double(lim), C.c_double(0.0), None)
         assert rc == 0
         torch.cuda.synchronize()
         return d_out.cpu().numpy().reshape(nch, len(cand), order + 2)
@@ -449,11 +449,13 @@ def test_search_exact_launcher_equals_serial_chains(oracle, hip, order, nch, bit
     assert np.isnan(run(limit * 2.0 ** -40)[:, :, 0]).all()
 
 
-def _encode_with_env(hip, monkeypatch, p, pcm, **env):
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+def _encode_with_options(hip, p, pcm, **options):
+    """one whole-file encode on a fresh handle whose routes / layout knobs are set through
+    sla_hip_encoder_set_option (nothing on the launch path reads the environment)"""
     enc = hip.Encoder(p.cap_channels, p.cap_block_samples, p.cap_parcor_order, p.cap_longterm_order, p.cap_lms_order)
     try:
+        for k, v in options.items():
+            enc.set_option(k, v)
         enc.set_wave_format(p.num_channels, p.bits_per_sample, p.sampling_rate)
         enc.set_encode_parameter(p.parcor_order, p.longterm_order, p.lms_order, p.ch_process_method,
                                  p.window_type, p.max_block_samples)
@@ -463,27 +465,109 @@ def _encode_with_env(hip, monkeypatch, p, pcm, **env):
         enc.close()
 
 
+@pytest.mark.parametrize("order,nch,bits,ms,kind", [
+    (48, 1, 24, 0, "bench"), (32, 2, 24, 1, "bench"), (16, 1, 24, 0, "noise"), (32, 1, 24, 0, "tone"), (8, 2, 26, 1, "noise"),
+    (48, 1, 24, 0, "mixed"), (24, 1, 32, 0, "bench"), (16, 1, 16, 0, "music")])
+def test_search_certificate_brackets_the_reference(oracle, hip, order, nch, bits, ms, kind):
+    """windows over the exactness limit: sla_hip_launch_search_exact keeps the tile sums and reports, per candidate, a
+    half width w of log2(e_p) (e_p = r0 * prod(1 - k^2)).  The reference's value -- autocorrelation summed in ITS order,
+    ITS Levinson recursion -- must lie inside [mid - w, mid + w] for every candidate: loud sinusoids + noise (the bench
+    signal), full-scale noise, an almost pure tone (nearly singular), a loud window with a quiet stretch, 32-bit material;
+    candidates without a bracket carry +inf.  (The limit is forced to zero so that every window takes this route.)"""
+    import torch
+    L = hip.lib()
+    L.sla_hip_search_exact_lags.restype = C.c_uint32
+    lags = L.sla_hip_search_exact_lags(order)
+    W_ = 8 * 1024
+    rng = np.random.default_rng(order + bits)
+    n = W_ + 64
+    t = np.arange(n) / 48000.0
+    fs = 2.0 ** (bits - 1) - 1
+    if kind == "bench":
+        x = [fs * (0.35 * np.sin(2 * np.pi * 220 * (c + 1) * t) + 0.2 * np.sin(2 * np.pi * 1333.7 * t + c) + 0.1 * np.sin(2 * np.pi * 5011.3 * t))
+             + rng.uniform(-0.02, 0.02, n) * fs for c in range(nch)]
+    elif kind == "noise":
+        x = [rng.uniform(-1, 1, n) * fs for _ in range(nch)]
+    elif kind == "tone":
+        x = [0.9 * fs * np.sin(2 * np.pi * 997.0 * t + c) + rng.uniform(-2, 2, n) for c in range(nch)]
+    elif kind == "mixed":
+        env = np.where((np.arange(n) > 3000) & (np.arange(n) < 5500), 1e-4, 1.0)
+        x = [rng.uniform(-1, 1, n) * fs * env for _ in range(nch)]
+    else:
+        x = [W.music_like(1, n, bits, seed=3)[0].astype(np.float64) / 2.0 ** (32 - bits)]
+    pcm = np.ascontiguousarray((np.round(np.stack(x)).astype(np.int64) << (32 - bits)).astype(np.int32))
+    stride = pcm.shape[1]
+    cand = sorted({(i * 1024, (j - i) * 1024) for i in range(9) for j in range(i + 2, 9)})
+
+    class Group(C.Structure):
+        _fields_ = [("pcm_off", C.c_uint64)] + [(k, C.c_uint32) for k in (
+            "num_samples", "channel", "win_off", "int_shift", "cand_first", "cand_count", "slot_first", "pad_")]
+    off = 17
+    groups = (Group * nch)(*[Group(off, W_, ch, 0xFFFFFFFF, 32 - bits, 0, len(cand), ch * len(cand), 0) for ch in range(nch)])
+    d_pcm = torch.from_numpy(pcm).cuda()
+    d_g = torch.frombuffer(bytearray(bytes(groups)), dtype=torch.uint8).cuda()
+    d_c = torch.from_numpy(np.array(cand, np.uint32)).cuda()
+    d_ts = torch.zeros(nch * 16 * 2 * lags, dtype=torch.float64, device="cuda")
+    d_out = torch.zeros(nch * len(cand) * (order + 2), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    rc = L.sla_hip_launch_search_exact(C.c_void_p(d_pcm.data_ptr()), C.c_uint64(stride), ms, order,
+                                       C.c_void_p(d_g.data_ptr()), nch, W_, len(cand), C.c_void_p(d_c.data_ptr()),
+                                       C.c_void_p(d_ts.data_ptr()), C.c_void_p(d_out.data_ptr()), C.c_double(0.0), C.c_double(64.0), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy().reshape(nch, len(cand), order + 2)
+    xd = pcm.astype(np.float64) * 2.0 ** -31
+    if ms:
+        xd = np.stack([(xd[0] + xd[1]) / 2, xd[0] - xd[1]])
+    bracketed, worst = 0, 0.0
+    for ch in range(nch):
+        for i, (s, ln) in enumerate(cand):
+            xs = np.ascontiguousarray(xd[ch, off + s:off + s + ln])
+            r0 = oracle.autocorr(xs, 1)[0]
+            _, par = oracle.parcor(xs, order)
+            o = out[ch, i]
+            w = o[1]
+            assert w > 0.0                                                 # marked as certified-not-exact
+            assert abs(o[0] - r0) <= 1e-9 * abs(r0) + 1e-300                # the tile sums are close ...
+            if not np.isfinite(w):
+                continue
+            bracketed += 1
+            ref = np.log2(r0) + np.sum(np.log2(1.0 - par[1:] ** 2))
+            mid = np.log2(o[0]) + np.sum(np.log2(1.0 - o[2:] ** 2))
+            assert abs(ref - mid) <= w, (ch, s, ln, ref - mid, w)           # ... and the reference sits inside the bracket,
+            worst = max(worst, abs(ref - mid) / w)
+    assert worst < 0.05                                                     # far inside it
+    if kind in ("bench", "noise", "music"):
+        assert bracketed == nch * len(cand)
+
+
 @pytest.mark.parametrize("nch,bits,ms,maxb", [(1, 16, 0, 4096), (2, 24, 1, 16384), (2, 16, 1, 12288)])
-def test_search_paths_agree(oracle, hip, monkeypatch, nch, bits, ms, maxb):
-    """the three ways a partition search can run -- tile sums, tile sums with every group over a lowered
-    limit (serial-chain fallback), serial chains only -- give the oracle's bytes"""
+def test_search_paths_agree(oracle, hip, nch, bits, ms, maxb):
+    """every way a partition search can run gives the oracle's bytes: tile sums (exact below the limit); every window
+    pushed over a lowered limit and (a) certified by the error bracket, (b) flagged at once and rerun as serial chains
+    (certificate off), (c) certificate so wide that nothing certifies -> flagged by k_plan, rerun, decided on the host;
+    no tile sums at all"""
     n = 200000
     pcm = W.music_like(nch, n, bits, seed=77)
     p = S.make_params(nch, bits, 48000, parcor=16, ltm=1, lms=8, ms=ms, max_block=maxb)
     ret, want, _ = oracle.encode_trace(p, pcm)
     assert ret == 0
-    a, ta = _encode_with_env(hip, monkeypatch, p, pcm)
-    b, tb = _encode_with_env(hip, monkeypatch, p, pcm, SLA_HIP_EXACT_BITS="1")
-    c, tc = _encode_with_env(hip, monkeypatch, p, pcm, SLA_HIP_SEARCH="chain")
-    assert a == want and b == want and c == want
+    a, ta = _encode_with_options(hip, p, pcm)
+    b, tb = _encode_with_options(hip, p, pcm, exact_bits=1)
+    b1, tb1 = _encode_with_options(hip, p, pcm, exact_bits=1, cert_safety=0)
+    b2, tb2 = _encode_with_options(hip, p, pcm, exact_bits=1, cert_safety=1e25)
+    b3, tb3 = _encode_with_options(hip, p, pcm, exact_bits=1, device_plan=0)
+    c, tc = _encode_with_options(hip, p, pcm, search_exact=0)
+    assert a == want and b == want and b1 == want and b2 == want and b3 == want and c == want
     assert ta[11] == 1.0 and tb[11] == 1.0 and tc[11] == 0.0
-    assert tb[10] > 0 and tc[10] == 0
+    assert tb1[10] > 0 and tb2[10] == tb1[10] and tb3[10] == tb1[10] and tc[10] == 0
+    assert tb[10] <= tb1[10] // 10                 # certified: (almost) nothing had to take the chains
     if bits <= 16:
         assert ta[10] == 0          # 16-bit material can never reach the limit
 
 
 @pytest.mark.parametrize("nch,bits,ms,maxb", [(1, 16, 0, 4096), (2, 24, 1, 16384), (8, 16, 0, 8192)])
-def test_plan_paths_agree(oracle, hip, monkeypatch, nch, bits, ms, maxb):
+def test_plan_paths_agree(oracle, hip, nch, bits, ms, maxb):
     """partition decided on the device (certified), on the host for every super-frame (margin raised so that
     nothing certifies) and with the device plan switched off: the oracle's bytes each time"""
     n = 150000
@@ -494,9 +578,9 @@ def test_plan_paths_agree(oracle, hip, monkeypatch, nch, bits, ms, maxb):
     p = S.make_params(nch, bits, 48000, parcor=16, ltm=1, lms=8, ms=ms, max_block=maxb)
     ret, want, _ = oracle.encode_trace(p, pcm)
     assert ret == 0
-    a, ta = _encode_with_env(hip, monkeypatch, p, pcm)
-    b, tb = _encode_with_env(hip, monkeypatch, p, pcm, SLA_HIP_PLAN_MARGIN="1e30")
-    c, tc = _encode_with_env(hip, monkeypatch, p, pcm, SLA_HIP_PLAN="host")
+    a, ta = _encode_with_options(hip, p, pcm)
+    b, tb = _encode_with_options(hip, p, pcm, plan_margin=1e30)
+    c, tc = _encode_with_options(hip, p, pcm, device_plan=0)
     assert a == want and b == want and c == want
     assert ta[15] == 1 and tb[15] == 1 and tc[15] == 0
     assert tb[13] > 0 and tb[13] >= ta[13] and tc[13] == 0
@@ -504,18 +588,21 @@ def test_plan_paths_agree(oracle, hip, monkeypatch, nch, bits, ms, maxb):
 
 
 @pytest.mark.parametrize("nch,bits,order,maxb", [(1, 16, 16, 4096), (2, 24, 32, 8192), (3, 16, 48, 16384), (2, 8, 5, 2048)])
-def test_lattice_fused_into_the_block_kernel(oracle, hip, monkeypatch, nch, bits, order, maxb):
-    """SLA_HIP_LATTICE=fused: sla_hip_launch_lpc_blocks runs the PARCOR lattice inside k_lpc_blocks"""
+def test_lattice_fused_into_the_block_kernel(oracle, hip, nch, bits, order, maxb):
+    """option fuse_lattice: sla_hip_launch_lpc_blocks runs the PARCOR lattice inside k_lpc_blocks; option
+    lpc_blocks_chains: the chosen blocks take k_lpc's serial chains"""
     pcm = W.music_like(nch, 90000, bits, seed=order)
     p = S.make_params(nch, bits, 48000, parcor=order, ltm=3, lms=8, ms=int(nch == 2), max_block=maxb)
     ret, want, _ = oracle.encode_trace(p, pcm)
     assert ret == 0
-    got, _ = _encode_with_env(hip, monkeypatch, p, pcm, SLA_HIP_LATTICE="fused")
+    got, _ = _encode_with_options(hip, p, pcm, fuse_lattice=1)
+    assert got == want
+    got, _ = _encode_with_options(hip, p, pcm, lpc_blocks_chains=1, lpc_pack=1, tail_waves=2)
     assert got == want
 
 
-def test_search_loud_24bit_takes_the_fallback_where_needed(oracle, hip, monkeypatch):
-    """full-scale 24-bit noise has > 2^51 units^2 per window: flagged groups rerun as serial chains"""
+def test_search_loud_24bit_takes_the_fallback_where_needed(oracle, hip):
+    """full-scale 24-bit noise has > 2^53 units^2 per window: certified partitions, or (certificate off) serial chains"""
     rng = np.random.default_rng(5)
     n = 70000
     loud = rng.integers(-2 ** 23, 2 ** 23 - 1, (2, n), dtype=np.int64).astype(np.int32)
@@ -524,9 +611,12 @@ def test_search_loud_24bit_takes_the_fallback_where_needed(oracle, hip, monkeypa
     p = S.make_params(2, 24, 96000, parcor=32, ltm=3, lms=16, ms=1, max_block=8192)
     ret, want, _ = oracle.encode_trace(p, pcm)
     assert ret == 0
-    got, t = _encode_with_env(hip, monkeypatch, p, pcm)
+    got, t = _encode_with_options(hip, p, pcm)
     assert got == want
-    assert t[11] == 1.0 and t[10] > 0
+    assert t[11] == 1.0
+    certified_run = t[10]
+    got, t = _encode_with_options(hip, p, pcm, cert_safety=0)
+    assert got == want and t[10] >= 8 and certified_run <= t[10] // 4       # certified: the chains are the exception
 
 
 # ------------------------------------------------------------------ seeded random walk over the parameter space

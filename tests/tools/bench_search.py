@@ -39,7 +39,7 @@ torch.cuda.synchronize()
 def run():
     rc = L.sla_hip_launch_search_exact(C.c_void_p(d_pcm.data_ptr()), C.c_uint64(n), 0, order, C.c_void_p(d_g.data_ptr()), ngroups, window, len(cand),
                                        C.c_void_p(d_c.data_ptr()), C.c_void_p(d_ts.data_ptr()), C.c_void_p(d_out.data_ptr()),
-                                       C.c_double(2.0 ** 21), None)
+                                       C.c_double(2.0 ** 21), C.c_double(0.0), None)
     assert rc == 0
 
 
