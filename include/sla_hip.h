@@ -185,7 +185,8 @@ int sla_hip_launch_lpc_rerun(const int32_t* d_pcm, uint64_t plane_stride, uint32
  * A group whose energy reaches the limit: with cert_safety <= 0 it gets NaN in r[0] of every candidate and the
  * caller reruns it through sla_hip_launch_lpc_rerun.  With cert_safety > 0 (the encoder passes 64) its candidates
  * keep their tile-sum results -- close to, but no longer bit-identical with, the reference's serially rounded sums --
- * and carry in parcor[0] (0 for every exact candidate) the half width w of log2(e_p), e_p = r0 * prod(1 - k_j^2):
+ * in the slot layout { r0, w, log2(e_p / r0), 0, .. }: parcor[0] (0 for every exact candidate) holds the half width w
+ * of log2(e_p), e_p = r0 * prod(1 - k_j^2), parcor[1] the logarithm itself instead of a coefficient (orders <= 64):
  * the reference's own value of log2(e_p) provably lies within +-w (Loewner-order bracket of the prediction error over
  * every Toeplitz matrix within cert_safety x the summation error bounds of both sides; see k_search_finish), or
  * +inf when no such bracket exists.  The code-length estimate depends on the autocorrelation only through e_p, so

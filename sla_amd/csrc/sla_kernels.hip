@@ -981,6 +981,34 @@ void k_acf_tiles(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
 // else (not positive definite, not finite, cert <= 0) is flagged -- NaN in r[0], or an infinite width -- and redone
 // as serial chains.
 #define XF_BATCH 64          // candidates one pass of the wave takes (at most)
+
+// Final prediction error e_p of the Toeplitz system (r0, rc[1..order]) by the Schur recursion, both generator vectors
+// in registers (static indices: the lower one moves down one slot per stage instead of the upper one moving up).
+// Only used where nothing has to match the reference's Levinson recursion bit for bit (the certificate): fused
+// multiply-adds, and NaN as soon as the recursion leaves the positive-definite range.
+template <int P>
+__device__ __forceinline__ double schur_error(const double* __restrict__ rc, double r0, uint32_t order)
+{
+  const double nan = __longlong_as_double(0x7FF8000000000000ll);
+  double u[P + 1], v[P + 2];
+#pragma unroll
+  for (int i = 0; i <= P; i++) { const double x = ((uint32_t)i <= order && i >= 1) ? rc[i] : 0.0; u[i] = (i == 0) ? r0 : x; v[i] = x; }
+  v[P + 1] = 0.0;
+  for (uint32_t m = 1; m <= order; m++) {
+    if (!(u[0] > 0.0)) { return nan; }
+    const double k = -v[1] / u[0];
+    if (!(fabs(k) < 1.0)) { return nan; }
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      const double t = v[i + 1], ui = u[i];
+      u[i] = __builtin_fma(k, t, ui);
+      v[i] = __builtin_fma(k, ui, t);
+    }
+  }
+  return (u[0] > 0.0) ? u[0] : nan;
+}
+
+template <int P>           // P >= order: 16, 32, 48, 64; 0 = no certificate (cert <= 0, or an order above 64)
 __global__ __launch_bounds__(64)
 void k_search_finish(uint32_t order, uint32_t lags, uint32_t batch,
                      const sla_hip_lpc_group* __restrict__ groups, const sla_hip_lpc_cand* __restrict__ cands,
@@ -1018,28 +1046,31 @@ void k_search_finish(uint32_t order, uint32_t lags, uint32_t batch,
       const sla_hip_lpc_cand cd = cands[g.cand_first + c0 + ci];
       double* o = out + ((uint64_t)g.slot_first + c0 + ci) * O2;
       const double* rc = r + ci * O1;
-      levinson_out(rc, av + ci * O2, vv + ci * O2, o, order, cd.len);
-      if (!exact) {
-        if (!(cert > 0.0)) {
-          o[0] = __longlong_as_double(0x7FF8000000000000ll);
-        } else {
-          const double u = 1.1102230246251565e-16;              // 2^-53
-          const double r0 = rc[0];
-          double w = inf;
-          if (cd.len >= order && r0 > 2.0 * (double)FLT_EPSILON) {       // the reference zeroes the coefficients below FLT_EPSILON (src/SLAPredictor.c:274)
-            const double delta = ((double)cd.len * u) * r0 + (48.0 * u) * energy;
-            const double d = cert * (double)(2 * order + 1) * delta;
-            double e_mid = r0;
-            for (uint32_t k = 1; k <= order; k++) { e_mid *= (1.0 - o[1 + k] * o[1 + k]); }
-            const double e_hi = levinson_error(rc, r0 + d, av + ci * O2, vv + ci * O2, order);
-            const double e_lo = (r0 - d > (double)FLT_EPSILON) ? levinson_error(rc, r0 - d, av + ci * O2, vv + ci * O2, order) : e_hi - e_hi + __longlong_as_double(0x7FF8000000000000ll);
-            if (e_mid > 0.0 && e_lo > 0.0 && e_hi >= e_mid && e_mid >= e_lo && e_hi < inf) {
-              const double up = log2(e_hi / e_mid), dn = log2(e_mid / e_lo);
-              w = ((up > dn) ? up : dn) * 1.000001 + 1e-12;       // (the device's log2 is good to a few ulp)
-            }
+      if (exact) {
+        levinson_out(rc, av + ci * O2, vv + ci * O2, o, order, cd.len);
+      } else if (P == 0) {
+        o[0] = __longlong_as_double(0x7FF8000000000000ll);          // flagged: rerun as serial chains
+      } else {
+        // slot layout of a certified candidate: { r0, width, log2(e_p / r0), 0, .. }
+        const double u = 1.1102230246251565e-16;                    // 2^-53
+        const double r0 = rc[0];
+        double w = inf, lg = 0.0;
+        if (cd.len >= order && r0 > 2.0 * (double)FLT_EPSILON) {     // (the reference zeroes the coefficients below FLT_EPSILON, src/SLAPredictor.c:274)
+          const double delta = ((double)cd.len * u) * r0 + (48.0 * u) * energy;
+          const double d = cert * (double)(2 * order + 1) * delta;
+          const double e_mid = schur_error<(P > 0) ? P : 1>(rc, r0, order);
+          const double e_hi = schur_error<(P > 0) ? P : 1>(rc, r0 + d, order);
+          const double e_lo = (r0 - d > (double)FLT_EPSILON) ? schur_error<(P > 0) ? P : 1>(rc, r0 - d, order) : (e_hi - e_hi) / (e_hi - e_hi);
+          if (e_mid > 0.0 && e_lo > 0.0 && e_hi >= e_mid && e_mid >= e_lo && e_hi < inf) {
+            const double up = log2(e_hi / e_mid), dn = log2(e_mid / e_lo);
+            w = ((up > dn) ? up : dn) * 1.000001 + 1e-11;         // (device log2: a few ulp)
+            lg = log2(e_mid / r0);
           }
-          o[1] = (w == w) ? w : inf;
         }
+        o[0] = r0;
+        o[1] = (w == w) ? w : inf;
+        o[2] = lg;
+        for (uint32_t k = 2; k <= order; k++) { o[1 + k] = 0.0; }
       }
     }
     __syncthreads();
@@ -1070,7 +1101,8 @@ __device__ __forceinline__ double plan_code_length(double sumsq, uint32_t n, uin
   if (fabs(power) <= (double)FLT_MIN) { if (width > 0.0) { sure = false; } return 0.0; }
   power = log(power) * l2e - log((double)n) * l2e;
   double gain = 0.0;
-  for (uint32_t ord = 1; ord <= order; ord++) { gain += log(1.0 - parcor[ord] * parcor[ord]) * l2e; }
+  if (width != 0.0) { gain = parcor[1]; }                        // certified candidate: log2(e_p / r0) itself (k_search_finish)
+  else { for (uint32_t ord = 1; ord <= order; ord++) { gain += log(1.0 - parcor[ord] * parcor[ord]) * l2e; } }
   double len = 1.9426950408889634 + 0.5 * (power + gain);
   len /= 8;
   if (!(fabs(len) > 1e-9 + width / 16.0)) { sure = false; }     // too close to the clamp (or NaN)
@@ -1860,10 +1892,20 @@ extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_
   if (e != hipSuccess) { return hip_rc(e); }
   const uint32_t batch = (max_cands_per_group < XF_BATCH) ? max_cands_per_group : XF_BATCH;
   const size_t lds = sizeof(double) * (size_t)batch * ((order + 1) + 2 * (size_t)(order + 2));
-  e = ensure_dynamic_lds((const void*)k_search_finish, lds);
-  if (e != hipSuccess) { return hip_rc(e); }
-  hipLaunchKernelGGL(k_search_finish, dim3(num_groups), dim3(64), lds, st, order, lags, batch,
-                     d_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety);
+  const int pclass = !(cert_safety > 0.0) ? 0 : (order <= 16) ? 16 : (order <= 32) ? 32 : (order <= 48) ? 48 : (order <= 64) ? 64 : 0;
+#define SLA_FINISH(PP) do { \
+    e = ensure_dynamic_lds((const void*)k_search_finish<PP>, lds); \
+    if (e != hipSuccess) { return hip_rc(e); } \
+    hipLaunchKernelGGL(k_search_finish<PP>, dim3(num_groups), dim3(64), lds, st, order, lags, batch, \
+                       d_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety); } while (0)
+  switch (pclass) {
+    case 16: SLA_FINISH(16); break;
+    case 32: SLA_FINISH(32); break;
+    case 48: SLA_FINISH(48); break;
+    case 64: SLA_FINISH(64); break;
+    default: SLA_FINISH(0); break;
+  }
+#undef SLA_FINISH
   return hip_rc(hipGetLastError());
 }
 

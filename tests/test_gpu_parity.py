@@ -533,7 +533,8 @@ def test_search_certificate_brackets_the_reference(oracle, hip, order, nch, bits
                 continue
             bracketed += 1
             ref = np.log2(r0) + np.sum(np.log2(1.0 - par[1:] ** 2))
-            mid = np.log2(o[0]) + np.sum(np.log2(1.0 - o[2:] ** 2))
+            mid = np.log2(o[0]) + o[2]                                      # slot of a certified candidate: { r0, w, log2(e_p / r0), 0.. }
+            assert not o[3:].any()
             assert abs(ref - mid) <= w, (ch, s, ln, ref - mid, w)           # ... and the reference sits inside the bracket,
             worst = max(worst, abs(ref - mid) / w)
     assert worst < 0.05                                                     # far inside it
