@@ -398,6 +398,36 @@ int sla_hip_analyze_batch_device(struct SLAEncoder* encoder, const int32_t* d_pc
                                  const uint32_t* file_start, const uint32_t* file_samples, uint32_t num_files,
                                  uint32_t* file_lshift, float* timing_ms);
 
+/* ---- one file, several GPUs ------------------------------------------------------------------------------
+ * Blocks are independent (every filter and the coder reset per block, src/SLAEncoder.c:594-659), so the super-frames
+ * of ONE file shard over the GPUs of a node, one process and one encoder handle per GPU.  Three facts of the whole
+ * file have to be agreed on first, and the library leaves the exchange to the caller (RCCL from C, or
+ * torch.distributed as in sla_amd/dist.py -- the library itself links no collective library):
+ *   offset_lshift   comes from the OR of EVERY sample (src/SLAEncoder.c:425-455)      -> all-reduce (bitwise OR) of 4 bytes
+ *   super-frames    hop over silence runs, so where one starts depends on everything before it
+ *                   (src/SLAEncoder.c:392-408, 846-869)                                -> all-gather of the 1-bit mask
+ *   the header      counts blocks and keeps the largest block / bit rate (:920-926)   -> gathered with the bytes
+ * Sequence on rank r of `world` (file of N samples per channel, pieces cut at multiples of 1024):
+ *   1. upload any piece of the file that contains [N*r/world, N*(r+1)/world) plus max_num_block_samples behind it;
+ *      sla_hip_shard_scan on exactly [N*r/world .. N*(r+1)/world)  ->  OR word, mask bits of the piece
+ *   2. all-reduce the OR words (|), all-gather the mask pieces (N/8 bytes in total)
+ *   3. sla_hip_shard_bounds (pure host arithmetic, every rank computes the same table): rank r owns
+ *      [bounds[r], bounds[r+1]), both super-frame starts of the whole file's hop
+ *   4. sla_hip_shard_analyze on the planes of that range with the file's OR word (the hot path: exactly
+ *      sla_hip_analyze_device, but offset_lshift and the sample unit are the file's), then sla_hip_pack_device:
+ *      a complete .sla image of the range, 43-byte header + blocks
+ *   5. gather sizes and bytes on one rank (all-gather over xGMI: compressed bytes, less than the residual planes the
+ *      north star's variant gathers -- sla_amd/dist.py keeps both); that rank drops the headers of ranks > 0 and
+ *      writes the file's header with sla_hip_shard_header.
+ * The result is byte-identical to SLAEncoder_EncodeWhole of the whole file on one GPU. */
+int sla_hip_shard_scan(struct SLAEncoder* encoder, const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_samples,
+                       uint32_t* or_word, uint64_t* nz_mask /* host, ceil(num_samples / 64) words */);
+int sla_hip_shard_bounds(uint32_t num_samples, uint32_t max_num_block_samples, const uint64_t* nz_mask, uint32_t world,
+                         uint32_t* bounds /* world + 1 entries */);
+int sla_hip_shard_analyze(struct SLAEncoder* encoder, const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_samples,
+                          uint32_t file_or_word, float* timing_ms);
+int sla_hip_shard_header(const uint8_t* const* shard_headers /* world x 43 bytes */, uint32_t world, uint8_t* data, uint32_t data_size);
+
 /* Device pointers of the last analysis (for RCCL gathers / tests). */
 const int32_t* sla_hip_final_residual(const struct SLAEncoder* encoder, uint64_t* plane_stride);
 const int32_t* sla_hip_lattice_residual(const struct SLAEncoder* encoder, uint64_t* plane_stride);

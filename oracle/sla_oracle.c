@@ -1303,8 +1303,10 @@ static void trace_block(enc_t* e, sla_flat_trace* tr, uint32_t b, uint32_t pos, 
 }
 
 /* whole file (reference src/SLAEncoder.c:804-932) */
+/* forced_lshift != 0xFFFFFFFF: the samples are a range of a longer file whose offset_lshift this is (tests of the
+ * multi-GPU sharding: the reference computes it over the whole input, src/SLAEncoder.c:835-837) */
 static int encode_whole_impl(const sla_flat_params* p, const int32_t* input, uint32_t n, uint8_t* out, uint32_t cap,
-                             uint32_t* out_size, sla_flat_trace* tr, int skip_pack)
+                             uint32_t* out_size, sla_flat_trace* tr, int skip_pack, uint32_t forced_lshift)
 {
   const int32_t* chan[K_MAX_CHANNELS];
   const int32_t* at[K_MAX_CHANNELS];
@@ -1318,7 +1320,7 @@ static int encode_whole_impl(const sla_flat_params* p, const int32_t* input, uin
   e->skip_pack = skip_pack;
   for (ch = 0; ch < p->num_channels; ch++) { chan[ch] = &input[(size_t)ch * n]; }
   if ((ret = write_header(p, 0, n, 0, 0xFFFFFFFFu, 0, out, cap)) != SLAO_OK) { goto done; }
-  e->lshift = common_lshift(p, chan, n);
+  e->lshift = (forced_lshift != 0xFFFFFFFFu) ? forced_lshift : common_lshift(p, chan, n);
   if (tr != NULL) { tr->offset_lshift = e->lshift; }
 
   while (pos < n) {
@@ -1349,17 +1351,20 @@ done:
 }
 
 int slao_encode_whole(const sla_flat_params* p, const int32_t* input, uint32_t n, uint8_t* out, uint32_t cap, uint32_t* out_size)
-{ return encode_whole_impl(p, input, n, out, cap, out_size, NULL, 0); }
+{ return encode_whole_impl(p, input, n, out, cap, out_size, NULL, 0, 0xFFFFFFFFu); }
+
+int slao_encode_range(const sla_flat_params* p, const int32_t* input, uint32_t n, uint32_t file_lshift, uint8_t* out, uint32_t cap, uint32_t* out_size)
+{ return encode_whole_impl(p, input, n, out, cap, out_size, NULL, 0, file_lshift); }
 
 int slao_encode_trace(const sla_flat_params* p, const int32_t* input, uint32_t n, uint8_t* out, uint32_t cap,
                       uint32_t* out_size, sla_flat_trace* tr)
-{ return encode_whole_impl(p, input, n, out, cap, out_size, tr, 0); }
+{ return encode_whole_impl(p, input, n, out, cap, out_size, tr, 0, 0xFFFFFFFFu); }
 
 /* CPU-baseline leg of bench.py: the LPC+residual path only (everything up to and including the
  * Rice initial parameter; the bit-serial residual body is not emitted) */
 int slao_hotpath(const sla_flat_params* p, const int32_t* input, uint32_t n, uint8_t* out, uint32_t cap,
                  uint32_t* out_size, sla_flat_trace* tr)
-{ return encode_whole_impl(p, input, n, out, cap, out_size, tr, 1); }
+{ return encode_whole_impl(p, input, n, out, cap, out_size, tr, 1, 0xFFFFFFFFu); }
 
 /* fixed-size EncodeBlock calls under one header */
 int slao_encode_fixed_blocks(const sla_flat_params* p, const int32_t* input, uint32_t n, uint32_t block_samples,

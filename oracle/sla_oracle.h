@@ -58,6 +58,9 @@ void     slao_decode_residual(const uint8_t* in, uint32_t size, uint32_t nch, ui
 /* codec level */
 int slao_encode_whole(const sla_flat_params* p, const int32_t* input, uint32_t n,
                       uint8_t* out, uint32_t cap, uint32_t* out_size);
+/* a range of a longer file: offset_lshift is the whole file's (the multi-GPU sharding tests assemble ranges) */
+int slao_encode_range(const sla_flat_params* p, const int32_t* input, uint32_t n, uint32_t file_lshift,
+                      uint8_t* out, uint32_t cap, uint32_t* out_size);
 int slao_encode_fixed_blocks(const sla_flat_params* p, const int32_t* input, uint32_t n, uint32_t block_samples,
                              uint8_t* out, uint32_t cap, uint32_t* out_size);
 int slao_encode_trace(const sla_flat_params* p, const int32_t* input, uint32_t n,

@@ -134,6 +134,10 @@ def lib():
         L.sla_hip_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.sla_hip_search_exact_lags.restype = C.c_uint32
         L.sla_hip_encoder_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        L.sla_hip_shard_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, u32p, C.POINTER(C.c_uint64)]
+        L.sla_hip_shard_bounds.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint32, u32p]
+        L.sla_hip_shard_analyze.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+        L.sla_hip_shard_header.argtypes = [C.POINTER(u8p), C.c_uint32, u8p, C.c_uint32]
         L.sla_hip_encode_batch.argtypes = [C.c_void_p, C.POINTER(BatchItem), C.c_uint32]
         L.sla_hip_analyze_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, u32p, u32p, C.c_uint32,
                                                    u32p, C.POINTER(C.c_float)]
@@ -175,7 +179,7 @@ EXPORTED_SYMBOLS = [
     "sla_hip_search_exact_lags", "sla_hip_launch_plan", "sla_hip_last_counters", "sla_hip_launch_lpc_rerun", "sla_hip_last_kernel_ms", "sla_hip_launch_lpc_blocks",
     "sla_hip_launch_lpc_f64", "sla_hip_launch_lattice_raw", "sla_hip_launch_tail_stages", "sla_hip_launch_emphasis_i32",
     "sla_hip_launch_emphasis_f64", "sla_hip_use_tuning",
-    "sla_hip_encoder_set_option",
+    "sla_hip_encoder_set_option", "sla_hip_shard_scan", "sla_hip_shard_bounds", "sla_hip_shard_analyze", "sla_hip_shard_header",
     # include/SLAPredictor.h, include/SLACoder.h (per-call API of the reference, encode side)
     "SLALPCCalculator_Create", "SLALPCCalculator_Destroy", "SLALPCCalculator_CalculatePARCORCoefDouble",
     "SLALPCCalculator_EstimateCodeLength", "SLALPCSynthesizer_Create", "SLALPCSynthesizer_Destroy", "SLALPCSynthesizer_Reset",
@@ -365,6 +369,22 @@ class Encoder:
         self.num_samples = span
         return list(timing), lsh
 
+    def shard_scan(self, device_ptr, plane_stride, num_samples):
+        """sla_hip_shard_scan: (OR of every sample word, 1-bit 'not silent' mask as uint64 words) of a piece of a file"""
+        orw = C.c_uint32(0)
+        mask = np.zeros((num_samples + 63) // 64, np.uint64)
+        self._check(self._lib.sla_hip_shard_scan(self._h, C.c_void_p(device_ptr), plane_stride, num_samples, C.byref(orw),
+                                                 mask.ctypes.data_as(C.POINTER(C.c_uint64))), "sla_hip_shard_scan")
+        return int(orw.value), mask
+
+    def shard_analyze(self, device_ptr, plane_stride, num_samples, file_or_word):
+        """sla_hip_shard_analyze: the hot path on a range of a longer file whose OR word is `file_or_word`"""
+        timing = (C.c_float * 12)()
+        self._check(self._lib.sla_hip_shard_analyze(self._h, C.c_void_p(device_ptr), plane_stride, num_samples,
+                                                    C.c_uint32(file_or_word), timing), "sla_hip_shard_analyze")
+        self.num_samples = num_samples
+        return list(timing)
+
     def last_timing(self):
         """the 12 stage timings / counters of the last analysis (see include/sla_hip.h)"""
         timing = (C.c_float * 12)()
@@ -404,6 +424,37 @@ class Encoder:
     def final_residual_ptr(self):
         stride = C.c_uint64(0)
         return self._lib.sla_hip_final_residual(self._h, C.byref(stride)), stride.value
+
+
+def shard_bounds(num_samples, max_num_block_samples, nz_mask, world):
+    """sla_hip_shard_bounds: [bounds[r], bounds[r+1]) = the samples rank r of `world` encodes, every bound a super-frame
+    start of the whole file's hop over silence runs.  Pure host arithmetic of the library (no GPU needed)."""
+    mask = np.ascontiguousarray(nz_mask, np.uint64)
+    if len(mask) < (num_samples + 63) // 64:
+        raise ValueError("mask too short")
+    bounds = np.zeros(world + 1, np.uint32)
+    rc = lib().sla_hip_shard_bounds(C.c_uint32(num_samples), C.c_uint32(max_num_block_samples),
+                                    mask.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_uint32(world), bounds.ctypes.data_as(u32p))
+    if rc != 0:
+        raise SlaError(rc, "sla_hip_shard_bounds")
+    return [int(b) for b in bounds]
+
+
+def shard_join(shard_images):
+    """the per-rank .sla images (43-byte header + blocks each, in rank order) -> the file: sla_hip_shard_header over
+    the shards' headers, then the blocks back to back"""
+    shard_images = [img for img in shard_images if len(img) != 0]        # a rank without super-frames contributes nothing
+    if not shard_images:
+        raise ValueError("no shard produced an image")
+    heads = [np.frombuffer(bytes(img[:43]), np.uint8).copy() for img in shard_images]
+    if any(len(h) != 43 for h in heads):
+        raise ValueError("shard image shorter than a header")
+    ptrs = (u8p * len(heads))(*[h.ctypes.data_as(u8p) for h in heads])
+    out = np.zeros(43, np.uint8)
+    rc = lib().sla_hip_shard_header(ptrs, len(heads), out.ctypes.data_as(u8p), 43)
+    if rc != 0:
+        raise SlaError(rc, "sla_hip_shard_header")
+    return out.tobytes() + b"".join(bytes(img[43:]) for img in shard_images)
 
 
 class Decoder:

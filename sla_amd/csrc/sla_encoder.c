@@ -18,6 +18,7 @@
  * SLAEncoder_Create fails.
  */
 #include "sla_internal.h"
+#include "SLADecoder.h"
 
 #include <math.h>
 #include <pthread.h>
@@ -93,6 +94,10 @@ struct SLAEncoder {
 
   /* caller-owned residual planes (e.g. torch tensors that feed an RCCL all-gather), optional */
   int32_t* user_res1; int32_t* user_res2; uint64_t user_stride;
+
+  /* one file over several GPUs (sla_hip_shard_*): this handle analyses a range of a longer file whose OR word -- hence
+   * offset_lshift and sample unit -- is the whole file's, not the range's.  0: off */
+  uint32_t file_or_word;
 
   /* batch of files in one pass (sla_hip_encode_batch): the files occupy [seg_start, seg_start + seg_len) of the
    * planes, every start a multiple of SLA_HIP_PREPASS_TILE, all with the same offset_lshift.  nsegs == 0: one file
@@ -867,6 +872,10 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
   }
   nz = (const uint64_t*)e->h_nz.ptr;
   ((uint64_t*)e->h_nz.ptr)[nwords] = 0; ((uint64_t*)e->h_nz.ptr)[nwords + 1] = 0;
+  if (e->file_or_word != 0) {
+    if ((e->h_or[0] & ~e->file_or_word) != 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }   /* not a range of that file */
+    e->h_or[0] = e->file_or_word;
+  }
   PTRACE("prepass + mask on the host");
 
   /* offset_lshift = bps - (32 - ntz(OR of all words))          src/SLAEncoder.c:425-455 */
@@ -1628,6 +1637,86 @@ int sla_hip_analyze_device(struct SLAEncoder* e, const int32_t* d_pcm, uint64_t 
   if (timing_ms != NULL) { memcpy(timing_ms, e->timing, sizeof(e->timing)); }
   e->analysed = 1;
   return 0;
+}
+
+/* ---- one file over several GPUs (include/sla_hip.h: "one file, several GPUs") --------------------------------- */
+
+int sla_hip_shard_scan(struct SLAEncoder* e, const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_samples,
+                       uint32_t* or_word, uint64_t* nz_mask)
+{
+  const uint64_t nwords = ((uint64_t)num_samples + 63) / 64;
+  uint32_t ms;
+  if (e == NULL || d_pcm == NULL || or_word == NULL || (nz_mask == NULL && num_samples != 0)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  RCCHK(check_ready(e));
+  if (plane_stride < num_samples) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  *or_word = 0;
+  if (num_samples == 0) { return 0; }
+  RCCHK(enter(e));
+  ms = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
+  RCCHK(dev_reserve(&e->d_or, 64));
+  RCCHK(dev_reserve(&e->d_nz, (size_t)(nwords + 2) * 8));
+  RCCHK(pin_reserve(&e->h_nz, (size_t)(nwords + 2) * 8));
+  RCCHK(sla_hip_launch_prepass(d_pcm, plane_stride, e->wave_format.num_channels, num_samples, e->wave_format.bit_per_sample, ms,
+                               (uint32_t*)e->d_or.ptr, (uint64_t*)e->d_nz.ptr, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_or, e->d_or.ptr, 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_nz.ptr, e->d_nz.ptr, (size_t)nwords * 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->nz_ones_words = 0;                                   /* h_nz no longer holds what the single-file path remembers */
+  *or_word = e->h_or[0];
+  memcpy(nz_mask, e->h_nz.ptr, (size_t)nwords * 8);
+  return 0;
+}
+
+/* The super-frame hop of the whole file (src/SLAEncoder.c:846-869 with the silence shortcut of :392-408), on the
+ * host from the 1-bit mask; bounds[r] = the first super-frame start at or behind sample r * N / world. */
+int sla_hip_shard_bounds(uint32_t num_samples, uint32_t max_num_block_samples, const uint64_t* nz_mask, uint32_t world,
+                         uint32_t* bounds)
+{
+  uint32_t pos = 0, r = 1;
+  if (bounds == NULL || world == 0 || max_num_block_samples < SLAI_MIN_BLOCK || (nz_mask == NULL && num_samples != 0)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  bounds[0] = 0;
+  while (pos < num_samples && r < world) {
+    const uint32_t remain = num_samples - pos;
+    const uint32_t window = (max_num_block_samples < remain) ? max_num_block_samples : remain;
+    const uint32_t min_blk = (SLAI_MIN_BLOCK < remain) ? SLAI_MIN_BLOCK : remain;
+    const uint32_t run = slai_zero_run(nz_mask, pos, window);
+    while (r < world && (uint64_t)pos >= ((uint64_t)num_samples * r + world - 1) / world) { bounds[r++] = pos; }
+    pos += (run >= min_blk) ? run : window;
+  }
+  while (r <= world) { bounds[r++] = num_samples; }
+  return 0;
+}
+
+int sla_hip_shard_analyze(struct SLAEncoder* e, const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_samples,
+                          uint32_t file_or_word, float* timing_ms)
+{
+  int rc;
+  if (e == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  e->file_or_word = file_or_word;
+  rc = sla_hip_analyze_device(e, d_pcm, plane_stride, num_samples, NULL, timing_ms);
+  e->file_or_word = 0;
+  return rc;
+}
+
+int sla_hip_shard_header(const uint8_t* const* shard_headers, uint32_t world, uint8_t* data, uint32_t data_size)
+{
+  struct SLAHeaderInfo total, h;
+  uint32_t r;
+  if (shard_headers == NULL || world == 0 || data == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  memset(&total, 0, sizeof(total));
+  for (r = 0; r < world; r++) {
+    if (shard_headers[r] == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+    if (SLADecoder_DecodeHeader(shard_headers[r], SLA_HEADER_SIZE, &h) != SLA_APIRESULT_OK) { return SLA_APIRESULT_INVALID_HEADER_FORMAT; }
+    if (r == 0) { total = h; continue; }
+    if (memcmp(&h.encode_param, &total.encode_param, sizeof(h.encode_param)) != 0 || h.wave_format.num_channels != total.wave_format.num_channels
+        || h.wave_format.bit_per_sample != total.wave_format.bit_per_sample || h.wave_format.sampling_rate != total.wave_format.sampling_rate
+        || h.wave_format.offset_lshift != total.wave_format.offset_lshift) { return SLA_APIRESULT_INVALID_HEADER_FORMAT; }
+    if ((uint64_t)total.num_samples + h.num_samples > 0xFFFFFFFFull) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
+    total.num_samples += h.num_samples; total.num_blocks += h.num_blocks;
+    if (h.max_block_size > total.max_block_size) { total.max_block_size = h.max_block_size; }
+    if (h.max_bit_per_second > total.max_bit_per_second) { total.max_bit_per_second = h.max_bit_per_second; }
+  }
+  return slai_write_header(&total, data, data_size);
 }
 
 int sla_hip_last_kernel_ms(const struct SLAEncoder* e, float* kernel_ms)

@@ -285,6 +285,17 @@ class CheckerLib:
                                       C.c_uint32(cap), C.byref(size))
         return ret, out[:size.value].tobytes()
 
+    def encode_range(self, params, pcm, file_lshift):
+        """a range of a longer file whose offset_lshift is `file_lshift` (oracle only; multi-GPU sharding tests)"""
+        pcm = np.ascontiguousarray(pcm, np.int32)
+        nch, n = pcm.shape
+        cap = 8 * nch * n + 65536
+        out = np.zeros(cap, np.uint8)
+        size = C.c_uint32(0)
+        ret = self.fn("encode_range")(C.byref(params), _ptr(pcm, i32p), C.c_uint32(n), C.c_uint32(file_lshift),
+                                      _ptr(out, u8p), C.c_uint32(cap), C.byref(size))
+        return ret, out[:size.value].tobytes()
+
     def encode_fixed_blocks(self, params, pcm, block_samples):
         pcm = np.ascontiguousarray(pcm, np.int32)
         nch, n = pcm.shape

@@ -83,3 +83,115 @@ def test_two_rank_gather_reassembles_residual_stream():
         pcm = S.synth_pcm(2, n, 16, 48000, seed=1000 + c)
         _, _, tr = o.encode_trace(p, pcm)
         assert np.array_equal(g[owner, slot], tr.res_final)
+
+
+# ------------------------------------------------------------------ ONE file over several ranks (sla_amd/dist.encode_sharded)
+
+class OracleShardBackend:
+    """stands in for the GPU in the CPU tests: the oracle scans and encodes the ranges; everything between -- piece
+    cuts, exchanges, sla_hip_shard_bounds, sla_hip_shard_header, assembly -- is the product's code"""
+
+    def __init__(self, oracle, p, pcm):
+        self.o, self.p, self.pcm = oracle, p, pcm
+
+    def scan(self, lo, hi):
+        x = self.pcm[:, lo:hi]
+        orw = int(np.bitwise_or.reduce(x.view(np.uint32).ravel())) if x.size else 0
+        sh = 32 - self.p.bits_per_sample
+        v = x >> sh
+        if self.p.ch_process_method == 1:
+            nz = (((v[0].astype(np.int64) + v[1]) >> 1) != 0) | (v[0] != v[1])
+        else:
+            nz = (v != 0).any(axis=0)
+        bits = np.zeros(((hi - lo + 63) // 64) * 64, np.uint8)
+        bits[:hi - lo] = nz
+        return orw, np.packbits(bits.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).ravel()
+
+    def encode_range(self, lo, hi, file_or):
+        if hi <= lo:
+            return b""
+        ntz = (file_or & -file_or).bit_length() - 1 if file_or else 32
+        lshift = self.p.bits_per_sample - (32 - ntz) if file_or else 0
+        ret, data = self.o.encode_range(self.p, np.ascontiguousarray(self.pcm[:, lo:hi]), lshift)
+        assert ret == 0
+        return data
+
+
+def sharded_cases():
+    """files whose sharding has something to get wrong: leading silence (shifts every later super-frame), silence
+    across a piece cut, a quiet piece whose own OR word would give another offset_lshift, a silent tail"""
+    out = []
+    a = S.synth_pcm(1, 70000, 16, 48000, seed=5)
+    a[:, :3000] = 0
+    a[:, 33000:37500] = 0
+    a[:, 66000:] = 0
+    out.append(("mono16", a, S.make_params(1, 16, 48000, 16, 1, 8, 0, 1, 4096, cap=(1, 4096, 16, 1, 8))))
+    b = S.synth_pcm(2, 90000, 24, 48000, seed=6)
+    b[:, :45000] &= ~np.int32(0xFFF)                  # the first half alone would shift by 4 more bits
+    b[:, 20000:23000] = 0
+    b[:, 44000:47000] = 0
+    out.append(("stereo24ms", b, S.make_params(2, 24, 48000, 32, 3, 8, 1, 1, 8192, cap=(2, 8192, 32, 3, 8))))
+    return out
+
+
+def _shard_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        o = S.oracle()
+        res = []
+        for name, pcm, p in sharded_cases():
+            got = sdist.encode_sharded(OracleShardBackend(o, p, pcm), pcm.shape[1], p.max_block_samples)
+            res.append((name, got))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_file_over_ranks_is_the_single_rank_file(world):
+    """world-size 2 and 3 over gloo: the assembled .sla of a file with leading and interior silence equals the
+    oracle's encode of the whole file, byte for byte"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = dict(q.get(timeout=600) for _ in range(world))
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    o = S.oracle()
+    for (name, pcm, p), (gname, data) in zip(sharded_cases(), got[0]):
+        ret, want = o.encode_whole(p, pcm)
+        assert ret == 0 and gname == name
+        assert data == want, name
+    assert all(d is None for r in range(1, world) for _, d in got[r])
+
+
+def test_shard_bounds_follow_the_silence_hop():
+    """sla_hip_shard_bounds (host arithmetic of the product, no GPU): bounds are super-frame starts of the reference's hop"""
+    import sla_amd
+    n, maxb = 100000, 4096
+    nz = np.ones(n, np.uint8)
+    nz[:3000] = 0                      # leading silence: one SILENT block of 3000, everything behind it shifted
+    nz[50000:50100] = 0                # too short to matter
+    nz[70000:80000] = 0                # a long run: super-frames inside it are silent blocks of up to 4096
+    bits = np.zeros((n + 63) // 64 * 64, np.uint8); bits[:n] = nz
+    mask = np.packbits(bits.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).ravel()
+    starts, pos = [], 0
+    while pos < n:
+        starts.append(pos)
+        win, minb = min(maxb, n - pos), min(2048, n - pos)
+        run = 0
+        while run < win and not nz[pos + run]:
+            run += 1
+        pos += run if run >= minb else win
+    for world in (1, 2, 3, 8, 64):
+        b = sla_amd.shard_bounds(n, maxb, mask, world)
+        assert b[0] == 0 and b[-1] == n and all(x <= y for x, y in zip(b, b[1:]))
+        for r in range(1, world):
+            target = (n * r + world - 1) // world
+            assert b[r] == min([s for s in starts if s >= target] + [n])
