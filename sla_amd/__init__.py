@@ -415,9 +415,9 @@ class Encoder:
         self._check(fn(self._h, out.ctypes.data_as(u8p), capacity, C.byref(size)), "sla_hip_pack")
         return out[:size.value].tobytes()
 
-    def trace(self, want_residuals=True):
+    def trace(self, want_residuals=True, max_blocks=None):
         tr = Trace(self.num_channels, self.order, self.ltm_order, self.num_samples,
-                   self.num_samples // 1024 + 8, want_residuals)
+                   max_blocks if max_blocks is not None else self.num_samples // 1024 + 8, want_residuals)
         self._check(self._lib.sla_hip_get_trace(self._h, C.byref(tr.c)), "sla_hip_get_trace")
         return tr
 
