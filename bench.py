@@ -252,7 +252,10 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
         top = min(n_file, hi0 + maxb) if world > 1 else n_file
         base = lo0
         span = top - lo0
-        stride = (span + 63) // 64 * 64
+        # the same plane stride on every rank (the residual planes are all-gathered as they are)
+        widest = max((min(n_file, sdist.scan_piece(n_file, world, r)[1] + maxb) if world > 1 else n_file) - sdist.scan_piece(n_file, world, r)[0]
+                     for r in range(world))
+        stride = (widest + 63) // 64 * 64
         d_pcm = torch.zeros((nch, stride), dtype=torch.int32, device="cuda")
         if primary and cfg == "C2" and world == 1:
             host_pcm = S.synth_pcm(nch, n_file, bits, rate, seed=12345)           # the numpy generator of BASELINE.md, as in round 1

@@ -591,7 +591,7 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
                   const double* __restrict__ window_pool, double* __restrict__ out,
                   int32_t* __restrict__ out_code, int32_t* __restrict__ out_kint, uint32_t* __restrict__ out_rshift,
                   uint32_t x_region, uint32_t nch, uint32_t clk, unsigned long long* exec_span,
-                  int32_t* __restrict__ lat_residual)
+                  int32_t* __restrict__ lat_residual, uint32_t defer_levinson)
 {
   constexpr uint32_t Q = LB_K / S;              // consecutive terms a producer lane makes per tile
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -737,6 +737,23 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
   __syncthreads();
   const unsigned long long t_chained = clk ? clock64() : 0;
 
+  if (defer_levinson) {
+    // the recursion and the quantiser run in k_blocks_finish (one LANE per window, everything in registers): this
+    // workgroup only hands over r[0..order] (in the slot's parcor area) and the quantiser's shift
+    if (wv < ng) {
+      const sla_hip_lpc_group g = s_g[wv];
+      double* o = out + (uint64_t)g.slot_first * O2;
+      if (lane <= order) { o[1 + lane] = r[wv * O1 + lane]; }
+      if (lane == 0) {
+        const uint32_t m = s_maxabs[wv];
+        const uint32_t l2c = (m > 1) ? (32u - (uint32_t)__builtin_clz(m - 1u)) : 0u;    // src/SLAUtility.c:677-696
+        const uint32_t bitwidth = (m > 0) ? (l2c + 1u) : 1u;
+        out_rshift[g.slot_first] = (bitwidth > 16) ? (bitwidth - 16) : 0;
+      }
+    }
+    span_end(exec_span);
+    return;
+  }
   // ---- Levinson-Durbin, one wave per window, lane j = coefficient j   src/SLAPredictor.c:253-328 ------
   if (wv < ng) {
     const sla_hip_lpc_group g = s_g[wv];
@@ -812,6 +829,78 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
     }
     if (wv == 2) { atomicAdd(&g_lpc_clk[5], t_prod); }
     if (wv == 1) { atomicAdd(&g_lpc_clk[6], t_cons); }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_blocks_finish: Levinson-Durbin (src/SLAPredictor.c:253-328) and the coefficient quantiser (src/SLAEncoder.c:567-589)
+// of the chosen blocks, one LANE per (block, channel).  Inside k_lpc_blocks the recursion ran lane-parallel on one wave
+// per window -- the sum gamma = sum a[i]*r[d+1-i] has to be added up in the reference's order, so it was (order^2)/2
+// dependent v_readlane + v_add_f64 pairs while the other waves of the workgroup idled: 91 of 376 thousand cycles per
+// C5 workgroup.  A lane that keeps a[] and r[] in registers does the same arithmetic, operation for operation, with no
+// cross-lane traffic at all, and 64 windows share a wave; the loops are unrolled over the stage and the coefficient
+// index so that every register index is static (the reversed vector v[i] = a[d+1-i] is just another register).
+// In: slot = { -, r[0..order] } as k_lpc_blocks left it, rshift.  Out: slot = { r0, parcor[0..order] }, code, kint.
+// ---------------------------------------------------------------------------------------------
+template <int P>           // P >= order
+__global__ __launch_bounds__(64)
+void k_blocks_finish(const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, uint32_t order,
+                     double* __restrict__ out, int32_t* __restrict__ out_code, int32_t* __restrict__ out_kint,
+                     const uint32_t* __restrict__ out_rshift)
+{
+  const uint32_t gi = blockIdx.x * 64 + threadIdx.x;
+  if (gi >= num_groups) { return; }
+  const uint32_t O1 = order + 1, O2 = order + 2;
+  const sla_hip_lpc_group g = groups[gi];
+  const uint64_t slot = g.slot_first;
+  double* o = out + slot * O2;
+  double r[P + 1], a[P + 1], par[P + 1];
+#pragma unroll
+  for (int i = 0; i <= P; i++) { r[i] = ((uint32_t)i <= order) ? o[1 + i] : 0.0; a[i] = 0.0; par[i] = 0.0; }
+  if (!(g.num_samples < order || fabs(r[0]) < (double)FLT_EPSILON)) {
+    a[0] = 1.0;
+    a[1] = -r[1] / r[0];
+    par[1] = r[1] / r[0];
+    double e = r[0] + r[1] * a[1];
+#pragma unroll
+    for (int d = 1; d < P; d++) {
+      if ((uint32_t)d < order) {
+        double gamma = 0.0;
+#pragma unroll
+        for (int i = 0; i <= d; i++) { gamma += a[i] * r[d + 1 - i]; }
+        gamma /= (-e);
+        e = (1.0 - gamma * gamma) * e;
+        // a[i] <- a[i] + gamma * v[i],  v = (0, a[d], a[d-1], .., a[1], 1),  a[0] = 1, a[d+1] = 0 beforehand
+        double nw[P + 1];
+#pragma unroll
+        for (int i = 1; i <= d; i++) { nw[i] = a[i] + gamma * a[d + 1 - i]; }
+#pragma unroll
+        for (int i = 1; i <= d; i++) { a[i] = nw[i]; }
+        a[0] = 1.0 + gamma * 0.0;
+        a[d + 1] = 0.0 + gamma * 1.0;
+        par[d + 1] = -gamma;
+      }
+    }
+  }
+  const uint32_t rshift = out_rshift[slot];
+  o[0] = r[0];
+  out_code[slot * O1] = 0; out_kint[slot * O1] = 0;
+#pragma unroll
+  for (int j = 0; j <= P; j++) {
+    if ((uint32_t)j <= order) {
+      o[1 + j] = par[j];
+      if (j >= 1) {
+        const uint32_t qb = (j < 4) ? 16 : 8;
+        const int32_t lim = 1 << (qb - 1);
+        const double kq = par[j] * (double)lim;
+        const double rk = (kq >= 0.0) ? floor(kq + 0.5) : -floor(-kq + 0.5);
+        int32_t code = f64_to_i32_x86(rk);
+        code = (code < -lim) ? -lim : code;
+        code = (code > lim - 1) ? (lim - 1) : code;
+        out_code[slot * O1 + j] = code;
+        out_kint[slot * O1 + j] = (int32_t)((uint32_t)code << (16u - qb)) >> rshift;
+      }
+    }
   }
 }
 
@@ -1807,12 +1896,22 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
 #else
       const uint32_t clk = 0;
 #endif
+      // Levinson-Durbin + quantiser: in registers, one lane per window (k_blocks_finish), unless the lattice is fused in
+      // (it needs the coefficients inside the workgroup)
+      const uint32_t defer = (d_lat_residual == nullptr && order <= 64) ? 1u : 0u;
       if (spl == 12) {
         hipLaunchKernelGGL(k_lpc_blocks<12>, grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
-                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span, d_lat_residual);
+                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span, d_lat_residual, defer);
       } else {
         hipLaunchKernelGGL(k_lpc_blocks<6>, grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
-                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span, d_lat_residual);
+                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span, d_lat_residual, defer);
+      }
+      if (defer) {
+        const dim3 fgrid((num_groups + 63) / 64), fblock(64);
+        if (order <= 16) { hipLaunchKernelGGL(k_blocks_finish<16>, fgrid, fblock, 0, (hipStream_t)stream, d_groups, num_groups, order, d_out, d_code, d_kint, d_rshift); }
+        else if (order <= 32) { hipLaunchKernelGGL(k_blocks_finish<32>, fgrid, fblock, 0, (hipStream_t)stream, d_groups, num_groups, order, d_out, d_code, d_kint, d_rshift); }
+        else if (order <= 48) { hipLaunchKernelGGL(k_blocks_finish<48>, fgrid, fblock, 0, (hipStream_t)stream, d_groups, num_groups, order, d_out, d_code, d_kint, d_rshift); }
+        else { hipLaunchKernelGGL(k_blocks_finish<64>, fgrid, fblock, 0, (hipStream_t)stream, d_groups, num_groups, order, d_out, d_code, d_kint, d_rshift); }
       }
 #ifdef SLA_HIP_DEBUG
       if (clk) {
