@@ -403,14 +403,14 @@ int sla_hip_analyze_batch_device(struct SLAEncoder* encoder, const int32_t* d_pc
  * of ONE file shard over the GPUs of a node, one process and one encoder handle per GPU.  Three facts of the whole
  * file have to be agreed on first, and the library leaves the exchange to the caller (RCCL from C, or
  * torch.distributed as in sla_amd/dist.py -- the library itself links no collective library):
- *   offset_lshift   comes from the OR of EVERY sample (src/SLAEncoder.c:425-455)      -> all-reduce (bitwise OR) of 4 bytes
+ *   offset_lshift   comes from the OR of EVERY sample (src/SLAEncoder.c:425-455)      -> OR of 4 bytes per rank (all-gathered: RCCL has no bitwise reduction)
  *   super-frames    hop over silence runs, so where one starts depends on everything before it
  *                   (src/SLAEncoder.c:392-408, 846-869)                                -> all-gather of the 1-bit mask
  *   the header      counts blocks and keeps the largest block / bit rate (:920-926)   -> gathered with the bytes
  * Sequence on rank r of `world` (file of N samples per channel, pieces cut at multiples of 1024):
  *   1. upload any piece of the file that contains [N*r/world, N*(r+1)/world) plus max_num_block_samples behind it;
  *      sla_hip_shard_scan on exactly [N*r/world .. N*(r+1)/world)  ->  OR word, mask bits of the piece
- *   2. all-reduce the OR words (|), all-gather the mask pieces (N/8 bytes in total)
+ *   2. all-gather the OR words and OR them, all-gather the mask pieces (N/8 bytes in total)
  *   3. sla_hip_shard_bounds (pure host arithmetic, every rank computes the same table): rank r owns
  *      [bounds[r], bounds[r+1]), both super-frame starts of the whole file's hop
  *   4. sla_hip_shard_analyze on the planes of that range with the file's OR word (the hot path: exactly

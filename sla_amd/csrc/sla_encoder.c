@@ -1425,7 +1425,9 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
 
   /* chunking: equal runs of super-frames */
   want_chunks = e->chunks;
-  if (preset_blocks || a.nsf < 64) { want_chunks = 1; }
+  /* chunks pay off once the kernels are throughput-bound; a short file (a 10-second clip: 118 super-frames) is one
+   * block's serial LMS / Rice chain per stage however it is cut, and every extra chunk adds one more of those */
+  if (preset_blocks || a.nsf < 1024) { want_chunks = 1; }
   if (want_chunks > a.nsf / 32 + 1) { want_chunks = a.nsf / 32 + 1; }
   if (want_chunks > MAX_CHUNKS) { want_chunks = MAX_CHUNKS; }
   if (want_chunks < 1) { want_chunks = 1; }
@@ -1903,6 +1905,8 @@ static int pack_device_core(struct SLAEncoder* e, pack_seg_t* segs, uint32_t nse
   job_of = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)nb + 1));
   if (job_of == NULL) { return SLA_APIRESULT_NG; }
 
+  const double tp0 = now_ms();
+  double tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0;
   /* per block: header bytes, coding mode, Rice jobs */
   for (b = 0; b < nb; b++) {
     const blk_t* k = &e->blk[b];
@@ -1936,6 +1940,7 @@ static int pack_device_core(struct SLAEncoder* e, pack_seg_t* segs, uint32_t nse
     }
   }
 
+  tp1 = now_ms();
   /* code lengths on the device */
   if (njobs > 0) {
     RCCHK(dev_reserve(&e->d_kk, sizeof(uint16_t) * (size_t)C * e->stride));
@@ -1949,6 +1954,7 @@ static int pack_device_core(struct SLAEncoder* e, pack_seg_t* segs, uint32_t nse
     HIPCHK(hipStreamSynchronize(e->stream));
   }
 
+  tp2 = now_ms();
   /* block sizes -> offsets; a file = 43 header bytes + its blocks */
   for (sg = 0; sg < nsegs; sg++) { segs[sg].out_size = 0; segs[sg].result = 0; segs[sg].num_blocks = 0; segs[sg].max_block = 0; segs[sg].max_bps = 0; }
   sg = 0; segs[0].img_off = 0; cur = SLA_HEADER_SIZE;
@@ -2007,10 +2013,16 @@ static int pack_device_core(struct SLAEncoder* e, pack_seg_t* segs, uint32_t nse
                                       e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS,
                                       (uint32_t*)e->d_image.ptr, e->stream));
     }
+    tp3 = now_ms();
     for (sg = 0; sg < nsegs; sg++) {
       if (segs[sg].result != 0) { continue; }
       RCCHK(download_bytes(e, segs[sg].data, (const uint8_t*)e->d_image.ptr + segs[sg].img_off, (size_t)segs[sg].out_size));
     }
+    tp4 = now_ms();
+  }
+  if (e->trace) {
+    fprintf(stderr, "[sla_hip] pack: headers + jobs %.3f ms, k_rice_len + sizes home %.3f ms, offsets + launches %.3f ms, write/crc kernels + download %.3f ms\n",
+            tp1 - tp0, tp2 - tp1, tp3 - tp2, tp4 - tp3);
   }
   for (sg = 0; sg < nsegs; sg++) {
     if (segs[sg].result != 0) { continue; }
@@ -2157,9 +2169,16 @@ SLAApiResult SLAEncoder_EncodeWhole(struct SLAEncoder* e, const int32_t* const* 
   if ((rc = check_ready(e)) != 0) { return (SLAApiResult)rc; }
   if (data_size < SLA_HEADER_SIZE) { return SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE; }
   if (enter(e) != 0) { return SLA_APIRESULT_NG; }
-  if ((rc = upload_pcm(e, input, num_samples)) != 0) { return (rc > 0) ? (SLAApiResult)rc : SLA_APIRESULT_NG; }
-  rc = sla_hip_analyze_device(e, e->pcm_dev, e->stride, num_samples, NULL, NULL);
-  if (rc == 0) { rc = sla_hip_pack_device(e, data, data_size, output_size); }
+  {
+    const double t0 = now_ms();
+    double t1, t2;
+    if ((rc = upload_pcm(e, input, num_samples)) != 0) { return (rc > 0) ? (SLAApiResult)rc : SLA_APIRESULT_NG; }
+    t1 = now_ms();
+    rc = sla_hip_analyze_device(e, e->pcm_dev, e->stride, num_samples, NULL, NULL);
+    t2 = now_ms();
+    if (rc == 0) { rc = sla_hip_pack_device(e, data, data_size, output_size); }
+    if (e->trace) { fprintf(stderr, "[sla_hip] EncodeWhole: upload %.3f ms, analysis %.3f ms, pack + download %.3f ms\n", t1 - t0, t2 - t1, now_ms() - t2); }
+  }
   return (rc >= 0) ? (SLAApiResult)rc : SLA_APIRESULT_NG;
 }
 

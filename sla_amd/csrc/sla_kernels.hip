@@ -2154,9 +2154,10 @@ extern "C" int sla_hip_launch_ltm_acf(const int32_t* d_residual, uint64_t plane_
 // residual (reference src/SLACoder.c:45-82, 120-138, 224-270, 429-467), block assembly and CRC16
 // (src/SLAEncoder.c:682-798, src/SLAUtility.c:322-339).
 //
-//   k_rice_len   one lane per (block, channel): walks the residual with the two adaptive parameters
-//                (8.8 fixed-point EMA, serial in time) and stores log2 of both Rice moduli per sample
-//                plus the channel's total bit count.  Blocks in fixed-Golomb mode need no state.
+//   k_rice_k     one lane per (block, channel): walks the residual with the two adaptive parameters
+//                (8.8 fixed-point EMA, serial in time) and stores log2 of both Rice moduli per sample.
+//                Blocks in fixed-Golomb mode need no state.
+//   k_rice_bits  one wave per (block, channel): the channel's total bit count (code lengths are stateless)
 //   k_rice_write one workgroup per block: header bytes, then tiles of 256 interleaved (sample, channel)
 //                elements -- code length from (value, k0, k1), workgroup prefix sum -> bit offset, and
 //                the <= 3 non-zero pieces of the codeword OR-ed into the zero-initialised image
@@ -2197,22 +2198,21 @@ __device__ __forceinline__ uint32_t golomb_len(uint32_t v, uint32_t m)
   return q + 1u + ((r < cut) ? (b - 1u) : b);
 }
 
+// The serial part only: the two adaptive parameters per sample (one lane per (block, channel)).  A lane issues its
+// instructions one after the other, so every instruction that is not on the recurrence costs as much as one that is:
+// the code lengths -- a function of (value, k0, k1), no state -- are left to k_rice_bits (a 10-second clip: 0.83 ->
+// see DESIGN.md ms for the two kernels).
 __global__ __launch_bounds__(64)
-void k_rice_len(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_rice_job* __restrict__ jobs,
-                uint32_t num_jobs, uint16_t* __restrict__ kk, uint64_t* __restrict__ chan_bits)
+void k_rice_k(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_rice_job* __restrict__ jobs,
+              uint32_t num_jobs, uint16_t* __restrict__ kk)
 {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= num_jobs) { return; }
   const sla_hip_rice_job job = jobs[j];
+  if (job.golomb_m != 0) { return; }                         // fixed-parameter mode: stateless
   const int32_t* in = res + (uint64_t)job.channel * stride + job.blk_off;
   uint16_t* ko = kk + (uint64_t)job.channel * stride + job.blk_off;
   const uint32_t n = job.blk_len;
-  uint64_t bits = 0;
-  if (job.golomb_m != 0) {                                   // fixed-parameter mode: stateless
-    for (uint32_t s = 0; s < n; s++) { bits += golomb_len(fold_u32(in[s]), job.golomb_m); }
-    chan_bits[j] = bits;
-    return;
-  }
   uint64_t p0 = (uint64_t)(uint32_t)(job.rice_init << 8), p1 = p0;
   uint32_t s = 0;
   for (; s + 8 <= n; s += 8) {
@@ -2222,10 +2222,9 @@ void k_rice_len(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_
     for (int u = 0; u < 8; u++) { v8[u] = in[s + u]; }       // loads first: the walk below is a serial chain
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      uint32_t v = fold_u32(v8[u]);
+      const uint32_t v = fold_u32(v8[u]);
       const uint32_t k0 = rice_k(p0), k1 = rice_k(p1);
       k8[u] = (uint16_t)(k0 | (k1 << 8));
-      bits += rrice_len(v, k0, k1);
       p0 = rice_adapt(p0, v);
       if (v >= (1u << k0)) { p1 = rice_adapt(p1, v - (1u << k0)); }
     }
@@ -2233,14 +2232,39 @@ void k_rice_len(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_
     for (int u = 0; u < 8; u++) { ko[s + u] = k8[u]; }
   }
   for (; s < n; s++) {
-    uint32_t v = fold_u32(in[s]);
+    const uint32_t v = fold_u32(in[s]);
     const uint32_t k0 = rice_k(p0), k1 = rice_k(p1);
     ko[s] = (uint16_t)(k0 | (k1 << 8));
-    bits += rrice_len(v, k0, k1);
     p0 = rice_adapt(p0, v);
     if (v >= (1u << k0)) { p1 = rice_adapt(p1, v - (1u << k0)); }
   }
-  chan_bits[j] = bits;
+}
+
+// total body bits of every (block, channel): one wave per job, lanes stride over the samples
+__global__ __launch_bounds__(256)
+void k_rice_bits(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_rice_job* __restrict__ jobs,
+                 uint32_t num_jobs, const uint16_t* __restrict__ kk, uint64_t* __restrict__ chan_bits)
+{
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= num_jobs) { return; }
+  const sla_hip_rice_job job = jobs[j];
+  const int32_t* in = res + (uint64_t)job.channel * stride + job.blk_off;
+  const uint16_t* ki = kk + (uint64_t)job.channel * stride + job.blk_off;
+  uint64_t bits = 0;
+  if (job.golomb_m != 0) {
+    for (uint32_t s = lane; s < job.blk_len; s += 64) { bits += golomb_len(fold_u32(in[s]), job.golomb_m); }
+  } else {
+    for (uint32_t s = lane; s < job.blk_len; s += 64) {
+      const uint32_t k = ki[s];
+      bits += rrice_len(fold_u32(in[s]), k & 0xFF, k >> 8);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bits, off), hi = (uint32_t)__shfl_xor((int)(uint32_t)(bits >> 32), off);
+    bits += ((uint64_t)hi << 32) | lo;
+  }
+  if (lane == 0) { chan_bits[j] = bits; }
 }
 
 // OR `len` (1..32) bits of `val` into the image, the first bit landing at absolute bit `pos` (MSB-first)
@@ -2365,7 +2389,9 @@ extern "C" int sla_hip_launch_rice_len(const int32_t* d_residual, uint64_t plane
 {
   if (d_residual == nullptr || d_jobs == nullptr || d_kk == nullptr || d_chan_bits == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (num_jobs == 0) { return 0; }
-  hipLaunchKernelGGL(k_rice_len, dim3((num_jobs + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_residual, plane_stride,
+  hipLaunchKernelGGL(k_rice_k, dim3((num_jobs + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_residual, plane_stride,
+                     d_jobs, num_jobs, d_kk);
+  hipLaunchKernelGGL(k_rice_bits, dim3((num_jobs + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_residual, plane_stride,
                      d_jobs, num_jobs, d_kk, d_chan_bits);
   return hip_rc(hipGetLastError());
 }

@@ -7,7 +7,8 @@ sla_hip.h, "one file, several GPUs", is the contract this module drives:
 
   1. scan        rank r scans its piece of the file            -> OR word (offset_lshift, src/SLAEncoder.c:425-455)
                                                                   + 1 bit per sample "not silent" (:392-408)
-  2. exchange    all-reduce (bitwise OR, 4 bytes) and all-gather of the mask pieces (N/8 bytes in total)
+  2. exchange    the OR of the ranks' words (4 bytes each, all-gathered: RCCL has no bitwise reduction) and all-gather of
+                 the mask pieces (N/8 bytes in total)
   3. bounds      every rank runs the same host arithmetic (sla_hip_shard_bounds): rank r owns super-frames
                  [bounds[r], bounds[r+1]) of the whole file's hop over silence runs (:846-869)
   4. encode      the hot path on the rank's own range with the FILE's OR word, then the device bit-pack
@@ -67,9 +68,13 @@ def max_over_ranks(seconds, device):
 def exchange_scan(or_word, mask_piece, num_samples, device="cpu"):
     """step 2: the file's OR word and its whole mask from every rank's piece (pieces tile [0, N) in rank order)"""
     world, rank = dist.get_world_size(), dist.get_rank()
+    # the OR of the ranks' words: RCCL has no bitwise reduction, so the 4 bytes are all-gathered and OR-ed here
     t = torch.tensor([or_word & 0x7FFFFFFF, or_word >> 31], dtype=torch.int32, device=device)      # (int32-safe halves)
-    dist.all_reduce(t, op=dist.ReduceOp.BOR)
-    file_or = int(t[0].item()) | (int(t[1].item()) << 31)
+    allt = torch.empty(2 * world, dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(allt, t)
+    file_or = 0
+    for lo, hi in allt.cpu().numpy().reshape(world, 2):
+        file_or |= int(lo) | (int(hi) << 31)
     words = [((scan_piece(num_samples, world, r)[1] - scan_piece(num_samples, world, r)[0]) + 63) // 64 for r in range(world)]
     pad = max(max(words), 1)
     mine = np.zeros(pad, np.int64)
