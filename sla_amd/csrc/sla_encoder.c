@@ -2108,14 +2108,38 @@ static int upload_pass(struct SLAEncoder* e, const int32_t* const* input, uint32
   return 0;
 }
 
+/* 1 when [p, p + bytes) is page-locked host memory the runtime knows (hipHostMalloc / hipHostRegister): such a
+ * buffer crosses the bus by DMA as it is, without the copy through the pinned staging slots */
+static int is_pinned_host(const void* p, size_t bytes)
+{
+  hipPointerAttribute_t at;
+  if (bytes == 0) { return 0; }
+  memset(&at, 0, sizeof(at));
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (at.type != hipMemoryTypeHost) { return 0; }
+  memset(&at, 0, sizeof(at));
+  if (hipPointerGetAttributes(&at, (const uint8_t*)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return at.type == hipMemoryTypeHost;
+}
+
 static int upload_pcm(struct SLAEncoder* e, const int32_t* const* input, uint32_t n)
 {
   const uint32_t C = e->wave_format.num_channels;
   const uint64_t stride = ((uint64_t)n + 63) & ~(uint64_t)63;
   uint32_t ch, lowbits = 0;
-  int mode16 = (e->wave_format.bit_per_sample <= 16);
+  int mode16 = (e->wave_format.bit_per_sample <= 16), pinned = (n > 0);
   for (ch = 0; ch < C; ch++) { if (input[ch] == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; } }
   RCCHK(dev_reserve(&e->d_pcm, sizeof(int32_t) * (size_t)C * (stride + 64)));
+  for (ch = 0; ch < C && pinned; ch++) { pinned = is_pinned_host(input[ch], sizeof(int32_t) * (size_t)n); }
+  if (pinned) {
+    /* the caller's planes are page-locked: one DMA per channel at the bus rate, nothing for the host threads to do */
+    for (ch = 0; ch < C; ch++) {
+      HIPCHK(hipMemcpyAsync((int32_t*)e->d_pcm.ptr + (size_t)ch * stride, input[ch], sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->pcm_dev = (const int32_t*)e->d_pcm.ptr; e->stride = stride; e->num_samples = n;
+    return 0;
+  }
   for (ch = 0; ch < 2; ch++) {
     RCCHK(pin_reserve(&e->h_stage[ch], XFER_SLOT_BYTES));
     RCCHK(dev_reserve(&e->d_stage[ch], XFER_SLOT_BYTES));
@@ -2142,6 +2166,11 @@ static int download_bytes(struct SLAEncoder* e, uint8_t* dst, const uint8_t* d_s
   size_t o, k = 0, nslots = (bytes + XFER_SLOT_BYTES - 1) / XFER_SLOT_BYTES;
   stage_out_t ctx;
   uint32_t s;
+  if (is_pinned_host(dst, bytes)) {            /* page-locked destination: straight DMA */
+    HIPCHK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+  }
   for (s = 0; s < 2; s++) { RCCHK(pin_reserve(&e->h_stage[s], XFER_SLOT_BYTES)); }
   for (k = 0; k <= nslots; k++) {
     if (k < nslots) {

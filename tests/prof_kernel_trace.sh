@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 REPO=$GRAFT_REPO_ROOT
 CFG=${1:-C2}; SECS=${2:-}; OUT=$REPO/gpurun_out/${3:-prof_$CFG}
 mkdir -p $OUT
-ARGS="--config $CFG --steps 5 --warmup 2 --no-cpu-baseline --no-e2e"
+ARGS="--config $CFG --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-other-configs"
 if [ -n "$SECS" ]; then ARGS="$ARGS --seconds $SECS"; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $REPO/bench.py $ARGS > $OUT/bench_under_rocprof.log 2>&1
 find $OUT -name "*kernel_stats*" | head
