@@ -244,6 +244,13 @@ int sla_hip_launch_lattice(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
                            const sla_hip_lattice_chunk* d_chunks, uint32_t num_chunks,
                            const int32_t* d_kint, int32_t* d_residual, sla_hip_stream_t stream);
 
+/* The same lattice, the waves derived on the device from block descriptors (one sla_hip_lpc_group per (block, channel):
+ * pcm_off, num_samples, channel, int_shift, slot_first -> coefficients at d_kint[slot_first * (order + 1)]); max_window =
+ * the longest block.  What the whole-file driver uses: no per-chunk descriptors to build and upload. */
+int sla_hip_launch_lattice_groups(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                                  const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                                  const int32_t* d_kint, int32_t* d_residual, sla_hip_stream_t stream);
+
 /* Autocorrelation of each job's residual, computed exactly as the reference's real-FFT route does
  * (zero-padded to fft_size, forward, |.|^2, inverse).  head == SLA_HIP_ACF_RECORD: per job a 12-double
  * record {code (0 silent, 1 ok, 2 no candidate), chosen pitch lag, acf[0..4], acf[chosen-2..chosen+2]}

@@ -311,7 +311,11 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   if (hipEventCreate(&e->ev_stage[0]) != hipSuccess || hipEventCreate(&e->ev_stage[1]) != hipSuccess
       || hipEventCreate(&e->ev_prep) != hipSuccess) { goto fail; }
   /* every knob is read here, once; sla_hip_encoder_set_option changes them afterwards */
-  e->chunks = 2;
+  /* one chunk: every stage of the pipeline ends in a kernel whose duration is one block's serial chain (LMS, Rice walk),
+   * paid once per chunk; A/B on one box in round 2 -- C2 3.34 / 3.44 / 3.90 ms per step with 1 / 2 / 3 chunks, C3-600 s
+   * 6.71 / 7.21, C5-120 s 12.8 / 13.3 -- after the partition search stopped being the long stage that a second chunk's
+   * host work could hide behind */
+  e->chunks = 1;
   env = getenv("SLA_HIP_CHUNKS");
   if (env != NULL && atoi(env) > 0) { e->chunks = (uint32_t)atoi(env); }
   env = getenv("SLA_HIP_CHUNK_SPLIT");
@@ -1215,14 +1219,7 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
         if (blk->type == SLAI_BLK_SILENT) { continue; }
         for (ch = 0; ch < C; ch++, g++) {
           acf_jobs[g].blk_off = blk->start; acf_jobs[g].blk_len = blk->nsmpl; acf_jobs[g].channel = ch;
-          for (at = 0; !fused && at < blk->nsmpl; at += chunk_samples) {
-            sla_hip_lattice_chunk* lc;
-            if (a->nlc >= a->lchunks_bound) { return SLA_APIRESULT_NG; }
-            lc = &lch[a->nlc++];
-            lc->blk_off = blk->start; lc->blk_len = blk->nsmpl; lc->chunk_start = at;
-            lc->count = (blk->nsmpl - at < chunk_samples) ? (blk->nsmpl - at) : chunk_samples;
-            lc->channel = ch; lc->slot = b * C + ch; lc->int_shift = shift;
-          }
+          (void)at; (void)lch; (void)chunk_samples;      /* the lattice waves are derived from the block groups on the device */
         }
       }
       k->lc_hi = a->nlc;
@@ -1234,7 +1231,7 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     }
     if (!fused) {
       slai_next_launch_span(SPAN_SLOT(e, c, 1));
-      RCCHK(sla_hip_launch_lattice(e->pcm_dev, e->stride, ms, order, dl, nl, (const int32_t*)e->d_kint.ptr, RES1(e), e->stream2));
+      RCCHK(sla_hip_launch_lattice_groups(e->pcm_dev, e->stride, ms, order, dg, ng, max_window, (const int32_t*)e->d_kint.ptr, RES1(e), e->stream2));
     }
     HIPCHK(hipEventRecord(ev[EV_LAT_E], e->stream2));
     if (sizeof(double) * (size_t)fft_size > SLA_HIP_LDS_BUDGET) { slots = (ng < 512) ? ng : 512; }
@@ -2134,7 +2131,11 @@ static int upload_pcm(struct SLAEncoder* e, const int32_t* const* input, uint32_
   if (pinned) {
     /* the caller's planes are page-locked: one DMA per channel at the bus rate, nothing for the host threads to do */
     for (ch = 0; ch < C; ch++) {
-      HIPCHK(hipMemcpyAsync((int32_t*)e->d_pcm.ptr + (size_t)ch * stride, input[ch], sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+      size_t o;
+      for (o = 0; o < n; o += XFER_SLOT_BYTES / 4) {       /* (pieces of the staging slots' size: measured faster than one copy per plane) */
+        const size_t cnt = (n - o < XFER_SLOT_BYTES / 4) ? (n - o) : XFER_SLOT_BYTES / 4;
+        HIPCHK(hipMemcpyAsync((int32_t*)e->d_pcm.ptr + (size_t)ch * stride + o, input[ch] + o, sizeof(int32_t) * cnt, hipMemcpyHostToDevice, e->stream));
+      }
     }
     HIPCHK(hipStreamSynchronize(e->stream));
     e->pcm_dev = (const int32_t*)e->d_pcm.ptr; e->stride = stride; e->num_samples = n;
@@ -2167,7 +2168,9 @@ static int download_bytes(struct SLAEncoder* e, uint8_t* dst, const uint8_t* d_s
   stage_out_t ctx;
   uint32_t s;
   if (is_pinned_host(dst, bytes)) {            /* page-locked destination: straight DMA */
-    HIPCHK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, e->stream));
+    for (o = 0; o < bytes; o += XFER_SLOT_BYTES) {
+      HIPCHK(hipMemcpyAsync(dst + o, d_src + o, (bytes - o < XFER_SLOT_BYTES) ? (bytes - o) : XFER_SLOT_BYTES, hipMemcpyDeviceToHost, e->stream));
+    }
     HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
   }

@@ -1325,6 +1325,29 @@ void k_lattice(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, ui
   span_end(span);
 }
 
+// The same lattice waves, derived from the block descriptors themselves: wave = (group, chunk index), `cpg` waves reserved
+// per group (enough for the longest block), the ones past a block's end return at once.  Saves the host a descriptor per
+// ~900 samples (4.5 MB for ten minutes of stereo: building and uploading them took longer than k_lpc_blocks runs).
+__global__ __launch_bounds__(256)
+void k_lattice_groups(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
+                      const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, uint32_t cpg,
+                      const int32_t* __restrict__ kint, int32_t* __restrict__ residual, unsigned long long* span)
+{
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t gi = w / cpg, c = w - gi * cpg;
+  if (gi >= num_groups) { return; }
+  span_begin(span);
+  const sla_hip_lpc_group g = groups[gi];
+  const uint32_t per = (SLA_WAVE - (order + LAT_T - 1) / LAT_T) * LAT_T;
+  const uint32_t at = c * per;
+  if (at < g.num_samples) {
+    lattice_chunk_wave(pcm, stride, ms, order, g.pcm_off, g.num_samples, at, (g.num_samples - at < per) ? (g.num_samples - at) : per,
+                       g.channel, g.int_shift, kint + (uint64_t)g.slot_first * (order + 1), residual, lane, false);
+  }
+  span_end(span);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Pre-emphasis as its own pass (per-call SLAEmphasisFilter API; the pipeline fuses it into k_lpc_blocks / k_lattice):
 // y[n] = x[n] - ((x[n-1] * (2^s - 1)) >> s) with x[-1] = prev      src/SLAPredictor.c:1741-1765, 1794-1813
@@ -2032,6 +2055,22 @@ extern "C" int sla_hip_launch_lattice(const int32_t* d_pcm, uint64_t plane_strid
   if (num_chunks == 0) { return 0; }
   hipLaunchKernelGGL(k_lattice, dim3((num_chunks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_pcm, plane_stride,
                      mid_side, order, d_chunks, num_chunks, d_kint, d_residual, take_span(), 0u);
+  return hip_rc(hipGetLastError());
+}
+
+extern "C" int sla_hip_launch_lattice_groups(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                                             const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                                             const int32_t* d_kint, int32_t* d_residual, sla_hip_stream_t stream)
+{
+  if (d_pcm == nullptr || d_groups == nullptr || d_kint == nullptr || d_residual == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (order < 1 || order > 255 || (order + LAT_T - 1) / LAT_T >= 32 || max_window == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (num_groups == 0) { return 0; }
+  const uint32_t per = (SLA_WAVE - (order + LAT_T - 1) / LAT_T) * LAT_T;
+  const uint32_t cpg = (max_window + per - 1) / per;
+  const uint64_t waves = (uint64_t)num_groups * cpg;
+  if (waves > 0x7FFFFFFFull) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
+  hipLaunchKernelGGL(k_lattice_groups, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_pcm, plane_stride,
+                     mid_side, order, d_groups, num_groups, cpg, d_kint, d_residual, take_span());
   return hip_rc(hipGetLastError());
 }
 
