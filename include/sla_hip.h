@@ -264,6 +264,14 @@ int sla_hip_launch_ltm_acf(const int32_t* d_residual, uint64_t plane_stride,
                            const double* d_twiddles, double* d_scratch, uint32_t scratch_slots,
                            double* d_acf_head, uint32_t head, sla_hip_stream_t stream);
 
+/* Long-term pitch and taps on the device: one lane per job solves the Wiener system around the lag k_ltm_acf chose
+ * (d_acf_records: num_jobs compact records, head SLA_HIP_ACF_RECORD) and writes the job k_tail reads -- position and
+ * channel from d_groups[job], pitch (0: stage bypassed) and the quantised taps (src/SLAPredictor.c:855-863, 913-979;
+ * src/SLAUtility.c:487-674; src/SLAEncoder.c:629-640).  The reference's long double refinement residual is computed
+ * in integer arithmetic with a 64-bit significand, so the taps are the reference's bit for bit.  longterm_order: 1, 3, 5. */
+int sla_hip_launch_ltm_solve(const double* d_acf_records, const sla_hip_lpc_group* d_groups, uint32_t num_jobs,
+                             uint32_t longterm_order, sla_hip_tail_job* d_jobs, sla_hip_stream_t stream);
+
 /* Long-term filter + sign-log LMS + folded-residual sum, one lane per job.
  * d_res_in/d_res_out are channel planes with the same stride as the PCM. */
 int sla_hip_launch_tail(const int32_t* d_res_in, int32_t* d_res_out, uint64_t plane_stride,

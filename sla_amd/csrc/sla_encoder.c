@@ -57,7 +57,7 @@ struct SLAEncoder {
   hipStream_t stream, stream2, stream3;
   int own_copy_streams;
   hipStream_t stream_up, stream_down;            /* descriptor uploads / result downloads: kept off the kernel streams */
-  hipEvent_t  ev[2 + 8 * 16];       /* prepass pair + MAX_CHUNKS x EV_PER_CHUNK */
+  hipEvent_t  ev[2 + 8 * 20];       /* prepass pair + MAX_CHUNKS x EV_PER_CHUNK (checked below) */
   uint32_t chunks;
   uint32_t split[8], split_count, chunk_cut[9];   /* relative chunk sizes (SLA_HIP_CHUNK_SPLIT="1,3,1"), boundaries of this run */
   int      fuse_lattice;            /* 1: the lattice runs inside k_lpc_blocks (SLA_HIP_LATTICE=fused), 0: separate k_lattice launch */
@@ -66,6 +66,10 @@ struct SLAEncoder {
   int      exact_bits;              /* log2 of the energy limit in units^2 (53; lowered by tests to force the fallback) */
   double   cert_safety;             /* windows over the limit: safety factor of the partition certificate (64); 0: always rerun them as serial chains */
   int      plan_copy_down;          /* 1: plan results travel on the download stream (debugging; default: search stream) */
+  int      chunks_forced;           /* the caller chose the chunk count: no short-file rule */
+  uint32_t first_chunk;             /* 1/1000 of the super-frames in chunk 0 (0: built-in shares) */
+  int      single_tail;             /* 1: one k_tail launch for all chunks (default) */
+  int      device_ltm;              /* 1: pitch + taps solved on the device, the block stage runs lattice -> tail without the host (default) */
   int      trace;                   /* host-side timeline on stderr (SLA_HIP_TRACE) */
   sla_hip_tuning tune;              /* launcher knobs, named to the launchers at every API entry */
   uint32_t host_planned;            /* last analysis: super-frames whose partition the host had to decide */
@@ -315,9 +319,15 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
    * paid once per chunk; A/B on one box in round 2 -- C2 3.34 / 3.44 / 3.90 ms per step with 1 / 2 / 3 chunks, C3-600 s
    * 6.71 / 7.21, C5-120 s 12.8 / 13.3 -- after the partition search stopped being the long stage that a second chunk's
    * host work could hide behind */
-  e->chunks = 1;
+  e->chunks = 2;
+  e->single_tail = 1;
+  e->device_ltm = 1;
+  env = getenv("SLA_HIP_LTM");
+  if (env != NULL) { e->device_ltm = (strcmp(env, "host") != 0); }
+  env = getenv("SLA_HIP_SINGLE_TAIL");
+  if (env != NULL) { e->single_tail = (atoi(env) != 0); }
   env = getenv("SLA_HIP_CHUNKS");
-  if (env != NULL && atoi(env) > 0) { e->chunks = (uint32_t)atoi(env); }
+  if (env != NULL && atoi(env) > 0) { e->chunks = (uint32_t)atoi(env); e->chunks_forced = 1; }
   env = getenv("SLA_HIP_CHUNK_SPLIT");
   if (env != NULL) {
     const char* q = env;
@@ -522,7 +532,8 @@ static int blocks_push(struct SLAEncoder* e, uint32_t start, uint32_t nsmpl, uin
 
 #define MAX_CHUNKS 8
 enum { EV_SEARCH_S, EV_SEARCH_E, EV_SEARCH_DONE, EV_LPCB_S, EV_LPCB_E, EV_LAT_E, EV_ACF_S, EV_ACF_E, EV_BLOCK_DONE,
-       EV_TAIL_S, EV_TAIL_E, EV_TAIL_DONE, EV_UPLOADED, EV_PLANNED, EV_UPLOADED2, EV_LPC_DOWN, EV_PER_CHUNK };
+       EV_TAIL_S, EV_TAIL_E, EV_TAIL_DONE, EV_UPLOADED, EV_PLANNED, EV_UPLOADED2, EV_LPC_DOWN, EV_SOLVED, EV_PER_CHUNK };
+typedef char ev_array_holds_every_chunk[(2 + MAX_CHUNKS * EV_PER_CHUNK <= 2 + 8 * 20) ? 1 : -1];
 
 typedef struct { uint32_t start, window, min_blk, shape, slot_base, grp_lo, grp_hi, xg; } sframe_t;
 typedef struct { uint32_t window, min_blk, nodes, ncand, cand_first; uint32_t pair[SLAI_MAX_NODES * SLAI_MAX_NODES]; } shape_t;
@@ -544,7 +555,7 @@ typedef struct {
   uint32_t ncands, nsgroups, nslots, max_window, max_cpg, nxg, max_xcands;
   int exact;                                      /* this run searches with tile sums            */
   uint32_t blocks_bound, lchunks_bound;
-  uint32_t nbg, nlc, njobs;                       /* running counters of the block stage */
+  uint32_t nbg, nlc, njobs, ltm_done;                      /* running counters of the block stage */
   uint32_t *job_blk, *job_ch, *job_grp, *grp_of_slot;
   uint32_t *parts, *nparts; int* status;          /* per super-frame plan results        */
   chunk_t ck[MAX_CHUNKS]; uint32_t nchunks;
@@ -1134,6 +1145,37 @@ static int plan_chunk(struct SLAEncoder* e, actx_t* a, uint32_t c)
   return 0;
 }
 
+
+/* device long-term mode: k_tail over the jobs [lo, hi) (job == block group) right behind k_ltm_solve on the kernel
+ * stream; folded sums and the solved pitch/taps go home on the download stream */
+static int tail_enqueue(struct SLAEncoder* e, actx_t* a, uint32_t c, uint32_t lo, uint32_t hi)
+{
+  const uint32_t ntaps = e->encode_param.longterm_order, lms = e->encode_param.lms_order_per_filter;
+  hipEvent_t* ev = a->ev + (size_t)c * EV_PER_CHUNK;
+  /* one tail per chunk: on its own stream, so that the serial LMS chains (few waves, latency-bound) run beside the next
+   * chunk's throughput-bound kernels; one tail for the file: behind the last solve on the kernel stream */
+  hipStream_t ts = e->single_tail ? e->stream2 : e->stream3;
+  if (!e->single_tail) {
+    HIPCHK(hipEventRecord(ev[EV_SOLVED], e->stream2));
+    HIPCHK(hipStreamWaitEvent(ts, ev[EV_SOLVED], 0));
+  }
+  HIPCHK(hipEventRecord(ev[EV_TAIL_S], ts));
+  if (hi > lo) {
+    sla_hip_tail_job* dj = (sla_hip_tail_job*)e->d_jobs.ptr + lo;
+    slai_next_launch_span(SPAN_SLOT(e, c, 3));
+    RCCHK(sla_hip_launch_tail(RES1(e), RES2(e), e->stride, dj, hi - lo, ntaps, lms, (uint64_t*)e->d_fold.ptr + lo, ts));
+  }
+  HIPCHK(hipEventRecord(ev[EV_TAIL_E], ts));
+  if (hi > lo) {
+    HIPCHK(hipStreamWaitEvent(e->stream_down, ev[EV_TAIL_E], 0));
+    HIPCHK(hipMemcpyAsync((uint64_t*)e->h_fold.ptr + lo, (uint64_t*)e->d_fold.ptr + lo, sizeof(uint64_t) * (hi - lo), hipMemcpyDeviceToHost, e->stream_down));
+    HIPCHK(hipMemcpyAsync((sla_hip_tail_job*)e->h_jobs.ptr + lo, (sla_hip_tail_job*)e->d_jobs.ptr + lo, sizeof(sla_hip_tail_job) * (hi - lo),
+                          hipMemcpyDeviceToHost, e->stream_down));
+  }
+  HIPCHK(hipEventRecord(ev[EV_TAIL_DONE], e->stream_down));
+  return 0;
+}
+
 /* stage 2 of chunk c: windowed LPC + quantiser, lattice, long-term FFT for blocks [blk_lo, blk_hi) */
 static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
 {
@@ -1171,11 +1213,13 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
       gr->cand_first = g; gr->cand_count = 1; gr->slot_first = b * C + ch; gr->pad_ = 0;
       cands[g].start = 0; cands[g].len = blk->nsmpl;
       a->grp_of_slot[(size_t)b * C + ch] = g;
+      if (e->device_ltm) { a->job_blk[g] = b; a->job_ch[g] = ch; a->job_grp[g] = g; }      /* tail job g == group g */
     }
     if (blk->nsmpl > max_window) { max_window = blk->nsmpl; }
   }
   k->bg_hi = a->nbg;
   ng = k->bg_hi - k->bg_lo;
+  if (e->device_ltm) { k->job_lo = k->bg_lo; k->job_hi = k->bg_hi; a->njobs = a->nbg; }
 
   if (ng == 0) { k->lc_hi = a->nlc; HIPCHK(hipEventRecord(ev[EV_LPCB_S], e->stream2)); }
   if (ng > 0) {
@@ -1241,15 +1285,23 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
                                  (double*)e->d_acf_scratch.ptr, slots,
                                  (double*)e->d_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD, SLAI_LTM_ACF_HEAD, e->stream2));
     HIPCHK(hipEventRecord(ev[EV_ACF_E], e->stream2));
-    HIPCHK(hipStreamWaitEvent(e->stream_down, ev[EV_ACF_E], 0));
-    HIPCHK(hipMemcpyAsync((double*)e->h_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD, (double*)e->d_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD,
-                          sizeof(double) * (size_t)ng * SLAI_LTM_ACF_HEAD, hipMemcpyDeviceToHost, e->stream_down));
+    if (e->device_ltm) {
+      /* pitch + taps into the job table k_tail reads; the tail follows on the same stream, no host in between */
+      RCCHK(sla_hip_launch_ltm_solve((const double*)e->d_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD, dg, ng,
+                                     e->encode_param.longterm_order, (sla_hip_tail_job*)e->d_jobs.ptr + k->bg_lo, e->stream2));
+      if (!e->single_tail) { RCCHK(tail_enqueue(e, a, c, k->bg_lo, k->bg_hi)); }
+    } else {
+      HIPCHK(hipStreamWaitEvent(e->stream_down, ev[EV_ACF_E], 0));
+      HIPCHK(hipMemcpyAsync((double*)e->h_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD, (double*)e->d_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD,
+                            sizeof(double) * (size_t)ng * SLAI_LTM_ACF_HEAD, hipMemcpyDeviceToHost, e->stream_down));
+    }
   } else {
     HIPCHK(hipEventRecord(ev[EV_LPCB_E], e->stream2));
     HIPCHK(hipEventRecord(ev[EV_LPC_DOWN], e->stream_down));
     HIPCHK(hipEventRecord(ev[EV_LAT_E], e->stream2));
     HIPCHK(hipEventRecord(ev[EV_ACF_S], e->stream2));
     HIPCHK(hipEventRecord(ev[EV_ACF_E], e->stream2));
+    if (e->device_ltm && !e->single_tail) { RCCHK(tail_enqueue(e, a, c, k->bg_lo, k->bg_lo)); }
   }
   HIPCHK(hipStreamWaitEvent(e->stream_down, ev[EV_ACF_E], 0));
   HIPCHK(hipEventRecord(ev[EV_BLOCK_DONE], e->stream_down));
@@ -1289,7 +1341,7 @@ static int raw_phase(struct SLAEncoder* e, actx_t* a, uint32_t c)
   chunk_t* k = &a->ck[c];
   const uint32_t C = e->wave_format.num_channels;
   uint32_t b, ch;
-  k->job_lo = a->njobs;
+  if (!e->device_ltm) { k->job_lo = a->njobs; }
   /* RAW decision per block (any channel's estimate >= 0.95, src/SLAEncoder.c:553-565) on the host threads */
   {
     raw_ctx_t rc;
@@ -1298,6 +1350,7 @@ static int raw_phase(struct SLAEncoder* e, actx_t* a, uint32_t c)
     parallel_for(e->pool, k->blk_hi - k->blk_lo, raw_one, &rc);
     PTRACE("tail: RAW decision");
   }
+  if (e->device_ltm) { k->job_lo = k->bg_lo; k->job_hi = k->bg_hi; return 0; }      /* the tail ran (or runs) over every group */
   for (b = k->blk_lo; b < k->blk_hi; b++) {
     if (e->blk[b].type != SLAI_BLK_COMPRESS) { continue; }
     for (ch = 0; ch < C; ch++) {
@@ -1310,6 +1363,17 @@ static int raw_phase(struct SLAEncoder* e, actx_t* a, uint32_t c)
 }
 
 /* host part 2 + stage 3 of chunk c: long-term solve from the FFT records, then k_tail */
+/* long-term pitch + taps of the jobs [a->ltm_done, upto) from their downloaded autocorrelations (host pool) */
+static void ltm_solve(struct SLAEncoder* e, actx_t* a, uint32_t upto)
+{
+  ltm_ctx_t lc;
+  if (upto <= a->ltm_done) { return; }
+  lc.e = e; lc.acf = (const double*)e->h_acf.ptr; lc.job_blk = a->job_blk; lc.job_ch = a->job_ch; lc.job_grp = a->job_grp;
+  lc.job_lo = a->ltm_done;
+  parallel_for(e->pool, upto - a->ltm_done, ltm_one, &lc);
+  a->ltm_done = upto;
+}
+
 static int tail_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
 {
   chunk_t* k = &a->ck[c];
@@ -1319,13 +1383,8 @@ static int tail_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
   hipEvent_t* ev = a->ev + (size_t)c * EV_PER_CHUNK;
   uint32_t j, t, nj;
   nj = k->job_hi - k->job_lo;
-  {
-    ltm_ctx_t lc;
-    lc.e = e; lc.acf = (const double*)e->h_acf.ptr; lc.job_blk = a->job_blk; lc.job_ch = a->job_ch; lc.job_grp = a->job_grp;
-    lc.job_lo = k->job_lo;
-    parallel_for(e->pool, nj, ltm_one, &lc);
-    PTRACE("tail: long-term solve");
-  }
+  ltm_solve(e, a, k->job_hi);
+  PTRACE("tail: long-term solve");
   HIPCHK(hipEventRecord(ev[EV_TAIL_S], e->stream3));
   if (nj > 0) {
     sla_hip_tail_job* dj = (sla_hip_tail_job*)e->d_jobs.ptr + k->job_lo;
@@ -1357,6 +1416,16 @@ static void finish_rice(struct SLAEncoder* e, const actx_t* a)
   const uint64_t* fold = (const uint64_t*)e->h_fold.ptr;
   uint32_t j;
   for (j = 0; j < a->njobs; j++) {
+    if (e->device_ltm) {
+      /* the jobs cover every non-silent block; what the device solved for a block that turned out RAW is dropped */
+      const sla_hip_tail_job* jb = (const sla_hip_tail_job*)e->h_jobs.ptr + j;
+      blkch_t* bc = &e->bc[(size_t)a->job_blk[j] * C + a->job_ch[j]];
+      uint32_t t;
+      if (e->blk[a->job_blk[j]].type != SLAI_BLK_COMPRESS) { continue; }
+      bc->pitch = jb->pitch;
+      for (t = 0; t < SLAI_MAX_TAPS; t++) { bc->ltm_q[t] = jb->ltm_coef[t]; }
+    }
+    {
     /* mean of the folded residual, at least 1                 src/SLACoder.c:371-384 */
     const uint64_t mean = fold[j] / e->blk[a->job_blk[j]].nsmpl;
     const uint32_t init = (uint32_t)(mean > 1 ? mean : 1);
@@ -1364,6 +1433,7 @@ static void finish_rice(struct SLAEncoder* e, const actx_t* a)
      * store the value that survives that round trip, which is also what is transmitted */
     const uint32_t kept = (uint32_t)((((uint64_t)(uint32_t)(init << 8)) + 128u) >> 8);
     e->bc[(size_t)a->job_blk[j] * C + a->job_ch[j]].rice_init = kept ? kept : 1u;
+    }
   }
 }
 
@@ -1424,17 +1494,23 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   want_chunks = e->chunks;
   /* chunks pay off once the kernels are throughput-bound; a short file (a 10-second clip: 118 super-frames) is one
    * block's serial LMS / Rice chain per stage however it is cut, and every extra chunk adds one more of those */
-  if (preset_blocks || a.nsf < 1024) { want_chunks = 1; }
+  if (preset_blocks || (a.nsf < 1024 && !e->chunks_forced)) { want_chunks = 1; }
   if (want_chunks > a.nsf / 32 + 1) { want_chunks = a.nsf / 32 + 1; }
   if (want_chunks > MAX_CHUNKS) { want_chunks = MAX_CHUNKS; }
   if (want_chunks < 1) { want_chunks = 1; }
   a.nchunks = want_chunks;
   /* chunk boundaries in 1/1000 of the super-frames: equal parts unless SLA_HIP_CHUNK_SPLIT gave the shares */
-  if (e->split_count != a.nchunks && a.nchunks == 2) {
-    /* measured on C2..C5 (one hardware queue per stream): two chunks, 40 % / 60 %.  The shorter first chunk fills the
-     * pipeline sooner (the host plans it while nothing else can run); every further chunk costs one more k_tail --
-     * latency-bound, the same 0.35 ms for any chunk up to 1024 waves -- and one more round of cross-stream hand-overs */
-    e->chunk_cut[0] = 0; e->chunk_cut[1] = 400; e->chunk_cut[2] = 1000;
+  if (e->first_chunk != 0 && a.nchunks >= 2) {
+    /* option first_chunk: that many 1/1000 of the super-frames in chunk 0, the others share the rest equally */
+    e->chunk_cut[0] = 0;
+    for (c = 1; c <= a.nchunks; c++) { e->chunk_cut[c] = e->first_chunk + (1000u - e->first_chunk) * (c - 1) / (a.nchunks - 1); }
+  } else if (e->split_count != a.nchunks && a.nchunks == 2) {
+    /* measured on C2, C3-600 s, C5-120 s (tests/tools/chunk_sweep.py, medians of interleaved rounds): two chunks, the
+     * first one short -- the host plans it while nothing else can run, and plans the second under the first one's
+     * kernels.  With one k_tail for the file (device long-term solve) 25 % / 75 % is best: 2.32 / 5.94 / 11.97 ms
+     * against 2.46 / 6.23 / 12.24 ms in one chunk; a third chunk only adds launches.  With a k_tail per chunk
+     * (host solve) every chunk costs one more serial LMS chain, and 40 % / 60 % was the best cut. */
+    e->chunk_cut[0] = 0; e->chunk_cut[1] = (e->device_ltm && e->single_tail) ? 250 : 400; e->chunk_cut[2] = 1000;
   } else if (e->split_count != a.nchunks && a.nchunks == 3) {
     e->chunk_cut[0] = 0; e->chunk_cut[1] = 250; e->chunk_cut[2] = 625; e->chunk_cut[3] = 1000;
   } else if (e->split_count != a.nchunks) {
@@ -1485,19 +1561,37 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
       hipEvent_t* pv = a.ev + (size_t)(c - 1) * EV_PER_CHUNK;
       if (hipEventSynchronize(pv[EV_LPC_DOWN]) != hipSuccess) { rc = SLA_APIRESULT_NG; break; }
       if ((rc = raw_phase(e, &a, c - 1)) != 0) { break; }
+      if (e->device_ltm) { continue; }
       if (hipEventSynchronize(pv[EV_BLOCK_DONE]) != hipSuccess) { rc = SLA_APIRESULT_NG; break; }
       TRACE("blocks done", c - 1);
-      t0 = now_ms();
-      rc = tail_launch(e, &a, c - 1);
-      e->timing[6] += (float)(now_ms() - t0);
-      TRACE("tail launched", c - 1);
+      if (e->single_tail) {
+        t0 = now_ms();
+        ltm_solve(e, &a, a.ck[c - 1].job_hi);      /* under the kernels of chunk c */
+        e->timing[6] += (float)(now_ms() - t0);
+      } else {
+        t0 = now_ms();
+        rc = tail_launch(e, &a, c - 1);
+        e->timing[6] += (float)(now_ms() - t0);
+        TRACE("tail launched", c - 1);
+      }
     }
   }
-  if (rc == 0) {
+  if (rc == 0 && e->device_ltm) {
+    /* everything is queued: one k_tail over all groups (unless every chunk queued its own), then the RAW decision of
+     * the last chunk on the host threads while the device works */
+    hipEvent_t* pv = a.ev + (size_t)(a.nchunks - 1) * EV_PER_CHUNK;
+    if (e->single_tail) { rc = tail_enqueue(e, &a, a.nchunks - 1, 0, a.nbg); TRACE("tail queued", a.nchunks - 1); }
+    if (rc == 0 && hipEventSynchronize(pv[EV_LPC_DOWN]) != hipSuccess) { rc = SLA_APIRESULT_NG; }
+    if (rc == 0) { rc = raw_phase(e, &a, a.nchunks - 1); }
+    TRACE("RAW decided", a.nchunks - 1);
+  } else if (rc == 0) {
     hipEvent_t* pv = a.ev + (size_t)(a.nchunks - 1) * EV_PER_CHUNK;
     if (hipEventSynchronize(pv[EV_LPC_DOWN]) != hipSuccess || (rc = raw_phase(e, &a, a.nchunks - 1)) != 0
         || hipEventSynchronize(pv[EV_BLOCK_DONE]) != hipSuccess) { if (rc == 0) { rc = SLA_APIRESULT_NG; } }
     else {
+      /* one k_tail for the whole file: its duration is one block's serial LMS chain however many blocks run beside it, so
+       * the chunks share it (the BLOCK_DONE events sit in order on the download stream: the last one covers them all) */
+      if (e->single_tail) { a.ck[a.nchunks - 1].job_lo = a.ck[0].job_lo; }
       TRACE("blocks done", a.nchunks - 1);
       t0 = now_ms();
       rc = tail_launch(e, &a, a.nchunks - 1);
@@ -1511,8 +1605,9 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
     unsigned long long* sp_host = (unsigned long long*)((uint8_t*)e->h_or + 64);
     int copied = 0;
     if (rc == 0) {
-      copied = (hipMemcpyAsync(sp_host, e->d_spans.ptr, sizeof(unsigned long long) * MAX_CHUNKS * 4 * 2, hipMemcpyDeviceToHost, e->stream3) == hipSuccess);
-      if (!preset_blocks && hipMemcpyAsync(e->h_or + 2, (uint32_t*)e->d_or.ptr + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream3) != hipSuccess) { rc = SLA_APIRESULT_NG; }
+      hipStream_t last = (e->device_ltm && e->single_tail) ? e->stream2 : e->stream3;      /* the stream the last k_tail runs on */
+      copied = (hipMemcpyAsync(sp_host, e->d_spans.ptr, sizeof(unsigned long long) * MAX_CHUNKS * 4 * 2, hipMemcpyDeviceToHost, last) == hipSuccess);
+      if (!preset_blocks && hipMemcpyAsync(e->h_or + 2, (uint32_t*)e->d_or.ptr + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, last) != hipSuccess) { rc = SLA_APIRESULT_NG; }
     }
   if (hipStreamSynchronize(e->stream) != hipSuccess || hipStreamSynchronize(e->stream2) != hipSuccess
       || hipStreamSynchronize(e->stream_up) != hipSuccess || hipStreamSynchronize(e->stream_down) != hipSuccess
@@ -1549,7 +1644,7 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
       e->timing[2] += ev_ms(ev[EV_LPCB_S], ev[EV_LPCB_E]);
       e->timing[3] += ev_ms(ev[EV_LPCB_E], ev[EV_LAT_E]);
       e->timing[8] += ev_ms(ev[EV_ACF_S], ev[EV_ACF_E]);
-      e->timing[4] += ev_ms(ev[EV_TAIL_S], ev[EV_TAIL_E]);
+      if (!e->single_tail || c == a.nchunks - 1) { e->timing[4] += ev_ms(ev[EV_TAIL_S], ev[EV_TAIL_E]); }
     }
     e->timing[9] = (float)a.nchunks;
     e->timing[10] = (float)e->fallback_groups;
@@ -1580,11 +1675,14 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   else if (strcmp(name, "tail_waves") == 0)        { OPT_RANGE(0, 4); e->tune.tail_waves = (uint32_t)iv; }
   else if (strcmp(name, "lpc_blocks_chains") == 0) { OPT_RANGE(0, 1); e->tune.lpc_blocks_chains = (uint32_t)iv; if (iv) { e->fuse_lattice = 0; } }
   else if (strcmp(name, "plan_margin") == 0)       { if (value < 0.0) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.plan_margin = value; }
-  else if (strcmp(name, "chunks") == 0)            { OPT_RANGE(1, 8); e->chunks = (uint32_t)iv; e->split_count = 0; }
+  else if (strcmp(name, "chunks") == 0)            { OPT_RANGE(1, 8); e->chunks = (uint32_t)iv; e->split_count = 0; e->chunks_forced = 1; }
   else if (strcmp(name, "search_exact") == 0)      { OPT_RANGE(0, 1); e->search_exact = (int)iv; }
   else if (strcmp(name, "exact_bits") == 0)        { OPT_RANGE(1, 53); e->exact_bits = (int)iv; }
   else if (strcmp(name, "cert_safety") == 0)       { if (value < 0.0 || value > 1e30) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->cert_safety = value; }
   else if (strcmp(name, "device_plan") == 0)       { OPT_RANGE(0, 1); e->device_plan = (int)iv; }
+  else if (strcmp(name, "single_tail") == 0)       { OPT_RANGE(0, 1); e->single_tail = (int)iv; }
+  else if (strcmp(name, "first_chunk") == 0)       { OPT_RANGE(0, 999); e->first_chunk = (uint32_t)iv; }
+  else if (strcmp(name, "device_ltm") == 0)        { OPT_RANGE(0, 1); e->device_ltm = (int)iv; }
   else if (strcmp(name, "fuse_lattice") == 0)      { OPT_RANGE(0, 1); e->fuse_lattice = (int)iv && !e->tune.lpc_blocks_chains; }
   else if (strcmp(name, "threads") == 0) {
     OPT_RANGE(1, 64);

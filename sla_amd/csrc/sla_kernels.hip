@@ -1761,6 +1761,202 @@ void k_ltm_acf(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_a
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_ltm_solve: pitch and taps of every (block, channel) from k_ltm_acf's compact record, written straight into the
+// job table k_tail reads -- the long-term stage never leaves the device (src/SLAPredictor.c:855-863, 913-979;
+// the 5x5 LU solve with two refinement passes is src/SLAUtility.c:487-674; the tap quantiser src/SLAEncoder.c:629-640).
+// One lane per job.  The reference accumulates the refinement residual in x87 long double: ext80 below is that
+// arithmetic in integers (64-bit significand, round to nearest even), so the result is the reference's bit for bit.
+// ---------------------------------------------------------------------------------------------
+struct ext80 { uint64_t m; int32_t e; uint32_t neg; };      // (-1)^neg * m * 2^e, bit 63 of m set (m == 0: zero)
+
+__device__ __forceinline__ ext80 ext_from_double(double d)
+{
+  ext80 r; r.m = 0; r.e = 0; r.neg = 0;
+  const uint64_t bits = (uint64_t)__double_as_longlong(d);
+  const uint32_t be = (uint32_t)(bits >> 52) & 0x7FFu;
+  uint64_t frac = bits & 0xFFFFFFFFFFFFFull;
+  r.neg = (uint32_t)(bits >> 63);
+  if (be == 0) {
+    if (frac == 0) { return r; }
+    const int lz = __clzll((long long)frac);
+    r.m = frac << lz; r.e = -1074 - lz;
+    return r;
+  }
+  r.m = (frac | (1ull << 52)) << 11;
+  r.e = (int32_t)be - 1075 - 11;
+  return r;
+}
+
+// a + b rounded to a 64-bit significand (FADD with the x87 precision control at its default, extended)
+__device__ __forceinline__ ext80 ext_add(ext80 a, ext80 b)
+{
+  if (b.m == 0) { return a; }
+  if (a.m == 0) { return b; }
+  if (b.e > a.e || (b.e == a.e && b.m > a.m)) { const ext80 t = a; a = b; b = t; }      // |a| >= |b|
+  const uint32_t shift = (uint32_t)(a.e - b.e);
+  const unsigned __int128 A = (unsigned __int128)a.m << 63;                                 // value = A * 2^(a.e - 63)
+  unsigned __int128 B = 0;
+  bool sticky = false;
+  if (shift < 128) {
+    const unsigned __int128 full = (unsigned __int128)b.m << 63;
+    B = full >> shift;
+    sticky = ((B << shift) != full);
+  } else {
+    sticky = true;
+  }
+  unsigned __int128 S;
+  if (a.neg == b.neg) { S = A + B; } else { S = A - B - (sticky ? 1u : 0u); }            // true value = S + (0, 1) when sticky
+  ext80 r; r.neg = a.neg; r.m = 0; r.e = 0;
+  if (S == 0 && !sticky) { r.neg = 0; return r; }
+  const uint64_t hi0 = (uint64_t)(S >> 64), lo0 = (uint64_t)S;
+  const int lz = hi0 ? __clzll((long long)hi0) : 64 + __clzll((long long)lo0);
+  S <<= lz;
+  uint64_t m = (uint64_t)(S >> 64);
+  const uint64_t low = (uint64_t)S;
+  int32_t ex = a.e - 63 - lz + 64;
+  const uint64_t half = 1ull << 63;
+  const bool up = (low > half) || (low == half && (sticky || (m & 1ull)));
+  if (up) { m += 1; if (m == 0) { m = half; ex += 1; } }
+  r.m = m; r.e = ex;
+  return r;
+}
+
+// (double)x: round the 64-bit significand to 53 bits, nearest even
+__device__ __forceinline__ double ext_to_double(ext80 x)
+{
+  if (x.m == 0) { return x.neg ? -0.0 : 0.0; }
+  uint64_t m53 = x.m >> 11;
+  const uint64_t rem = x.m & 0x7FFull;
+  if (rem > 0x400ull || (rem == 0x400ull && (m53 & 1ull))) { m53 += 1; }
+  const double v = ldexp((double)m53, x.e + 11);           // m53 <= 2^53: exact
+  return x.neg ? -v : v;
+}
+
+#define LTM_NT 5
+
+__device__ int ltm_lu_factor(double (*A)[LTM_NT], uint32_t dim, uint32_t* perm, double* scale)
+{
+  uint32_t row, col, k, imax;
+  double big, sum;
+  for (row = 0; row < dim; row++) {
+    big = 0.0;
+    for (col = 0; col < dim; col++) { if (fabs(A[row][col]) > big) { big = fabs(A[row][col]); } }
+    if (fabs(big) <= (double)FLT_EPSILON) { return -1; }
+    scale[row] = 1.0 / big;
+  }
+  for (col = 0; col < dim; col++) {
+    for (row = 0; row < col; row++) {
+      sum = A[row][col];
+      for (k = 0; k < row; k++) { sum -= A[row][k] * A[k][col]; }
+      A[row][col] = sum;
+    }
+    big = 0.0;
+    imax = row;
+    for (row = col; row < dim; row++) {
+      sum = A[row][col];
+      for (k = 0; k < col; k++) { sum -= A[row][k] * A[k][col]; }
+      A[row][col] = sum;
+      if ((scale[row] * fabs(sum)) >= big) { big = scale[row] * fabs(sum); imax = row; }
+    }
+    if (col != imax) {
+      for (k = 0; k < dim; k++) { const double t = A[imax][k]; A[imax][k] = A[col][k]; A[col][k] = t; }
+      scale[imax] = scale[col];
+    }
+    perm[col] = imax;
+    if (fabs(A[col][col]) <= (double)FLT_EPSILON) { return -1; }
+    if (col != dim - 1) {
+      const double inv = 1.0 / A[col][col];
+      for (row = col + 1; row < dim; row++) { A[row][col] *= inv; }
+    }
+  }
+  return 0;
+}
+
+__device__ void ltm_lu_substitute(double (*A)[LTM_NT], double* b, uint32_t dim, const uint32_t* perm)
+{
+  uint32_t row, col, first_nz = 0;
+  double sum;
+  for (row = 0; row < dim; row++) {
+    const uint32_t pv = perm[row];
+    sum = b[pv];
+    b[pv] = b[row];
+    if (first_nz != 0) {
+      for (col = first_nz; col < row; col++) { sum -= A[row][col] * b[col]; }
+    } else if (sum != 0.0) {
+      first_nz = row;
+    }
+    b[row] = sum;
+  }
+  for (row = dim; row-- > 0;) {
+    sum = b[row];
+    for (col = row + 1; col < dim; col++) { sum -= A[row][col] * b[col]; }
+    b[row] = sum / A[row][row];
+  }
+}
+
+__global__ __launch_bounds__(64)
+void k_ltm_solve(const double* __restrict__ acf, const sla_hip_lpc_group* __restrict__ groups, uint32_t num_jobs,
+                 uint32_t ntaps, sla_hip_tail_job* __restrict__ jobs)
+{
+  const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= num_jobs) { return; }
+  const double* rec = acf + (uint64_t)j * SLA_HIP_ACF_RECORD;
+  const double* low = rec + 2;
+  const double* mid = rec + 7;
+  const uint32_t chosen = (uint32_t)rec[1];
+  double vec[LTM_NT] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  uint32_t pitch = 0;
+  int ret = 0;
+  if (rec[0] == 0.0) {
+    ret = 0;                                               // silent residual: no pitch, zero taps
+  } else if (rec[0] != 1.0 || chosen < ntaps / 2 + 1) {
+    ret = 4;
+  } else {
+    double R[LTM_NT][LTM_NT], A[LTM_NT][LTM_NT], x[LTM_NT], err[LTM_NT], scale[LTM_NT], b[LTM_NT];
+    uint32_t perm[LTM_NT];
+    for (uint32_t r = 0; r < LTM_NT; r++) { for (uint32_t c = 0; c < LTM_NT; c++) { R[r][c] = 0.0; } }
+    for (uint32_t r = 0; r < ntaps; r++) { for (uint32_t c = 0; c < ntaps; c++) { R[r][c] = low[(r >= c) ? (r - c) : (c - r)]; } }
+    for (uint32_t r = 0; r < LTM_NT; r++) { for (uint32_t c = 0; c < LTM_NT; c++) { A[r][c] = R[r][c]; } }
+    for (uint32_t r = 0; r < ntaps; r++) { b[r] = mid[2 + r - ntaps / 2]; x[r] = b[r]; }
+    if (ltm_lu_factor(A, ntaps, perm, scale) != 0) {
+      ret = 4;
+    } else {
+      ltm_lu_substitute(A, x, ntaps, perm);
+      for (uint32_t it = 0; it < 2; it++) {
+        for (uint32_t r = 0; r < ntaps; r++) {
+          ext80 acc = ext_from_double(-b[r]);
+          for (uint32_t c = 0; c < ntaps; c++) { acc = ext_add(acc, ext_from_double(R[r][c] * x[c])); }
+          err[r] = ext_to_double(acc);
+        }
+        ltm_lu_substitute(A, err, ntaps, perm);
+        for (uint32_t r = 0; r < ntaps; r++) { x[r] -= err[r]; }
+      }
+      double mag = 0.0;
+      for (uint32_t r = 0; r < ntaps; r++) { mag += fabs(x[r]); }
+      if (mag >= 1.0) {
+        for (uint32_t r = 0; r < ntaps; r++) { x[r] = 0.0; }
+        x[ntaps / 2] = mid[2] / low[0];
+      }
+      pitch = chosen;
+      for (uint32_t r = 0; r < ntaps; r++) { vec[r] = x[r]; }
+    }
+  }
+  if (ret != 0 || pitch >= 256u) { pitch = 0; }            // src/SLAEncoder.c:629-632
+  const sla_hip_lpc_group g = groups[j];
+  sla_hip_tail_job out;
+  out.blk_off = g.pcm_off; out.blk_len = g.num_samples; out.channel = g.channel; out.pitch = pitch;
+  for (uint32_t t = 0; t < LTM_NT; t++) {
+    // Round(coef * 2^15) << 16 with the x86 conversion (out of range / NaN -> INT32_MIN)   src/SLAEncoder.c:635-640
+    const double v = ((t < ntaps) ? vec[t] : 0.0) * 32768.0;
+    const double rv = (v >= 0.0) ? floor(v + 0.5) : -floor(-v + 0.5);
+    const int32_t q = (!(rv > -2147483649.0 && rv < 2147483648.0)) ? INT32_MIN : (int32_t)rv;
+    out.ltm_coef[t] = (int32_t)((uint32_t)q << 16);
+  }
+  out.pad_[0] = out.pad_[1] = 0;
+  jobs[j] = out;
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers (C-ABI, see include/sla_hip.h)
 // ---------------------------------------------------------------------------------------------
 // The driver may ask for the on-device execution span of its next launch of k_lpc_blocks / k_lattice / k_ltm_acf /
@@ -2185,6 +2381,17 @@ extern "C" int sla_hip_launch_ltm_acf(const int32_t* d_residual, uint64_t plane_
     hipLaunchKernelGGL(k_ltm_acf<false>, dim3(grid), dim3(ACF_THREADS), 0, st, d_residual, plane_stride, d_jobs, num_jobs,
                        log2F, d_twiddles, d_scratch, d_acf_head, head, span);
   }
+  return hip_rc(hipGetLastError());
+}
+
+extern "C" int sla_hip_launch_ltm_solve(const double* d_acf_records, const sla_hip_lpc_group* d_groups, uint32_t num_jobs,
+                                        uint32_t longterm_order, sla_hip_tail_job* d_jobs, sla_hip_stream_t stream)
+{
+  if (d_acf_records == nullptr || d_groups == nullptr || d_jobs == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (longterm_order == 0 || longterm_order > LTM_NT || (longterm_order & 1u) == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (num_jobs == 0) { return 0; }
+  hipLaunchKernelGGL(k_ltm_solve, dim3((num_jobs + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_acf_records, d_groups, num_jobs,
+                     longterm_order, d_jobs);
   return hip_rc(hipGetLastError());
 }
 

@@ -389,6 +389,132 @@ def test_lpc_launcher_candidates(oracle, hip):
         assert np.array_equal(out[i, 1:].view(np.uint64), par.view(np.uint64)), (i, s, n)
 
 
+@pytest.mark.parametrize("ntaps", [1, 3, 5])
+def test_ltm_solve_launcher(oracle, hip, ntaps):
+    """sla_hip_launch_ltm_solve (pitch + taps on the device, the long double refinement residual in integer arithmetic)
+    against the host solve the CPU suite pins to the oracle (tests/test_host_logic.py::test_longterm_solve): records of
+    real residuals through the oracle's own analysis, and 30000 synthetic records -- smooth, near-singular, huge, tiny,
+    cancelling, refused codes, lags at both ends of the range"""
+    import torch
+    L = hip.lib()
+    f64p, u32p = C.POINTER(C.c_double), C.POINTER(C.c_uint32)
+    L.slai_ltm_solve.argtypes = [f64p, C.c_uint32, u32p, f64p]
+    L.slai_ltm_solve.restype = C.c_int
+    rng = np.random.default_rng(100 + ntaps)
+    recs = []
+    # (a) real residuals: the record the FFT kernel would hand over, from the oracle's autocorrelation
+    base = rng.integers(-2000, 2000, 97)
+    real = [W.gen(nm, 1, 4096, 16, seed=11)[0] >> 18 for nm in W.NAMES]
+    real.append((np.tile(base, 50)[:4096] + rng.integers(-50, 50, 4096)).astype(np.int32))
+    want_real = []
+    for res in real:
+        ret, pitch, coef, ac = oracle.ltm_analyze(np.ascontiguousarray(res, np.int32), 8192, ntaps, want_autocorr=True)
+        if ret != 0 or abs(ac[0]) <= np.finfo(np.float32).tiny:
+            continue
+        rec = np.zeros(12)
+        rec[0], rec[1] = 1.0, float(pitch)
+        rec[2:7] = ac[:5]
+        rec[7:12] = [ac[pitch + k - 2] if pitch + k >= 2 else 0.0 for k in range(5)]
+        recs.append(rec)
+        want_real.append((pitch, coef))
+    assert len(want_real) >= 3
+    # (b) synthetic records
+    for i in range(30000):
+        kind = i % 10
+        rho = rng.uniform(-0.999, 0.999)
+        scale = 10.0 ** rng.uniform(-6, 18) if kind != 7 else 10.0 ** rng.uniform(-40, -30)
+        low = scale * rho ** np.arange(5) * (1.0 + (0 if kind == 1 else 1e-3) * rng.standard_normal(5))
+        low[0] = abs(low[0]) + (0 if kind in (1, 2) else scale * rng.uniform(0, 0.5))
+        if kind == 2:
+            low[:] = scale                                  # rank one
+        if kind == 3:
+            low = scale * np.cos(0.7 * np.arange(5))        # a pure tone: singular for 3 and 5 taps
+        mid = low[0] * rng.uniform(-1.2, 1.2, 5)
+        if kind == 4:
+            mid = low[[2, 1, 0, 1, 2]] * (1 + 1e-12 * rng.standard_normal(5))      # the taps cancel in the residual
+        chosen = int(rng.integers(0, 300)) if kind == 5 else int(rng.integers(3, 256))
+        code = [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0, 1.0, 2.0, 1.0][kind]
+        if kind == 9:
+            low = np.round(low / scale * 2 ** 20) * scale / 2 ** 20      # few significant bits: exact ties in the rounding
+            mid = np.round(mid / scale * 2 ** 20) * scale / 2 ** 20
+        recs.append(np.concatenate([[code, float(chosen)], low, mid]))
+    recs = np.ascontiguousarray(np.array(recs))
+    n = len(recs)
+
+    class Group(C.Structure):
+        _fields_ = [("pcm_off", C.c_uint64)] + [(nm, C.c_uint32) for nm in (
+            "num_samples", "channel", "win_off", "int_shift", "cand_first", "cand_count", "slot_first", "pad_")]
+
+    class Job(C.Structure):
+        _fields_ = [("blk_off", C.c_uint64), ("blk_len", C.c_uint32), ("channel", C.c_uint32), ("pitch", C.c_uint32),
+                    ("ltm_coef", C.c_int32 * 5), ("pad_", C.c_uint32 * 2)]
+    assert C.sizeof(Job) == 48
+    groups = (Group * n)()
+    for i in range(n):
+        groups[i] = Group(1000 * i, 100 + i, i % 7, 0, 0, 0, 1, i, 0)
+    d_rec = torch.from_numpy(recs).cuda()
+    d_g = torch.frombuffer(bytearray(bytes(groups)), dtype=torch.uint8).cuda()
+    d_jobs = torch.full((n * C.sizeof(Job),), 0xAB, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    L.sla_hip_launch_ltm_solve.restype = C.c_int
+    rc = L.sla_hip_launch_ltm_solve(C.c_void_p(d_rec.data_ptr()), C.c_void_p(d_g.data_ptr()), C.c_uint32(n), C.c_uint32(ntaps),
+                                    C.c_void_p(d_jobs.data_ptr()), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    jobs = (Job * n).from_buffer_copy(d_jobs.cpu().numpy().tobytes())
+    solved = refused = fallback = 0
+    for i in range(n):
+        pitch = C.c_uint32(0)
+        coef = np.zeros(5)
+        ret = L.slai_ltm_solve(recs[i].ctypes.data_as(f64p), ntaps, C.byref(pitch), coef.ctypes.data_as(f64p))
+        if i < len(want_real):
+            assert ret == 0 and pitch.value == want_real[i][0]
+            assert np.array_equal(coef[:ntaps].view(np.uint64), want_real[i][1].view(np.uint64))
+        if ret != 0:
+            coef[:] = 0
+            refused += 1
+        wp = 0 if (ret != 0 or pitch.value >= 256) else pitch.value
+        q = []
+        for t in range(5):
+            v = (coef[t] if t < ntaps else 0.0) * 32768.0
+            rv = np.floor(v + 0.5) if v >= 0 else -np.floor(-v + 0.5)
+            qi = -2 ** 31 if not (-2147483649.0 < rv < 2147483648.0) else int(rv)
+            q.append(((qi << 16) & 0xFFFFFFFF) - (1 << 32) if ((qi << 16) & 0x80000000) else (qi << 16) & 0xFFFFFFFF)
+        j = jobs[i]
+        assert (j.blk_off, j.blk_len, j.channel) == (1000 * i, 100 + i, i % 7)
+        assert j.pitch == wp, (i, recs[i])
+        assert list(j.ltm_coef) == q, (i, recs[i], list(j.ltm_coef), q)
+        assert tuple(j.pad_) == (0, 0)
+        solved += int(ret == 0 and recs[i][0] == 1.0)
+        fallback += int(ret == 0 and ntaps > 1 and np.count_nonzero(coef[:ntaps]) == 1)
+    assert solved > 15000 and refused > 3000
+    if ntaps > 1:
+        assert fallback > 100          # |taps| >= 1: the single-tap fallback was taken
+
+
+@pytest.mark.parametrize("ltm", [1, 3, 5])
+def test_longterm_paths_agree(oracle, hip, ltm):
+    """long-term stage solved on the device (one k_tail for the file, or one per chunk) and on the host threads: the
+    oracle's bytes each time -- pitched material, silence gaps, RAW blocks (white noise) in the same file"""
+    rng = np.random.default_rng(40 + ltm)
+    n = 300000
+    base = rng.integers(-6000, 6000, 131)
+    x = (np.tile(base, n // 131 + 1)[:n] + rng.integers(-300, 300, n)).astype(np.int64)
+    y = W.music_like(1, n, 16, seed=ltm)[0].astype(np.int64) >> 16
+    pcm = np.stack([x, y])
+    pcm[:, 50000:70000] = rng.integers(-32768, 32767, (2, 20000))           # RAW blocks
+    pcm[:, 120000:131000] = 0
+    pcm = np.ascontiguousarray((pcm << 16).astype(np.int32))
+    p = S.make_params(2, 16, 48000, parcor=8, ltm=ltm, lms=8, ms=0, max_block=4096)
+    ret, want, tro = oracle.encode_trace(p, pcm)
+    assert ret == 0
+    assert (tro.blk_type[:tro.num_blocks] == 2).any() and (tro.pitch[:tro.num_blocks] >= 3).any()
+    for opts in ({}, {"chunks": 3}, {"chunks": 3, "single_tail": 0}, {"device_ltm": 0}, {"device_ltm": 0, "chunks": 2},
+                 {"device_ltm": 0, "chunks": 3, "single_tail": 0}):
+        got, _ = _encode_with_options(hip, p, pcm, **opts)
+        assert got == want, opts
+
+
 @pytest.mark.parametrize("order,nch,bits,ms", [(16, 1, 16, 0), (32, 2, 16, 1), (5, 2, 24, 1), (48, 1, 24, 0), (10, 1, 8, 0)])
 def test_search_exact_launcher_equals_serial_chains(oracle, hip, order, nch, bits, ms):
     """sla_hip_launch_search_exact (tile sums, any summation order) == oracle autocorr+Levinson in the
@@ -684,7 +810,12 @@ def test_random_parameter_walk_chunked(oracle, hip, seed):
         pcm[:, a:b] = 0
     p = S.make_params(nch, bits, 48000, parcor=order, ltm=int(rng.choice([1, 3])), lms=int(rng.choice([8, 16])),
                       ms=int(nch == 2 and rng.integers(0, 2)), window=int(rng.integers(0, 5)), max_block=maxb)
-    assert_same_as_oracle(oracle, hip, p, np.ascontiguousarray(pcm), roundtrip=False)
+    pcm = np.ascontiguousarray(pcm)
+    assert_same_as_oracle(oracle, hip, p, pcm, roundtrip=False)
+    want = oracle.encode_trace(p, pcm)[1]
+    for opts in ({"chunks": 3}, {"chunks": 2, "single_tail": 0}, {"chunks": 3, "device_ltm": 0}):
+        got, t = _encode_with_options(hip, p, pcm, **opts)
+        assert got == want and t[9] == opts["chunks"], opts
 
 
 # ------------------------------------------------------------------ BASELINE sizes: size-independent properties
