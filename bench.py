@@ -367,8 +367,9 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
     ev = {"k_lpc_blocks": kernel_ms[2], "k_lattice": kernel_ms[3], "k_ltm_acf": kernel_ms[8], "k_tail": kernel_ms[4]}
     dev = dict(zip(("k_lpc_blocks", "k_lattice", "k_ltm_acf", "k_tail"), span_ms))
     kernels = {"k_prepass": (kernel_ms[0], 1)}
+    tail_launches = max(int(enc.last_counters()[4]), 1)         # one k_tail for the whole file unless the handle was told otherwise
     for name in ev:
-        kernels[name] = (ev[name], nchunks)                      # HIP events on the kernel's own stream, as the contract asks
+        kernels[name] = (ev[name], tail_launches if name == "k_tail" else nchunks)      # HIP events on the kernel's own stream, as the contract asks
     search_name = ("k_acf_tiles+k_search_finish" + ("+k_lpc" if kernel_ms[10] > 0 else "")) if exact_search else "k_lpc"
     kernels[search_name] = (kernel_ms[1], nchunks)               # one event pair spans the kernels of the search stage
     dom = max(kernels, key=lambda k: kernels[k][0])
@@ -501,34 +502,50 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
         out["end_to_end"]["one_clip_per_call_msamples_s"] = round(one.shape[0] * one.shape[1] / per_clip / 1e6, 3)
         out["end_to_end"]["one_clip_per_call_ms"] = round(per_clip * 1e3, 3)
         enc2.close()
-    if primary and not args.no_e2e and world == 1 and batch is None:
+    if not args.no_e2e and world == 1 and batch is None:
         if host_pcm is None:
             host_pcm = np.ascontiguousarray(d_pcm[:, :n_file].cpu().numpy())
         enc2 = sla_amd.Encoder(*cap)
         enc2.set_wave_format(nch, bits, rate)
         enc2.set_encode_parameter(order, ltm, lms, ms, win, maxb)
-        outbuf = np.zeros(4 * nch * n_file + 65536, np.uint8)
-        enc2.encode_whole(host_pcm, out=outbuf)
-        reps = 3
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            data = enc2.encode_whole(host_pcm, out=outbuf)
-        e2e = (time.perf_counter() - t1) / reps
+        out_cap = min(4 * nch * n_file + 65536, 0xFFFFFFF0)                # the API's sizes are 32-bit
+        outbuf = np.zeros(out_cap, np.uint8)
+        reps = 3 if primary else 2
+
+        def timed(src, dst):
+            got = enc2.encode_whole(src, out=dst)
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                got = enc2.encode_whole(src, out=dst)
+            return got, (time.perf_counter() - t1) / reps
+
+        # files of >= 2 x 32 Mi samples take the streamed path (pieces on worker lanes: upload, kernels and download of
+        # different pieces overlap); shorter ones the plain path.  Both are timed; the bytes must be the same.
+        data, e2e = timed(host_pcm, outbuf)
+        size = len(data)
+        enc2.set_option("stream", 0)
+        plain, e2e_plain = timed(host_pcm, np.zeros(size + 65536, np.uint8))
+        same = bool(len(plain) == size and np.array_equal(plain, data))
+        del plain
+        enc2.set_option("stream", 1)
         out["end_to_end"] = {"msamples_s": round(n_file * nch / e2e / 1e6, 3), "samples": n_file * nch,
-                             "sla_bytes": len(data), "note": "SLAEncoder_EncodeWhole: pageable host PCM -> .sla bytes incl. PCIe both ways and the device bit-pack"}
+                             "plain_path_msamples_s": round(n_file * nch / e2e_plain / 1e6, 3), "streamed_equals_plain": same,
+                             "sla_bytes": size, "note": "SLAEncoder_EncodeWhole: pageable host PCM -> .sla bytes incl. PCIe both ways and the device bit-pack"}
         # the same call on page-locked caller memory (hipHostMalloc / hipHostRegister, here torch pinned tensors): DMA without the staging copy
         pin_in = torch.from_numpy(host_pcm).pin_memory()
-        pin_out = torch.zeros(4 * nch * n_file + 65536, dtype=torch.uint8).pin_memory()
-        enc2.encode_whole(pin_in.numpy(), out=pin_out.numpy())
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            data_p = enc2.encode_whole(pin_in.numpy(), out=pin_out.numpy())
-        e2p = (time.perf_counter() - t1) / reps
+        pin_out = torch.zeros(size + 65536, dtype=torch.uint8).pin_memory()
+        data_p, e2p = timed(pin_in.numpy(), pin_out.numpy())
         out["end_to_end"]["pinned_msamples_s"] = round(n_file * nch / e2p / 1e6, 3)
-        out["end_to_end"]["pinned_identical"] = bool(bytes(data_p) == bytes(data))
+        out["end_to_end"]["pinned_identical"] = bool(len(data_p) == size and np.array_equal(data_p, data))
+        enc2.set_option("stream", 0)
+        _, e2p_plain = timed(pin_in.numpy(), pin_out.numpy())
+        out["end_to_end"]["pinned_plain_path_msamples_s"] = round(n_file * nch / e2p_plain / 1e6, 3)
         del pin_in, pin_out
         enc2.close()
-        if lms in (4, 8, 16, 32) and maxb <= 16384:
+        if not (same and out["end_to_end"]["pinned_identical"]):
+            print(json.dumps({"error": "end-to-end paths disagree", "config": cfg}), file=sys.stderr, flush=True)
+            raise SystemExit(3)
+        if primary and lms in (4, 8, 16, 32) and maxb <= 16384:
             dec = sla_amd.Decoder(nch, maxb, order, ltm, lms)
             stream = bytes(data)
             rc, back = dec.decode_whole(stream, n_file)

@@ -474,8 +474,9 @@ const char* sla_hip_device_name(void);
 /* The 12 floats of the last analysis (sla_hip_analyze_device or SLAEncoder_EncodeWhole/Block). */
 int sla_hip_last_timing(const struct SLAEncoder* encoder, float* timing_ms);
 
-/* 4 counters of the last analysis: search groups rerun as serial chains; super-frames whose partition the host
- * had to decide (device plan not certified); 1 if the search ran on tile sums; 1 if the device plan is enabled. */
+/* 6 counters of the last analysis: search groups rerun as serial chains; super-frames whose partition the host
+ * had to decide (device plan not certified); 1 if the search ran on tile sums; 1 if the device plan is enabled;
+ * k_tail launches (1: one for the file, else one per pipeline chunk); 1 if pitch + taps were solved on the device. */
 int sla_hip_last_counters(const struct SLAEncoder* encoder, uint32_t* counters);
 
 /* 4 floats [ms]: execution time of k_lpc_blocks, k_lattice, k_ltm_acf, k_tail in the last analysis, summed over

@@ -398,8 +398,9 @@ class Encoder:
         return list(k)
 
     def last_counters(self):
-        """(search groups rerun as chains, super-frames planned on the host, exact search used, device plan enabled)"""
-        c = (C.c_uint32 * 4)()
+        """(search groups rerun as chains, super-frames planned on the host, exact search used, device plan enabled,
+        k_tail launches, long-term solve on the device)"""
+        c = (C.c_uint32 * 6)()
         self._check(self._lib.sla_hip_last_counters(self._h, c), "sla_hip_last_counters")
         return tuple(c)
 

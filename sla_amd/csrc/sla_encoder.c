@@ -74,6 +74,7 @@ struct SLAEncoder {
   sla_hip_tuning tune;              /* launcher knobs, named to the launchers at every API entry */
   uint32_t host_planned;            /* last analysis: super-frames whose partition the host had to decide */
   uint32_t fallback_groups;         /* last analysis: search groups that had to take the chain kernel */
+  uint32_t tail_launches;           /* last analysis: k_tail launches (1 with the device long-term solve, else one per chunk) */
   slai_fft_plan* fft;
   uint32_t threads;
   struct slai_pool* pool;
@@ -109,6 +110,15 @@ struct SLAEncoder {
   uint32_t nsegs; const uint32_t* seg_start; const uint32_t* seg_len;
   uint32_t batch_lshift, batch_or;
   devbuf_t d_tile_or; pinbuf_t h_tile_or;
+
+  /* SLAEncoder_EncodeWhole of a long file: pieces cross the bus, are analysed and packed on worker lanes (handles of
+   * their own on the same device, one host thread each), so upload, kernels and download of different pieces overlap */
+  int      stream_mode;             /* 1 (default): on for files of at least two pieces */
+  uint32_t stream_piece;            /* samples (all channels together) per piece */
+  uint32_t stream_lanes;            /* worker lanes (1..4) */
+  struct SLAEncoder* lane[4];
+  int      is_lane;
+  int      streamed;                /* the last EncodeWhole ran on the lanes: this handle holds no analysis tables */
 
   /* last analysis */
   const int32_t* pcm_dev;           /* borrowed or &d_pcm */
@@ -340,6 +350,9 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
     if (e->split_count > 0) { e->chunks = e->split_count; }
   }
   e->search_exact = 1; e->exact_bits = 53; e->device_plan = 1; e->cert_safety = 64.0;
+  e->stream_mode = 1; e->stream_piece = 32u << 20; e->stream_lanes = 4;
+  env = getenv("SLA_HIP_STREAM");
+  if (env != NULL) { e->stream_mode = (atoi(env) != 0); }
   /* measured on C2: the lattice inside k_lpc_blocks costs 0.6 ms per step (9 wave-chunks on the 8 waves of a workgroup
    * that has nothing else left to overlap them with), its own launch 0.27 ms: separate by default */
   e->fuse_lattice = 0;
@@ -404,6 +417,7 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   pinbuf_t* h[25];
   int i;
   if (e == NULL) { return; }
+  for (i = 0; i < 4; i++) { SLAEncoder_Destroy(e->lane[i]); e->lane[i] = NULL; }
   (void)hipSetDevice(e->device);
   if (e->stream != NULL) { (void)hipStreamSynchronize(e->stream); }
   if (e->stream2 != NULL) { (void)hipStreamSynchronize(e->stream2); }
@@ -1647,6 +1661,7 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
       if (!e->single_tail || c == a.nchunks - 1) { e->timing[4] += ev_ms(ev[EV_TAIL_S], ev[EV_TAIL_E]); }
     }
     e->timing[9] = (float)a.nchunks;
+    e->tail_launches = (e->single_tail) ? 1u : a.nchunks;
     e->timing[10] = (float)e->fallback_groups;
     e->timing[11] = (float)a.exact;
   }
@@ -1681,6 +1696,9 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   else if (strcmp(name, "cert_safety") == 0)       { if (value < 0.0 || value > 1e30) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->cert_safety = value; }
   else if (strcmp(name, "device_plan") == 0)       { OPT_RANGE(0, 1); e->device_plan = (int)iv; }
   else if (strcmp(name, "single_tail") == 0)       { OPT_RANGE(0, 1); e->single_tail = (int)iv; }
+  else if (strcmp(name, "stream") == 0)            { OPT_RANGE(0, 1); e->stream_mode = (int)iv; }
+  else if (strcmp(name, "stream_piece") == 0)      { OPT_RANGE(1024, 1 << 30); e->stream_piece = (uint32_t)iv; }
+  else if (strcmp(name, "stream_lanes") == 0)      { OPT_RANGE(1, 4); e->stream_lanes = (uint32_t)iv; }
   else if (strcmp(name, "first_chunk") == 0)       { OPT_RANGE(0, 999); e->first_chunk = (uint32_t)iv; }
   else if (strcmp(name, "device_ltm") == 0)        { OPT_RANGE(0, 1); e->device_ltm = (int)iv; }
   else if (strcmp(name, "fuse_lattice") == 0)      { OPT_RANGE(0, 1); e->fuse_lattice = (int)iv && !e->tune.lpc_blocks_chains; }
@@ -1828,6 +1846,7 @@ int sla_hip_last_counters(const struct SLAEncoder* e, uint32_t* counters)
   if (e == NULL || counters == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   counters[0] = e->fallback_groups; counters[1] = e->host_planned;
   counters[2] = (uint32_t)e->timing[11]; counters[3] = (uint32_t)e->device_plan;
+  counters[4] = e->tail_launches; counters[5] = (uint32_t)e->device_ltm;
   return 0;
 }
 
@@ -1975,6 +1994,11 @@ typedef struct {
   uint32_t out_size; int result;         /* out */
   uint32_t num_blocks, max_block, max_bps;
   uint64_t img_off;                      /* where the file starts in the device image */
+  /* a piece of a streamed file (one segment only): no 43-byte header in front of the blocks, and the destination is
+   * asked for once the size is known -- place() sets data / data_size (the piece's place in the caller's buffer) */
+  int bare;
+  int (*place)(void* ctx, uint32_t out_size, uint8_t** data, uint32_t* data_size);
+  void* place_ctx;
 } pack_seg_t;
 
 static int download_bytes(struct SLAEncoder* e, uint8_t* dst, const uint8_t* d_src, size_t bytes);
@@ -2052,7 +2076,7 @@ static int pack_device_core(struct SLAEncoder* e, pack_seg_t* segs, uint32_t nse
   tp2 = now_ms();
   /* block sizes -> offsets; a file = 43 header bytes + its blocks */
   for (sg = 0; sg < nsegs; sg++) { segs[sg].out_size = 0; segs[sg].result = 0; segs[sg].num_blocks = 0; segs[sg].max_block = 0; segs[sg].max_bps = 0; }
-  sg = 0; segs[0].img_off = 0; cur = SLA_HEADER_SIZE;
+  sg = 0; segs[0].img_off = 0; cur = (nsegs == 1 && segs[0].bare) ? 0 : SLA_HEADER_SIZE;
   for (b = 0; b < nb; b++) {
     const blk_t* k = &e->blk[b];
     uint64_t body_bits = 0, bytes;
@@ -2089,6 +2113,11 @@ static int pack_device_core(struct SLAEncoder* e, pack_seg_t* segs, uint32_t nse
     segs[sg].img_off = cur; cur += SLA_HEADER_SIZE;
   }
   free(job_of);
+  if (nsegs == 1 && segs[0].place != NULL) {
+    rc = segs[0].place(segs[0].place_ctx, segs[0].out_size, &segs[0].data, &segs[0].data_size);
+    if (rc != 0) { return rc; }
+    if (segs[0].out_size > segs[0].data_size) { segs[0].result = SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE; }
+  }
   if (nsegs == 1 && segs[0].result != 0) { return segs[0].result; }     /* one file: nothing worth assembling */
 
   /* assemble the image on the device, bring it back with one copy */
@@ -2120,7 +2149,7 @@ static int pack_device_core(struct SLAEncoder* e, pack_seg_t* segs, uint32_t nse
             tp1 - tp0, tp2 - tp1, tp3 - tp2, tp4 - tp3);
   }
   for (sg = 0; sg < nsegs; sg++) {
-    if (segs[sg].result != 0) { continue; }
+    if (segs[sg].result != 0 || segs[sg].bare) { continue; }
     hinfo.wave_format = e->wave_format; hinfo.wave_format.offset_lshift = (uint8_t)e->lshift;
     hinfo.encode_param = e->encode_param; hinfo.num_samples = segs[sg].hi - segs[sg].lo; hinfo.num_blocks = segs[sg].num_blocks;
     hinfo.max_block_size = segs[sg].max_block; hinfo.max_bit_per_second = segs[sg].max_bps;
@@ -2291,6 +2320,251 @@ static int download_bytes(struct SLAEncoder* e, uint8_t* dst, const uint8_t* d_s
   return 0;
 }
 
+/* ---- SLAEncoder_EncodeWhole of a long file, streamed ------------------------------------------------------------
+ * One file = upload (PCIe in), analysis (kernels), pack (kernels), download (PCIe out): four resources that the plain
+ * path uses one after the other.  Blocks are independent and the only sequential thing in the format is
+ * the super-frame hop, so the file is cut into pieces exactly as "one file, several GPUs" cuts it (sla_hip.h) -- only
+ * that the "ranks" are worker lanes on ONE device: handles of their own (own streams, buffers, host threads), piece r
+ * on lane r mod L.  A lane uploads its piece (+ one block of halo), scans it, takes over the hop where the piece
+ * before it ended, analyses [bounds[r], bounds[r+1]), sizes its blocks, learns where they go in the caller's buffer
+ * from the piece before it, and writes them there.  Uploads take turns in piece order (piece 0 should be analysed
+ * while piece 1 is still on the bus, not share the bus with it).
+ * offset_lshift is a property of the whole file (trailing zeros of the OR of every sample, src/SLAEncoder.c:425-455):
+ * the lanes take it from piece 0 and every later piece checks its own samples against it; a piece that disagrees
+ * (or an all-zero piece 0) abandons the streamed pass and the file takes the plain path -- same bytes either way. */
+typedef struct {
+  struct SLAEncoder* parent;
+  const int32_t* const* input; uint32_t n;
+  uint8_t* data; uint32_t data_size;
+  uint32_t K, L, maxb;
+  uint32_t nominal[65];              /* piece r scans [nominal[r], nominal[r+1]) (multiples of 64) */
+  pthread_mutex_t mu; pthread_cond_t cv;
+  uint32_t upload_turn;              /* the piece whose upload may start */
+  int      have_ntz; uint32_t ntz;   /* trailing zeros of piece 0's OR word */
+  uint32_t bounds[65]; uint32_t bounds_known;      /* bounds[0..bounds_known) are final */
+  uint64_t off[65]; uint32_t off_known;            /* byte offset of piece r's first block in the file */
+  uint32_t num_blocks, max_block, max_bps, lshift;
+  int      failed;                   /* > 0: API result to return; < 0: take the plain path */
+  double   t0; double stamp[65][7];  /* SLA_HIP_TRACE: per piece -- upload begins / ends, scanned, hop known, analysed, sized, delivered */
+} stream_ctx_t;
+
+typedef struct { stream_ctx_t* sc; uint32_t lane; } stream_arg_t;
+
+static void stream_fail(stream_ctx_t* sc, int code)
+{
+  pthread_mutex_lock(&sc->mu);
+  if (sc->failed == 0) { sc->failed = code; }
+  pthread_cond_broadcast(&sc->cv);
+  pthread_mutex_unlock(&sc->mu);
+}
+
+typedef struct { stream_ctx_t* sc; uint32_t r; } place_arg_t;
+
+/* pack callback: piece r knows its size -- wait for the place the piece before it ends at, publish our own end */
+static int stream_place(void* vctx, uint32_t out_size, uint8_t** data, uint32_t* data_size)
+{
+  place_arg_t* pa = (place_arg_t*)vctx;
+  stream_ctx_t* sc = pa->sc;
+  uint64_t at;
+  int rc = 0;
+  pthread_mutex_lock(&sc->mu);
+  while (sc->off_known <= pa->r && sc->failed == 0) { pthread_cond_wait(&sc->cv, &sc->mu); }
+  if (sc->failed != 0) { pthread_mutex_unlock(&sc->mu); return SLA_APIRESULT_NG; }
+  at = sc->off[pa->r];
+  sc->stamp[pa->r][5] = now_ms() - sc->t0;
+  sc->off[pa->r + 1] = at + out_size;
+  sc->off_known = pa->r + 2;
+  pthread_cond_broadcast(&sc->cv);
+  pthread_mutex_unlock(&sc->mu);
+  if (at + out_size > (uint64_t)sc->data_size) { rc = SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE; }
+  else { *data = sc->data + at; *data_size = (uint32_t)(sc->data_size - at); }
+  return rc;
+}
+
+static void* stream_lane_main(void* varg)
+{
+  stream_arg_t* sa = (stream_arg_t*)varg;
+  stream_ctx_t* sc = sa->sc;
+  struct SLAEncoder* e = sc->parent->lane[sa->lane];
+  const uint32_t C = e->wave_format.num_channels;
+  const int32_t* planes[SLAI_MAX_CHANNELS];
+  uint64_t* mask = NULL; size_t mask_cap = 0;
+  uint32_t r, ch;
+  for (r = sa->lane; r < sc->K; r += sc->L) {
+    const uint32_t lo = sc->nominal[r], nominal_hi = sc->nominal[r + 1];
+    const uint32_t hi = (sc->n - nominal_hi > sc->maxb) ? nominal_hi + sc->maxb : sc->n;      /* + the halo the hop may run into */
+    const uint32_t cnt = hi - lo;
+    const size_t nwords = ((size_t)cnt + 63) / 64;
+    uint32_t orw = 0, b_lo, b_hi, pos, word;
+    int rc;
+    /* upload, in piece order */
+    pthread_mutex_lock(&sc->mu);
+    while (sc->upload_turn != r && sc->failed == 0) { pthread_cond_wait(&sc->cv, &sc->mu); }
+    pthread_mutex_unlock(&sc->mu);
+    if (sc->failed != 0) { break; }
+    sc->stamp[r][0] = now_ms() - sc->t0;
+    for (ch = 0; ch < C; ch++) { planes[ch] = sc->input[ch] + lo; }
+    rc = (enter(e) != 0) ? SLA_APIRESULT_NG : upload_pcm(e, planes, cnt);
+    pthread_mutex_lock(&sc->mu);
+    sc->upload_turn = r + 1;
+    pthread_cond_broadcast(&sc->cv);
+    pthread_mutex_unlock(&sc->mu);
+    sc->stamp[r][1] = now_ms() - sc->t0;
+    if (rc != 0) { stream_fail(sc, rc > 0 ? rc : SLA_APIRESULT_NG); break; }
+    /* scan: OR word and silence mask of the piece and its halo */
+    if (nwords + 2 > mask_cap) {
+      free(mask);
+      mask_cap = nwords + 2;
+      mask = (uint64_t*)malloc(mask_cap * 8);
+      if (mask == NULL) { stream_fail(sc, SLA_APIRESULT_NG); break; }
+    }
+    rc = sla_hip_shard_scan(e, e->pcm_dev, e->stride, cnt, &orw, mask);
+    if (rc != 0) { stream_fail(sc, rc > 0 ? rc : SLA_APIRESULT_NG); break; }
+    mask[nwords] = 0; mask[nwords + 1] = 0;
+    sc->stamp[r][2] = now_ms() - sc->t0;
+    /* offset_lshift: piece 0 speaks for the file, everybody else checks */
+    pthread_mutex_lock(&sc->mu);
+    if (r == 0) {
+      if (orw == 0) { sc->failed = -1; } else { sc->ntz = (uint32_t)__builtin_ctz(orw); sc->have_ntz = 1; }
+      pthread_cond_broadcast(&sc->cv);
+    }
+    while (!sc->have_ntz && sc->failed == 0) { pthread_cond_wait(&sc->cv, &sc->mu); }
+    if (sc->failed == 0 && orw != 0 && (uint32_t)__builtin_ctz(orw) < sc->ntz) { sc->failed = -1; pthread_cond_broadcast(&sc->cv); }
+    /* the hop: from where the piece before us ended, through our piece */
+    while (sc->bounds_known <= r && sc->failed == 0) { pthread_cond_wait(&sc->cv, &sc->mu); }
+    if (sc->failed != 0) { pthread_mutex_unlock(&sc->mu); break; }
+    b_lo = sc->bounds[r];
+    pthread_mutex_unlock(&sc->mu);
+    sc->stamp[r][3] = now_ms() - sc->t0;
+    pos = b_lo;
+    if (r + 1 == sc->K) {
+      pos = sc->n;
+    } else {
+      while (pos < nominal_hi) {                                  /* src/SLAEncoder.c:846-869, 392-408 */
+        const uint32_t remain = sc->n - pos;
+        const uint32_t window = (sc->maxb < remain) ? sc->maxb : remain;
+        const uint32_t min_blk = (SLAI_MIN_BLOCK < remain) ? SLAI_MIN_BLOCK : remain;
+        const uint32_t run = slai_zero_run(mask, pos - lo, window);
+        pos += (run >= min_blk) ? run : window;
+      }
+    }
+    b_hi = pos;
+    pthread_mutex_lock(&sc->mu);
+    sc->bounds[r + 1] = b_hi;
+    sc->bounds_known = r + 2;
+    pthread_cond_broadcast(&sc->cv);
+    pthread_mutex_unlock(&sc->mu);
+    if (b_hi == b_lo) {                                           /* nothing starts in this piece */
+      pthread_mutex_lock(&sc->mu);
+      while (sc->off_known <= r && sc->failed == 0) { pthread_cond_wait(&sc->cv, &sc->mu); }
+      if (sc->failed == 0) { sc->off[r + 1] = sc->off[r]; sc->off_known = r + 2; pthread_cond_broadcast(&sc->cv); }
+      pthread_mutex_unlock(&sc->mu);
+      continue;
+    }
+    /* the hot path on our range, with the file's sample unit */
+    word = 0xFFFFFFFFu << sc->ntz;
+    rc = sla_hip_shard_analyze(e, e->pcm_dev + (b_lo - lo), e->stride, b_hi - b_lo, word, NULL);
+    if (rc != 0) { stream_fail(sc, rc > 0 ? rc : SLA_APIRESULT_NG); break; }
+    sc->stamp[r][4] = now_ms() - sc->t0;
+    {
+      pack_seg_t seg;
+      place_arg_t pa;
+      memset(&seg, 0, sizeof(seg));
+      pa.sc = sc; pa.r = r;
+      seg.lo = 0; seg.hi = b_hi - b_lo; seg.data = NULL; seg.data_size = 0xFFFFFFFFu; seg.bare = 1;
+      seg.place = stream_place; seg.place_ctx = &pa;
+      rc = (enter(e) != 0) ? SLA_APIRESULT_NG : pack_device_core(e, &seg, 1);
+      if (rc == 0 && seg.result != 0) { rc = seg.result; }
+      if (rc != 0) { stream_fail(sc, rc > 0 ? rc : SLA_APIRESULT_NG); break; }
+      pthread_mutex_lock(&sc->mu);
+      sc->num_blocks += seg.num_blocks;
+      if (seg.max_block > sc->max_block) { sc->max_block = seg.max_block; }
+      if (seg.max_bps > sc->max_bps) { sc->max_bps = seg.max_bps; }
+      sc->lshift = e->lshift;
+      pthread_mutex_unlock(&sc->mu);
+      sc->stamp[r][6] = now_ms() - sc->t0;
+    }
+  }
+  free(mask);
+  return NULL;
+}
+
+/* a lane: a handle like its parent, fewer host threads; knobs and formats are copied at every use */
+static struct SLAEncoder* stream_lane(struct SLAEncoder* e, uint32_t t)
+{
+  struct SLAEncoder* l = e->lane[t];
+  if (l == NULL) {
+    l = SLAEncoder_Create(&e->cfg);
+    if (l == NULL) { return NULL; }
+    l->is_lane = 1; l->stream_mode = 0;
+    if (l->threads > 4) { pool_destroy(l->pool); l->threads = 4; l->pool = pool_create(4); if (l->pool == NULL) { SLAEncoder_Destroy(l); return NULL; } }
+    e->lane[t] = l;
+  }
+  l->wave_format = e->wave_format; l->encode_param = e->encode_param; l->status_flag = e->status_flag; l->analysed = 0;
+  l->chunks = e->chunks; l->chunks_forced = e->chunks_forced; l->first_chunk = e->first_chunk; l->split_count = 0;
+  l->fuse_lattice = e->fuse_lattice; l->device_plan = e->device_plan; l->search_exact = e->search_exact; l->exact_bits = e->exact_bits;
+  l->cert_safety = e->cert_safety; l->single_tail = e->single_tail; l->device_ltm = e->device_ltm; l->tune = e->tune;
+  l->trace = 0;
+  return l;
+}
+
+/* 0: done; < 0: not streamed (too short, switched off, or the pieces disagreed on offset_lshift) -- take the plain path;
+ * > 0: the API result to return */
+static int encode_whole_streamed(struct SLAEncoder* e, const int32_t* const* input, uint32_t n, uint8_t* data, uint32_t data_size,
+                                 uint32_t* output_size)
+{
+  const uint32_t C = e->wave_format.num_channels;
+  stream_ctx_t* sc;
+  stream_arg_t args[4];
+  pthread_t th[4];
+  uint32_t piece, K, L, r, t, started = 0;
+  int rc = 0;
+  struct SLAHeaderInfo hinfo;
+  if (!e->stream_mode || e->is_lane || C == 0) { return -1; }
+  piece = e->stream_piece / C;
+  piece = (piece + 63u) & ~63u;
+  if (piece < e->encode_param.max_num_block_samples * 2u) { piece = (e->encode_param.max_num_block_samples * 2u + 63u) & ~63u; }
+  if ((uint64_t)n < 2ull * piece) { return -1; }
+  K = (uint32_t)(((uint64_t)n + piece - 1) / piece);
+  if (K > 64) { K = 64; piece = (uint32_t)((((uint64_t)n + K - 1) / K + 63u) & ~(uint64_t)63u); K = (uint32_t)(((uint64_t)n + piece - 1) / piece); }
+  L = (e->stream_lanes < K) ? e->stream_lanes : K;
+  for (t = 0; t < L; t++) { if (stream_lane(e, t) == NULL) { return -1; } }
+  sc = (stream_ctx_t*)calloc(1, sizeof(*sc));
+  if (sc == NULL) { return SLA_APIRESULT_NG; }
+  sc->parent = e; sc->input = input; sc->n = n; sc->data = data; sc->data_size = data_size;
+  sc->K = K; sc->L = L; sc->maxb = e->encode_param.max_num_block_samples;
+  for (r = 0; r <= K; r++) { const uint64_t at = (uint64_t)r * piece; sc->nominal[r] = (at < n && r < K) ? (uint32_t)at : n; }
+  sc->bounds[0] = 0; sc->bounds_known = 1;
+  sc->off[0] = SLA_HEADER_SIZE; sc->off_known = 1;
+  pthread_mutex_init(&sc->mu, NULL); pthread_cond_init(&sc->cv, NULL);
+  sc->t0 = now_ms();
+  for (t = 0; t < L; t++) {
+    args[t].sc = sc; args[t].lane = t;
+    if (pthread_create(&th[t], NULL, stream_lane_main, &args[t]) != 0) { stream_fail(sc, SLA_APIRESULT_NG); break; }
+    started++;
+  }
+  for (t = 0; t < started; t++) { pthread_join(th[t], NULL); }
+  (void)enter(e);                                         /* the lanes named their own knobs on their threads; this thread is ours */
+  rc = sc->failed;
+  if (e->trace) {
+    for (r = 0; r < K; r++) {
+      fprintf(stderr, "[sla_hip] piece %2u lane %u: upload %7.3f..%7.3f scanned %7.3f hop %7.3f analysed %7.3f sized %7.3f delivered %7.3f ms\n", r, r % L,
+              sc->stamp[r][0], sc->stamp[r][1], sc->stamp[r][2], sc->stamp[r][3], sc->stamp[r][4], sc->stamp[r][5], sc->stamp[r][6]);
+    }
+  }
+  if (rc == 0) {
+    memset(&hinfo, 0, sizeof(hinfo));
+    hinfo.wave_format = e->wave_format; hinfo.wave_format.offset_lshift = (uint8_t)sc->lshift;
+    hinfo.encode_param = e->encode_param; hinfo.num_samples = n; hinfo.num_blocks = sc->num_blocks;
+    hinfo.max_block_size = sc->max_block; hinfo.max_bit_per_second = sc->max_bps;
+    rc = slai_write_header(&hinfo, data, data_size);
+    if (rc == 0) { *output_size = (uint32_t)sc->off[K]; e->streamed = 1; e->analysed = 0; e->lshift = sc->lshift; e->num_samples = n; }
+  }
+  pthread_mutex_destroy(&sc->mu); pthread_cond_destroy(&sc->cv);
+  free(sc);
+  return rc;
+}
+
 SLAApiResult SLAEncoder_EncodeWhole(struct SLAEncoder* e, const int32_t* const* input, uint32_t num_samples,
                                     uint8_t* data, uint32_t data_size, uint32_t* output_size)
 {
@@ -2302,6 +2576,12 @@ SLAApiResult SLAEncoder_EncodeWhole(struct SLAEncoder* e, const int32_t* const* 
   {
     const double t0 = now_ms();
     double t1, t2;
+    e->streamed = 0;
+    rc = encode_whole_streamed(e, input, num_samples, data, data_size, output_size);
+    if (rc >= 0) {
+      if (e->trace) { fprintf(stderr, "[sla_hip] EncodeWhole: streamed, %.3f ms\n", now_ms() - t0); }
+      return (SLAApiResult)rc;
+    }
     if ((rc = upload_pcm(e, input, num_samples)) != 0) { return (rc > 0) ? (SLAApiResult)rc : SLA_APIRESULT_NG; }
     t1 = now_ms();
     rc = sla_hip_analyze_device(e, e->pcm_dev, e->stride, num_samples, NULL, NULL);

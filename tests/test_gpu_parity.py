@@ -36,8 +36,18 @@ def hip_encode(hip, p, pcm, want_residuals=True):
         enc.set_wave_format(p.num_channels, p.bits_per_sample, p.sampling_rate)
         enc.set_encode_parameter(p.parcor_order, p.longterm_order, p.lms_order, p.ch_process_method,
                                  p.window_type, p.max_block_samples)
+        enc.set_option("stream", 0)              # the analysis tables below describe an analysis on THIS handle
         data = enc.encode_whole(pcm)
-        return data, enc.trace(want_residuals)
+        tr = enc.trace(want_residuals)
+        n = pcm.shape[1]
+        if n >= 4 * p.max_block_samples and n * p.num_channels <= (1 << 24):
+            # the same file through the streamed path (pieces on worker lanes), in pieces as small as it takes them
+            enc.set_option("stream", 1)
+            enc.set_option("stream_piece", 1024)
+            enc.set_option("stream_lanes", 1 + (n // 7) % 4)
+            again = enc.encode_whole(pcm)
+            assert again == data, "streamed EncodeWhole differs from the plain path"
+        return data, tr
     finally:
         enc.close()
 
@@ -818,6 +828,81 @@ def test_random_parameter_walk_chunked(oracle, hip, seed):
         assert got == want and t[9] == opts["chunks"], opts
 
 
+# ------------------------------------------------------------------ streamed SLAEncoder_EncodeWhole
+
+def _streamed(hip, p, pcm, piece, lanes, capacity=None):
+    enc = hip.Encoder(p.cap_channels, p.cap_block_samples, p.cap_parcor_order, p.cap_longterm_order, p.cap_lms_order)
+    try:
+        enc.set_wave_format(p.num_channels, p.bits_per_sample, p.sampling_rate)
+        enc.set_encode_parameter(p.parcor_order, p.longterm_order, p.lms_order, p.ch_process_method,
+                                 p.window_type, p.max_block_samples)
+        enc.set_option("stream_piece", piece)
+        enc.set_option("stream_lanes", lanes)
+        first = enc.encode_whole(pcm, capacity=capacity)
+        second = enc.encode_whole(pcm, capacity=capacity)         # the lanes are reused
+        assert first == second
+        return first
+    finally:
+        enc.close()
+
+
+@pytest.mark.parametrize("nch,bits,ms,maxb,piece,lanes", [
+    (1, 16, 0, 4096, 1024, 1), (1, 16, 0, 4096, 20000, 2), (2, 16, 1, 4096, 40000, 3), (2, 24, 1, 2048, 9000, 4),
+    (8, 24, 0, 8192, 300000, 3), (3, 16, 0, 16384, 1024, 2)])
+def test_streamed_encode_whole(oracle, hip, nch, bits, ms, maxb, piece, lanes):
+    """a file long enough for several pieces: upload, analysis, pack and download of different pieces overlap on the
+    worker lanes; the bytes are the oracle's.  Silence runs lie across piece borders (the hop must carry over), start
+    pieces, fill whole pieces"""
+    rng = np.random.default_rng(nch * 100 + lanes)
+    n = 40 * maxb + 777
+    pcm = W.music_like(nch, n, bits, seed=piece % 97)
+    per = max((piece // nch + 63) // 64 * 64, (2 * maxb + 63) // 64 * 64)
+    for k in range(1, n // per + 1):
+        if k % 3 == 1:
+            pcm[:, k * per - 1500:k * per + 900] = 0              # across the border
+        elif k % 3 == 2:
+            pcm[:, k * per:k * per + int(rng.integers(1, 3 * maxb))] = 0
+    if n > 5 * per:
+        pcm[:, 3 * per - 10:4 * per + 10] = 0                     # a whole piece and more
+    pcm = np.ascontiguousarray(pcm)
+    p = S.make_params(nch, bits, 48000, parcor=16, ltm=3, lms=8, ms=ms, max_block=maxb)
+    ret, want, _ = oracle.encode_trace(p, pcm)
+    assert ret == 0
+    assert _streamed(hip, p, pcm, piece, lanes) == want
+
+
+def test_streamed_pieces_disagree_on_offset_lshift(oracle, hip):
+    """offset_lshift belongs to the whole file: piece 0 speaks for it.  Later samples with lower bits set, or a silent
+    piece 0, send the file down the plain path -- the oracle's bytes either way"""
+    maxb, n = 4096, 30 * 4096
+    p = S.make_params(2, 24, 48000, parcor=8, ltm=1, lms=8, ms=0, max_block=maxb)
+    base = W.music_like(2, n, 24, seed=5)
+    coarse = (base >> 12) << 12                                   # 20 significant bits ...
+    mixed = coarse.copy()
+    mixed[:, 20 * maxb:] = base[:, 20 * maxb:]                    # ... then all 24 from the 20th block on
+    late = np.zeros_like(base)
+    late[:, 9 * maxb:] = base[:, 9 * maxb:]                       # piece 0 is silent
+    finer_first = base.copy()
+    finer_first[:, 10 * maxb:] = coarse[:, 10 * maxb:]            # piece 0 has the lowest bit: later pieces agree with it
+    for pcm in (mixed, late, finer_first, coarse):
+        pcm = np.ascontiguousarray(pcm)
+        ret, want, _ = oracle.encode_trace(p, pcm)
+        assert ret == 0
+        assert _streamed(hip, p, pcm, 16384, 3) == want
+
+
+def test_streamed_buffer_too_small(oracle, hip):
+    pcm = W.music_like(2, 30 * 4096, 16, seed=8)
+    p = S.make_params(2, 16, 48000, parcor=8, ltm=1, lms=8, ms=1, max_block=4096)
+    ret, want, _ = oracle.encode_trace(p, pcm)
+    assert ret == 0
+    for cap in (len(want) - 1, len(want) // 2, 43, 44 + 100):
+        with pytest.raises(hip.SlaError) as err:
+            _streamed(hip, p, pcm, 16384, 3, capacity=cap)
+        assert err.value.code == 4, cap                            # SLA_APIRESULT_INSUFFICIENT_BUFFER_SIZE
+    assert _streamed(hip, p, pcm, 16384, 3, capacity=len(want)) == want
+
+
 # ------------------------------------------------------------------ BASELINE sizes: size-independent properties
 
 def _full_size_check(oracle, hip, p, pcm, prefix_frames):
@@ -933,9 +1018,15 @@ def _full_length_check(oracle, hip, p, cap, nch, n, bits, rate, prefix_frames):
     enc.set_wave_format(nch, bits, rate)
     enc.set_encode_parameter(p.parcor_order, p.longterm_order, p.lms_order, p.ch_process_method, p.window_type, p.max_block_samples)
     out = np.zeros(min(4 * nch * n + 65536, 0xFFFFFFF0), np.uint8)      # the API's sizes are 32-bit
-    data = enc.encode_whole(pcm, out=out)
+    data = enc.encode_whole(pcm, out=out)                               # streamed: pieces on worker lanes
     t2 = time.time()
+    enc.set_option("stream", 0)
+    plain = enc.encode_whole(pcm, out=np.zeros(len(data) + 65536, np.uint8))
+    t2b = time.time()
+    assert len(plain) == len(data) and np.array_equal(plain, data)
+    del plain
     enc.close()
+    print("streamed %.3f s, plain %.3f s" % (t2 - t1, t2b - t2))
     dec = hip.Decoder(cap[0], cap[1], cap[2], cap[3], cap[4])
     rc, back = dec.decode_whole(data, n)
     t3 = time.time()
