@@ -465,7 +465,14 @@ int sla_hip_get_trace(struct SLAEncoder* encoder, sla_hip_trace* trace);
  * windows over that limit, default 64; 0: no certificate, such windows are rerun as serial chains) [SLA_HIP_CERT],
  * "device_plan" (0: partitions decided on the host) [SLA_HIP_PLAN=host],
  * "plan_margin" [SLA_HIP_PLAN_MARGIN], "lpc_blocks_chains" [SLA_HIP_LPC_BLOCKS=chains], "fuse_lattice"
- * [SLA_HIP_LATTICE=fused].  Returns SLA_APIRESULT_INVALID_ARGUMENT for an unknown name or a value out of range. */
+ * [SLA_HIP_LATTICE=fused], "device_ltm" (0: long-term pitch + taps solved on the host threads from the downloaded
+ * autocorrelations, one k_tail per pipeline chunk) [SLA_HIP_LTM=host], "single_tail" (0: one k_tail per pipeline chunk
+ * instead of one for the file) [SLA_HIP_SINGLE_TAIL], "first_chunk" (1/1000 of the super-frames in pipeline chunk 0;
+ * 0: built-in shares).  SLAEncoder_EncodeWhole of long files: "stream" (0: never streamed) [SLA_HIP_STREAM],
+ * "stream_piece" (samples per piece, all channels together; default 32 Mi; a file of fewer than two pieces is not
+ * streamed), "stream_lanes" (worker lanes, 1..4, default 4).  After a streamed call the handle holds no analysis tables:
+ * sla_hip_get_trace / sla_hip_pack / sla_hip_final_residual answer SLA_APIRESULT_PARAMETER_NOT_SET (NULL).
+ * Returns SLA_APIRESULT_INVALID_ARGUMENT for an unknown name or a value out of range. */
 int sla_hip_encoder_set_option(struct SLAEncoder* encoder, const char* name, double value);
 
 /* Name of the device the library bound to ("" when none). */
