@@ -91,6 +91,7 @@ struct SLAEncoder {
   size_t nz_ones_cap; uint64_t nz_ones_words;    /* h_nz words [0, nz_ones_words) are known to be all ones (h_nz.cap == nz_ones_cap) */
   pinbuf_t h_stage[2]; devbuf_t d_stage[2]; hipEvent_t ev_stage[2];
   hipEvent_t ev_prep;               /* the prepass result has reached the host */
+  hipEvent_t ev_pack[4];            /* device pack: the blocks of a quarter of the image are written and checksummed */
 
   /* window pool: tables for every block length seen so far */
   double*   win_host; size_t win_count, win_cap;
@@ -324,6 +325,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { if (hipEventCreate(&e->ev[i]) != hipSuccess) { goto fail; } }
   if (hipEventCreate(&e->ev_stage[0]) != hipSuccess || hipEventCreate(&e->ev_stage[1]) != hipSuccess
       || hipEventCreate(&e->ev_prep) != hipSuccess) { goto fail; }
+  for (i = 0; i < 4; i++) { if (hipEventCreate(&e->ev_pack[i]) != hipSuccess) { goto fail; } }
   /* every knob is read here, once; sla_hip_encoder_set_option changes them afterwards */
   /* one chunk: every stage of the pipeline ends in a kernel whose duration is one block's serial chain (LMS, Rice walk),
    * paid once per chunk; A/B on one box in round 2 -- C2 3.34 / 3.44 / 3.90 ms per step with 1 / 2 / 3 chunks, C3-600 s
@@ -449,6 +451,7 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   }
   for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { if (e->ev[i] != NULL) { (void)hipEventDestroy(e->ev[i]); } }
   if (e->ev_prep != NULL) { (void)hipEventDestroy(e->ev_prep); }
+  for (i = 0; i < 4; i++) { if (e->ev_pack[i] != NULL) { (void)hipEventDestroy(e->ev_pack[i]); } }
   if (e->own_copy_streams) {
     if (e->stream_up != NULL) { (void)hipStreamDestroy(e->stream_up); }
     if (e->stream_down != NULL) { (void)hipStreamDestroy(e->stream_down); }
@@ -1688,6 +1691,7 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   if (strcmp(name, "lpc_pack") == 0)               { OPT_RANGE(0, 4); e->tune.lpc_pack = (uint32_t)iv; }
   else if (strcmp(name, "lpc_threads") == 0)       { if (iv != 0 && iv != 256 && iv != 512) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.lpc_threads = (uint32_t)iv; }
   else if (strcmp(name, "tail_waves") == 0)        { OPT_RANGE(0, 4); e->tune.tail_waves = (uint32_t)iv; }
+  else if (strcmp(name, "tail_lanes") == 0)        { OPT_RANGE(0, 2); e->tune.tail_lanes = (uint32_t)iv; }
   else if (strcmp(name, "lpc_blocks_chains") == 0) { OPT_RANGE(0, 1); e->tune.lpc_blocks_chains = (uint32_t)iv; if (iv) { e->fuse_lattice = 0; } }
   else if (strcmp(name, "plan_margin") == 0)       { if (value < 0.0) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.plan_margin = value; }
   else if (strcmp(name, "chunks") == 0)            { OPT_RANGE(1, 8); e->chunks = (uint32_t)iv; e->split_count = 0; e->chunks_forced = 1; }
@@ -1986,6 +1990,7 @@ int sla_hip_pack(struct SLAEncoder* e, uint8_t* data, uint32_t data_size, uint32
  * packs the few header bytes of every block (it owns the per-block parameters), turns the per-channel
  * bit counts into block sizes/offsets, and writes the 43-byte file header. */
 static int download_bytes(struct SLAEncoder* e, uint8_t* dst, const uint8_t* d_src, size_t bytes);
+static int download_bytes_after(struct SLAEncoder* e, uint8_t* dst, const uint8_t* d_src, size_t bytes, hipEvent_t after);
 
 /* One output file of a pack pass: the blocks that start inside [lo, hi) of the planes. */
 typedef struct {
@@ -2002,6 +2007,50 @@ typedef struct {
 } pack_seg_t;
 
 static int download_bytes(struct SLAEncoder* e, uint8_t* dst, const uint8_t* d_src, size_t bytes);
+
+typedef struct {
+  struct SLAEncoder* e; sla_hip_pack_block* pb; sla_hip_rice_job* jobs; uint8_t* hdr; const uint32_t* job_of; int bad;
+} pack_hdr_ctx_t;
+
+/* header bytes and Rice jobs of one block, at the places pack_device_core laid out */
+static void pack_hdr_one(void* vctx, uint32_t b)
+{
+  pack_hdr_ctx_t* c = (pack_hdr_ctx_t*)vctx;
+  struct SLAEncoder* e = c->e;
+  const uint32_t C = e->wave_format.num_channels, O1 = e->encode_param.parcor_order + 1;
+  const blk_t* k = &e->blk[b];
+  sla_hip_pack_block* pb = &c->pb[b];
+  slai_block_params bp;
+  uint32_t rshift[SLAI_MAX_CHANNELS], pitch[SLAI_MAX_CHANNELS], rice[SLAI_MAX_CHANNELS], ch;
+  int32_t ltm[SLAI_MAX_CHANNELS * SLAI_MAX_TAPS];
+  uint8_t tmp[16];
+  memset(&bp, 0, sizeof(bp));
+  bp.num_samples = k->nsmpl; bp.type = k->type; bp.num_channels = C; bp.order = O1 - 1;
+  bp.ntaps = e->encode_param.longterm_order; bp.bps = e->wave_format.bit_per_sample; bp.lshift = e->lshift;
+  bp.mid_side = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
+  for (ch = 0; ch < C; ch++) {
+    const blkch_t* bc = &e->bc[(size_t)b * C + ch];
+    rshift[ch] = bc->rshift; pitch[ch] = bc->pitch; rice[ch] = bc->rice_init;
+    memcpy(&ltm[ch * SLAI_MAX_TAPS], bc->ltm_q, sizeof(int32_t) * SLAI_MAX_TAPS);
+  }
+  bp.code = e->code + (size_t)b * C * O1; bp.rshift = rshift; bp.pitch = pitch; bp.ltm_q = ltm; bp.rice_init = rice;
+  pb->blk_off = k->start; pb->num_samples = k->nsmpl; pb->type = k->type;
+  if (pb->header_bytes >= 16) {
+    if (slai_pack_header(&bp, c->hdr + pb->header_off, pb->header_bytes) != pb->header_bytes) { c->bad = 1; return; }
+  } else {                                      /* (the packer wants 16 bytes of room: a silent block's header has 11) */
+    const uint32_t got = slai_pack_header(&bp, tmp, sizeof(tmp));
+    if (got != pb->header_bytes) { c->bad = 1; return; }
+    memcpy(c->hdr + pb->header_off, tmp, got);
+  }
+  pb->raw_bits = bp.bps - e->lshift;
+  if (k->type == SLAI_BLK_COMPRESS) {
+    slai_coding_mode(rice, C, pb->golomb_m);
+    for (ch = 0; ch < C; ch++) {
+      sla_hip_rice_job* j = &c->jobs[c->job_of[b] + ch];
+      j->blk_off = k->start; j->blk_len = k->nsmpl; j->channel = ch; j->rice_init = rice[ch]; j->golomb_m = pb->golomb_m[ch];
+    }
+  }
+}
 
 /* Rice code lengths, block assembly and CRC16 on the device for every file of the analysed planes (segs sorted by
  * position, blocks are), one image holding the files back to back; each file is then copied to its buffer and gets
@@ -2026,37 +2075,32 @@ static int pack_device_core(struct SLAEncoder* e, pack_seg_t* segs, uint32_t nse
 
   const double tp0 = now_ms();
   double tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0;
-  /* per block: header bytes, coding mode, Rice jobs */
-  for (b = 0; b < nb; b++) {
-    const blk_t* k = &e->blk[b];
-    slai_block_params bp;
-    uint32_t rshift[SLAI_MAX_CHANNELS], pitch[SLAI_MAX_CHANNELS], rice[SLAI_MAX_CHANNELS];
-    int32_t ltm[SLAI_MAX_CHANNELS * SLAI_MAX_TAPS];
-    memset(&bp, 0, sizeof(bp));
-    bp.num_samples = k->nsmpl; bp.type = k->type; bp.num_channels = C; bp.order = O1 - 1;
-    bp.ntaps = e->encode_param.longterm_order; bp.bps = e->wave_format.bit_per_sample; bp.lshift = e->lshift;
-    bp.mid_side = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
-    for (ch = 0; ch < C; ch++) {
-      const blkch_t* bc = &e->bc[(size_t)b * C + ch];
-      rshift[ch] = bc->rshift; pitch[ch] = bc->pitch; rice[ch] = bc->rice_init;
-      memcpy(&ltm[ch * SLAI_MAX_TAPS], bc->ltm_q, sizeof(int32_t) * SLAI_MAX_TAPS);
-    }
-    bp.code = e->code + (size_t)b * C * O1; bp.rshift = rshift; bp.pitch = pitch; bp.ltm_q = ltm; bp.rice_init = rice;
-    memset(&pb[b], 0, sizeof(pb[b]));
-    pb[b].blk_off = k->start; pb[b].num_samples = k->nsmpl; pb[b].type = k->type;
-    pb[b].header_off = (uint32_t)hdr_used;
-    pb[b].header_bytes = slai_pack_header(&bp, hdr + hdr_used, (uint32_t)(hdr_cap - hdr_used));
-    if (pb[b].header_bytes == 0) { free(job_of); return SLA_APIRESULT_NG; }
-    hdr_used += pb[b].header_bytes;
-    pb[b].raw_bits = bp.bps - e->lshift;
-    job_of[b] = njobs;
-    if (k->type == SLAI_BLK_COMPRESS) {
-      slai_coding_mode(rice, C, pb[b].golomb_m);
-      for (ch = 0; ch < C; ch++) {
-        sla_hip_rice_job* j = &jobs[njobs++];
-        j->blk_off = k->start; j->blk_len = k->nsmpl; j->channel = ch; j->rice_init = rice[ch]; j->golomb_m = pb[b].golomb_m[ch];
+  /* per block: header bytes, coding mode, Rice jobs.  Sizes and places first (arithmetic only), then the host threads
+   * write the headers and job records side by side */
+  {
+    const uint32_t order = O1 - 1, ntaps = e->encode_param.longterm_order, bps = e->wave_format.bit_per_sample;
+    const uint32_t coef_bits = 16 * (order < 3 ? order : 3) + 8 * (order > 3 ? order - 3 : 0);
+    pack_hdr_ctx_t hc;
+    for (b = 0; b < nb; b++) {
+      const blk_t* k = &e->blk[b];
+      uint32_t bits = 16 + 32 + 16 + 16 + 2;                    /* src/SLAEncoder.c:682-741 */
+      memset(&pb[b], 0, sizeof(pb[b]));
+      if (k->type == SLAI_BLK_COMPRESS) {
+        for (ch = 0; ch < C; ch++) {
+          bits += 4 + coef_bits + 1 + bps;
+          if (e->bc[(size_t)b * C + ch].pitch >= SLAI_LTM_MIN_PITCH) { bits += SLAI_LTM_PERIOD_BITS + 16 * ntaps; }
+        }
       }
+      pb[b].header_off = (uint32_t)hdr_used;
+      pb[b].header_bytes = (bits + 7) / 8;
+      hdr_used += pb[b].header_bytes;
+      job_of[b] = njobs;
+      if (k->type == SLAI_BLK_COMPRESS) { njobs += C; }
     }
+    if (hdr_used > hdr_cap) { free(job_of); return SLA_APIRESULT_NG; }
+    hc.e = e; hc.pb = pb; hc.jobs = jobs; hc.hdr = hdr; hc.job_of = job_of; hc.bad = 0;
+    parallel_for(e->pool, nb, pack_hdr_one, &hc);
+    if (hc.bad) { free(job_of); return SLA_APIRESULT_NG; }
   }
 
   tp1 = now_ms();
@@ -2128,19 +2172,45 @@ static int pack_device_core(struct SLAEncoder* e, pack_seg_t* segs, uint32_t nse
     RCCHK(dev_reserve(&e->d_pk_hdr, hdr_used + 16));
     if (e->d_kk.ptr == NULL) { RCCHK(dev_reserve(&e->d_kk, sizeof(uint16_t) * (size_t)C * e->stride)); }
     HIPCHK(hipMemsetAsync(e->d_image.ptr, 0, img_bytes, e->stream));
+    /* one file of some size: the blocks are written in up to four runs of about equal bytes, and a run's bytes leave
+     * on the download stream while the next run is written (blocks are byte-aligned and only ever OR into their own
+     * bytes, so a finished run is final even where it shares a word with its neighbour) */
+    uint32_t nruns = (nsegs == 1 && nb >= 64 && cur >= (8u << 20)) ? 4u : 1u, run_lo[5], r;
+    run_lo[0] = 0;
+    for (r = 1; r < nruns; r++) {
+      uint32_t lo = run_lo[r - 1], hi = nb;
+      const uint64_t want = segs[0].img_off + (cur - segs[0].img_off) * r / nruns;
+      while (lo < hi) { const uint32_t m = (lo + hi) / 2; if (pb[m].out_off < want) { lo = m + 1; } else { hi = m; } }
+      run_lo[r] = lo;
+    }
+    run_lo[nruns] = nb;
     if (nb > 0) {
       HIPCHK(hipMemcpyAsync(e->d_pk_blocks.ptr, pb, sizeof(sla_hip_pack_block) * nb, hipMemcpyHostToDevice, e->stream));
       HIPCHK(hipMemcpyAsync(e->d_pk_hdr.ptr, hdr, hdr_used, hipMemcpyHostToDevice, e->stream));
-      RCCHK(sla_hip_launch_rice_write(RES2(e), e->pcm_dev, e->stride, (const uint16_t*)e->d_kk.ptr,
-                                      (const sla_hip_pack_block*)e->d_pk_blocks.ptr, nb, (const uint8_t*)e->d_pk_hdr.ptr, C,
-                                      32 - e->wave_format.bit_per_sample + e->lshift,
-                                      e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS,
-                                      (uint32_t*)e->d_image.ptr, e->stream));
+      for (r = 0; r < nruns; r++) {
+        if (run_lo[r + 1] > run_lo[r]) {
+          RCCHK(sla_hip_launch_rice_write(RES2(e), e->pcm_dev, e->stride, (const uint16_t*)e->d_kk.ptr,
+                                          (const sla_hip_pack_block*)e->d_pk_blocks.ptr + run_lo[r], run_lo[r + 1] - run_lo[r],
+                                          (const uint8_t*)e->d_pk_hdr.ptr, C, 32 - e->wave_format.bit_per_sample + e->lshift,
+                                          e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS,
+                                          (uint32_t*)e->d_image.ptr, e->stream));
+        }
+        if (nruns > 1) { HIPCHK(hipEventRecord(e->ev_pack[r], e->stream)); }
+      }
     }
     tp3 = now_ms();
-    for (sg = 0; sg < nsegs; sg++) {
-      if (segs[sg].result != 0) { continue; }
-      RCCHK(download_bytes(e, segs[sg].data, (const uint8_t*)e->d_image.ptr + segs[sg].img_off, (size_t)segs[sg].out_size));
+    if (nruns > 1 && segs[0].result == 0) {
+      for (r = 0; r < nruns; r++) {
+        const uint64_t from = (r == 0) ? segs[0].img_off : pb[run_lo[r]].out_off;
+        const uint64_t upto = (r + 1 == nruns || run_lo[r + 1] >= nb) ? cur : pb[run_lo[r + 1]].out_off;
+        if (r > 0 && run_lo[r] >= nb) { break; }
+        RCCHK(download_bytes_after(e, segs[0].data + (from - segs[0].img_off), (const uint8_t*)e->d_image.ptr + from, (size_t)(upto - from), e->ev_pack[r]));
+      }
+    } else {
+      for (sg = 0; sg < nsegs; sg++) {
+        if (segs[sg].result != 0) { continue; }
+        RCCHK(download_bytes(e, segs[sg].data, (const uint8_t*)e->d_image.ptr + segs[sg].img_off, (size_t)segs[sg].out_size));
+      }
     }
     tp4 = now_ms();
   }
@@ -2288,17 +2358,22 @@ static void stage_out_one(void* vctx, uint32_t i)
   memcpy(c->dst + lo, c->src + lo, hi - lo);
 }
 
-/* device -> pageable host, double-buffered through the pinned slots */
-static int download_bytes(struct SLAEncoder* e, uint8_t* dst, const uint8_t* d_src, size_t bytes)
+/* device -> host: page-locked destinations by DMA, pageable ones double-buffered through the pinned slots.  `after` (may
+ * be NULL): the copies run on the download stream once that event has happened, beside later kernels of the handle's
+ * main stream; without it they follow whatever the main stream holds */
+static int download_bytes_after(struct SLAEncoder* e, uint8_t* dst, const uint8_t* d_src, size_t bytes, hipEvent_t after)
 {
   size_t o, k = 0, nslots = (bytes + XFER_SLOT_BYTES - 1) / XFER_SLOT_BYTES;
+  hipStream_t st = (after != NULL) ? e->stream_down : e->stream;
   stage_out_t ctx;
   uint32_t s;
+  if (bytes == 0) { return 0; }
+  if (after != NULL) { HIPCHK(hipStreamWaitEvent(st, after, 0)); }
   if (is_pinned_host(dst, bytes)) {            /* page-locked destination: straight DMA */
     for (o = 0; o < bytes; o += XFER_SLOT_BYTES) {
-      HIPCHK(hipMemcpyAsync(dst + o, d_src + o, (bytes - o < XFER_SLOT_BYTES) ? (bytes - o) : XFER_SLOT_BYTES, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync(dst + o, d_src + o, (bytes - o < XFER_SLOT_BYTES) ? (bytes - o) : XFER_SLOT_BYTES, hipMemcpyDeviceToHost, st));
     }
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipStreamSynchronize(st));
     return 0;
   }
   for (s = 0; s < 2; s++) { RCCHK(pin_reserve(&e->h_stage[s], XFER_SLOT_BYTES)); }
@@ -2306,8 +2381,8 @@ static int download_bytes(struct SLAEncoder* e, uint8_t* dst, const uint8_t* d_s
     if (k < nslots) {
       o = k * XFER_SLOT_BYTES;
       HIPCHK(hipMemcpyAsync(e->h_stage[k & 1].ptr, d_src + o, (bytes - o < XFER_SLOT_BYTES) ? (bytes - o) : XFER_SLOT_BYTES,
-                            hipMemcpyDeviceToHost, e->stream));
-      HIPCHK(hipEventRecord(e->ev_stage[k & 1], e->stream));
+                            hipMemcpyDeviceToHost, st));
+      HIPCHK(hipEventRecord(e->ev_stage[k & 1], st));
     }
     if (k >= 1) {
       o = (k - 1) * XFER_SLOT_BYTES;
@@ -2318,6 +2393,11 @@ static int download_bytes(struct SLAEncoder* e, uint8_t* dst, const uint8_t* d_s
     }
   }
   return 0;
+}
+
+static int download_bytes(struct SLAEncoder* e, uint8_t* dst, const uint8_t* d_src, size_t bytes)
+{
+  return download_bytes_after(e, dst, d_src, bytes, NULL);
 }
 
 /* ---- SLAEncoder_EncodeWhole of a long file, streamed ------------------------------------------------------------

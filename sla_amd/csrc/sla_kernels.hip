@@ -1409,7 +1409,7 @@ __device__ __forceinline__ uint32_t group_sum(uint32_t x)
 {
   x += dpp_u32<0xB1>(x);                       // quad_perm [1,0,3,2]   lane ^ 1
   x += dpp_u32<0x4E>(x);                       // quad_perm [2,3,0,1]   lane ^ 2
-  x += dpp_u32<0x141>(x);                      // row_half_mirror       other quad of the 8
+  if (G >= 8) { x += dpp_u32<0x141>(x); }      // row_half_mirror       other quad of the 8
   if (G >= 16) { x += dpp_u32<0x140>(x); }     // row_mirror            other half of the 16
   if (G >= 32) { x += (uint32_t)__shfl_xor((int)x, 16); }
   if (G >= 64) { x += (uint32_t)__shfl_xor((int)x, 32); }
@@ -1520,6 +1520,120 @@ void k_tail(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, u
     }
   }
   // sum of the lanes' partial folded sums
+#pragma unroll
+  for (int off = 1; off < G; off <<= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)fsum, off);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(fsum >> 32), off);
+    fsum += ((uint64_t)hi << 32) | lo;
+  }
+  if (have && t == 0) { fold_sum[j] = fsum; }
+  span_end(span);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tail2: the same stage with TWO coefficients per lane.  The cascade is 2*ORDER taps -- ORDER on the input history,
+// ORDER on the prediction history -- that differ only in what is shifted into their history; a lane owns tap t of both
+// halves, so a job takes ORDER lanes and a wave carries twice as many jobs.  The kernel is bound by instruction issue
+// (k_tail: ~25 instructions per sample and wave, 1.7 - 7 waves per SIMD on the bench configurations), and the second
+// tap costs a lane 5 instructions more (product, two sign products, update, history shift) while it saves the other
+// wave's 25 -- and one step of the DPP sum.
+// ---------------------------------------------------------------------------------------------
+template <int ORDER, bool FIRST>
+__device__ __forceinline__ int32_t tail_block2(int32_t v_mine, uint32_t grp_base, bool is_head, uint32_t t,
+                                               int32_t& ca, int32_t& cb, int32_t& ha, int32_t& hb)
+{
+  constexpr int G = ORDER;
+  int32_t e_mine = 0;
+  int32_t vs[G];
+#pragma unroll
+  for (int u = 0; u < G; u++) { vs[u] = __shfl(v_mine, (int)(grp_base + u)); }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < G; u++) {
+    const int32_t v = vs[u];
+    int32_t e, ph;
+    if (FIRST) {
+      e = v; ph = v;                                   // the first ORDER samples only prime both histories
+    } else {
+      const int32_t sa = sgn(ha), sb = sgn(hb);
+      const uint32_t sum = group_sum<G>((uint32_t)ca * (uint32_t)ha + (uint32_t)cb * (uint32_t)hb) + (1u << 9);
+      const int32_t p = (int32_t)sum >> 10;
+      e = (int32_t)((uint32_t)v - (uint32_t)p);
+      const int32_t ne = (int32_t)((uint32_t)p - (uint32_t)v);
+      const uint32_t mag = (uint32_t)max(e, ne);
+      const int32_t lg = 32 - (int32_t)__clz((int)mag);
+      const int32_t se = sgn(e);
+      ca = mad24(__mul24(se, sa), lg >> 1, ca);
+      cb = mad24(__mul24(se, sb), lg >> 1, cb);
+      ph = p;
+    }
+    // histories: lane t takes lane t-1; the job's first lane takes the new input / the new prediction
+    if (G <= 16) {
+      ha = (int32_t)__builtin_amdgcn_update_dpp(v, ha, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
+      hb = (int32_t)__builtin_amdgcn_update_dpp(ph, hb, 0x111, 0xF, 0xF, false);
+    } else {
+      ha = (int32_t)__builtin_amdgcn_update_dpp(v, ha, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+      hb = (int32_t)__builtin_amdgcn_update_dpp(ph, hb, 0x138, 0xF, 0xF, false);
+    }
+    if (G != 16) { ha = is_head ? v : ha; hb = is_head ? ph : hb; }      // (a 16-lane job is one DPP row: its lane 0 got `old`)
+    e_mine = (t == (uint32_t)u) ? e : e_mine;
+  }
+  return e_mine;
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(256)
+void k_tail2(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, uint64_t stride,
+             const sla_hip_tail_job* __restrict__ jobs, uint32_t num_jobs, uint32_t ntaps,
+             uint64_t* __restrict__ fold_sum, unsigned long long* span, uint32_t stage_flags)
+{
+  span_begin(span);
+  constexpr int G = ORDER;                     // lanes per job
+  constexpr int JPW = 64 / G;                  // jobs per wave
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t t = lane & (G - 1);
+  const uint32_t grp_base = lane - t;
+  const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t j = wave * JPW + (lane / G);
+  const bool have = (j < num_jobs);
+  const sla_hip_tail_job job = jobs[have ? j : 0];
+  const uint32_t n = have ? job.blk_len : 0;
+  const int32_t* in = res_in + (uint64_t)job.channel * stride + job.blk_off;
+  int32_t* out = res_out + (uint64_t)job.channel * stride + job.blk_off;
+  const uint32_t delay = job.pitch + (ntaps >> 1);
+  const bool use_ltm = (job.pitch >= 3);
+  const bool short_job = (n < (uint32_t)ORDER);      // fewer samples than taps: everything passes through
+  const bool is_head = (t == 0);
+  const uint32_t nmax = umax_wave(n);
+
+  auto fetch = [&](uint32_t s) -> int32_t {          // src/SLAPredictor.c:1063-1099
+    int32_t v = 0;
+    if (s < n) {
+      v = in[s];
+      if (use_ltm && s >= delay) {
+        int64_t acc = (int64_t)1 << 30;
+        for (uint32_t k = 0; k < ntaps; k++) { acc += (int64_t)job.ltm_coef[k] * (int64_t)in[s - delay + k]; }
+        v = (int32_t)((uint32_t)v - (uint32_t)(int32_t)(acc >> 31));
+      }
+    }
+    return v;
+  };
+
+  int32_t ca = 0, cb = 0, ha = 0, hb = 0;
+  uint64_t fsum = 0;
+  int32_t v_next = fetch(t);
+  for (uint32_t s0 = 0; s0 < nmax; s0 += G) {
+    const int32_t v_mine = v_next;
+    v_next = fetch(s0 + G + t);
+    int32_t e_mine = (s0 == 0) ? tail_block2<ORDER, true>(v_mine, grp_base, is_head, t, ca, cb, ha, hb)
+                               : tail_block2<ORDER, false>(v_mine, grp_base, is_head, t, ca, cb, ha, hb);
+    e_mine = (short_job || (stage_flags & 1u)) ? v_mine : e_mine;
+    const uint32_t s = s0 + t;
+    if (s < n) {
+      out[s] = e_mine;
+      fsum += (e_mine < 0) ? ~((uint32_t)e_mine << 1) : ((uint32_t)e_mine << 1);
+    }
+  }
 #pragma unroll
   for (int off = 1; off < G; off <<= 1) {
     const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)fsum, off);
@@ -2343,10 +2457,28 @@ static int launch_tail_impl(const int32_t* d_res_in, int32_t* d_res_out, uint64_
   if (num_jobs == 0) { return 0; }
   const uint32_t tw = tuning().tail_waves;
   const uint32_t tail_waves = (tw >= 1 && tw <= 4) ? tw : 1u;     /* one wave per workgroup: the dispatcher spreads the (few, long-running) waves over all CUs */
-  const uint32_t jobs_per_block = tail_waves * (64 / (2 * lms_order));     // 64/(2*order) jobs per wave
-  dim3 grid((num_jobs + jobs_per_block - 1) / (jobs_per_block ? jobs_per_block : 1)), block(64 * tail_waves);
   hipStream_t st = (hipStream_t)stream;
   unsigned long long* span = take_span();
+  /* One tap per lane (k_tail) has the shorter dependent chain per sample -- one quarter-rate 32-bit multiply instead of
+   * two -- and wins while the SIMDs hold a few waves each (C2: 1.7 waves per SIMD, 0.44 against 0.59 ms; C5-120 s: 1.30
+   * against 1.48); two taps per lane (k_tail2) halve the waves and win once instruction issue is the limit (C3-600 s:
+   * 6.9 waves per SIMD, 1.01 -> 0.79 ms).  Automatic: k_tail2 above five one-tap waves per SIMD of an MI355X. */
+  const uint32_t one_tap_waves = (num_jobs + (64 / (2 * lms_order)) - 1) / (64 / (2 * lms_order));
+  const uint32_t lanes_knob = tuning().tail_lanes;
+  if (lanes_knob == 1 || (lanes_knob == 0 && one_tap_waves > 5u * 1024u)) {      /* two taps per lane: `order` lanes per job */
+    const uint32_t jpb = tail_waves * (64 / lms_order);
+    dim3 grid2((num_jobs + jpb - 1) / jpb), block2(64 * tail_waves);
+    switch (lms_order) {
+      case 4:  hipLaunchKernelGGL(k_tail2<4>,  grid2, block2, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
+      case 8:  hipLaunchKernelGGL(k_tail2<8>,  grid2, block2, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
+      case 16: hipLaunchKernelGGL(k_tail2<16>, grid2, block2, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
+      case 32: hipLaunchKernelGGL(k_tail2<32>, grid2, block2, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
+      default: return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY;
+    }
+    return hip_rc(hipGetLastError());
+  }
+  const uint32_t jobs_per_block = tail_waves * (64 / (2 * lms_order));     // 64/(2*order) jobs per wave
+  dim3 grid((num_jobs + jobs_per_block - 1) / (jobs_per_block ? jobs_per_block : 1)), block(64 * tail_waves);
   switch (lms_order) {
     case 4:  hipLaunchKernelGGL(k_tail<4>,  grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
     case 8:  hipLaunchKernelGGL(k_tail<8>,  grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;

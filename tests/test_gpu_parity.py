@@ -45,6 +45,7 @@ def hip_encode(hip, p, pcm, want_residuals=True):
             enc.set_option("stream", 1)
             enc.set_option("stream_piece", 1024)
             enc.set_option("stream_lanes", 1 + (n // 7) % 4)
+            enc.set_option("tail_lanes", 1 + (n // 5) % 2)               # both layouts of the tail kernel take turns
             again = enc.encode_whole(pcm)
             assert again == data, "streamed EncodeWhole differs from the plain path"
         return data, tr
@@ -154,7 +155,11 @@ def test_window_types(oracle, hip, wtype):
 def test_tail_orders(oracle, hip, lms, ltm):
     pcm = W.music_like(2, 20000, 24, seed=lms + ltm)
     p = S.make_params(2, 24, 48000, 16, ltm, lms, 1, 1, 4096)
-    assert_same_as_oracle(oracle, hip, p, pcm)
+    want = assert_same_as_oracle(oracle, hip, p, pcm)             # one tap per lane (k_tail: the choice for few jobs)
+    got, _ = _encode_with_options(hip, p, pcm, tail_lanes=1)      # two taps per lane (k_tail2)
+    assert got == want
+    got, _ = _encode_with_options(hip, p, pcm, tail_lanes=1, tail_waves=2, chunks=1)
+    assert got == want
 
 
 def test_pitched_signal_uses_longterm(oracle, hip):

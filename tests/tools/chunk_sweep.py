@@ -15,19 +15,13 @@ import bench          # noqa: E402
 import sla_amd        # noqa: E402
 
 SETTINGS = [
-    {"chunks": 1},
-    {"chunks": 2, "first_chunk": 250},
-    {"chunks": 2, "single_tail": 0},
-    {"chunks": 2, "single_tail": 0, "first_chunk": 250},
-    {"chunks": 2, "single_tail": 0, "first_chunk": 500},
-    {"chunks": 3, "single_tail": 0},
-    {"chunks": 3, "single_tail": 0, "first_chunk": 200},
-    {"chunks": 3, "single_tail": 0, "first_chunk": 333},
-    {"chunks": 4, "single_tail": 0},
-    {"chunks": 4, "single_tail": 0, "first_chunk": 250},
-    {"chunks": 3, "device_ltm": 0, "single_tail": 0},
+    {},
+    {"tail_lanes": 2},
+    {"tail_waves": 2},
+    {"tail_waves": 4},
+    {"tail_lanes": 2, "tail_waves": 2},
 ]
-DEFAULTS = {"chunks": 1, "first_chunk": 0, "single_tail": 1, "device_ltm": 1}
+DEFAULTS = {"chunks": 2, "first_chunk": 0, "single_tail": 1, "device_ltm": 1, "tail_lanes": 0, "tail_waves": 0}
 
 
 def main():
