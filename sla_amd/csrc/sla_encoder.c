@@ -69,6 +69,7 @@ struct SLAEncoder {
   int      chunks_forced;           /* the caller chose the chunk count: no short-file rule */
   uint32_t first_chunk;             /* 1/1000 of the super-frames in chunk 0 (0: built-in shares) */
   int      single_tail;             /* 1: one k_tail launch for all chunks (default) */
+  int      alt_streams;             /* 1: the block stages of odd and even chunks on two streams */
   int      device_ltm;              /* 1: pitch + taps solved on the device, the block stage runs lattice -> tail without the host (default) */
   int      trace;                   /* host-side timeline on stderr (SLA_HIP_TRACE) */
   sla_hip_tuning tune;              /* launcher knobs, named to the launchers at every API entry */
@@ -1175,6 +1176,11 @@ static int tail_enqueue(struct SLAEncoder* e, actx_t* a, uint32_t c, uint32_t lo
   if (!e->single_tail) {
     HIPCHK(hipEventRecord(ev[EV_SOLVED], e->stream2));
     HIPCHK(hipStreamWaitEvent(ts, ev[EV_SOLVED], 0));
+  } else if (e->alt_streams) {
+    uint32_t cc;
+    for (cc = 1; cc < a->nchunks; cc += 2) {
+      if (a->ck[cc].bg_hi > a->ck[cc].bg_lo) { HIPCHK(hipStreamWaitEvent(ts, a->ev[(size_t)cc * EV_PER_CHUNK + EV_SOLVED], 0)); }
+    }
   }
   HIPCHK(hipEventRecord(ev[EV_TAIL_S], ts));
   if (hi > lo) {
@@ -1211,6 +1217,10 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
   hipEvent_t* ev = a->ev + (size_t)c * EV_PER_CHUNK;
   uint32_t b, ch, max_window = 1, ng, nl;
   const int fused = (e->fuse_lattice && order <= 64);
+  /* option alt_streams: odd chunks run their block stage on the third stream, beside the even chunks' (not when the FFT
+   * works in the shared global scratch) */
+  hipStream_t bs = (e->alt_streams && e->device_ltm && e->single_tail && (c & 1u)
+                    && sizeof(double) * (size_t)fft_size <= SLA_HIP_LDS_BUDGET) ? e->stream3 : e->stream2;
   const size_t slot_lo = (size_t)k->blk_lo * C, nsl = (size_t)(k->blk_hi - k->blk_lo) * C;
 
   /* pass 1: what k_lpc_blocks needs (one group per block and channel).  The descriptors of the lattice and FFT
@@ -1238,7 +1248,7 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
   ng = k->bg_hi - k->bg_lo;
   if (e->device_ltm) { k->job_lo = k->bg_lo; k->job_hi = k->bg_hi; a->njobs = a->nbg; }
 
-  if (ng == 0) { k->lc_hi = a->nlc; HIPCHK(hipEventRecord(ev[EV_LPCB_S], e->stream2)); }
+  if (ng == 0) { k->lc_hi = a->nlc; HIPCHK(hipEventRecord(ev[EV_LPCB_S], bs)); }
   if (ng > 0) {
     sla_hip_lpc_group* dg = (sla_hip_lpc_group*)e->d_bgroups.ptr + k->bg_lo;
     sla_hip_lattice_chunk* dl = (sla_hip_lattice_chunk*)e->d_chunks.ptr + k->lc_lo;
@@ -1249,21 +1259,21 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     /* (k_lpc_blocks writes every output slot of its groups; slots of silent blocks are never read) */
     /* uploads and result downloads travel on their own streams: the kernel stream runs kernel after kernel */
     HIPCHK(hipEventRecord(ev[EV_UPLOADED], e->stream_up));
-    HIPCHK(hipStreamWaitEvent(e->stream2, ev[EV_UPLOADED], 0));
-    HIPCHK(hipEventRecord(ev[EV_LPCB_S], e->stream2));
+    HIPCHK(hipStreamWaitEvent(bs, ev[EV_UPLOADED], 0));
+    HIPCHK(hipEventRecord(ev[EV_LPCB_S], bs));
     slai_next_launch_span(SPAN_SLOT(e, c, 0));
     if (fused) {
       RCCHK(sla_hip_launch_lpc_blocks(e->pcm_dev, e->stride, ms, order, dg, ng, max_window,
                                       (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
                                       (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
-                                      (uint32_t*)e->d_rshift.ptr, RES1(e), e->stream2));
+                                      (uint32_t*)e->d_rshift.ptr, RES1(e), bs));
     } else {
       RCCHK(sla_hip_launch_lpc(e->pcm_dev, e->stride, ms, order, dg, ng, max_window, 1,
                                (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
                                (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
-                               (uint32_t*)e->d_rshift.ptr, e->stream2));
+                               (uint32_t*)e->d_rshift.ptr, bs));
     }
-    HIPCHK(hipEventRecord(ev[EV_LPCB_E], e->stream2));
+    HIPCHK(hipEventRecord(ev[EV_LPCB_E], bs));
     /* the LPC results go home while lattice and FFT run: the host decides RAW blocks in the meantime */
     HIPCHK(hipStreamWaitEvent(e->stream_down, ev[EV_LPCB_E], 0));
     HIPCHK(hipMemcpyAsync((double*)e->h_blk_out.ptr + slot_lo * O2, (double*)e->d_blk_out.ptr + slot_lo * O2, sizeof(double) * nsl * O2, hipMemcpyDeviceToHost, e->stream_down));
@@ -1288,36 +1298,37 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
       if (nl > 0) { HIPCHK(hipMemcpyAsync(dl, lch + k->lc_lo, sizeof(sla_hip_lattice_chunk) * nl, hipMemcpyHostToDevice, e->stream_up)); }
       HIPCHK(hipMemcpyAsync(da, acf_jobs + k->bg_lo, sizeof(sla_hip_acf_job) * ng, hipMemcpyHostToDevice, e->stream_up));
       HIPCHK(hipEventRecord(ev[EV_UPLOADED2], e->stream_up));
-      HIPCHK(hipStreamWaitEvent(e->stream2, ev[EV_UPLOADED2], 0));
+      HIPCHK(hipStreamWaitEvent(bs, ev[EV_UPLOADED2], 0));
     }
     if (!fused) {
       slai_next_launch_span(SPAN_SLOT(e, c, 1));
-      RCCHK(sla_hip_launch_lattice_groups(e->pcm_dev, e->stride, ms, order, dg, ng, max_window, (const int32_t*)e->d_kint.ptr, RES1(e), e->stream2));
+      RCCHK(sla_hip_launch_lattice_groups(e->pcm_dev, e->stride, ms, order, dg, ng, max_window, (const int32_t*)e->d_kint.ptr, RES1(e), bs));
     }
-    HIPCHK(hipEventRecord(ev[EV_LAT_E], e->stream2));
+    HIPCHK(hipEventRecord(ev[EV_LAT_E], bs));
     if (sizeof(double) * (size_t)fft_size > SLA_HIP_LDS_BUDGET) { slots = (ng < 512) ? ng : 512; }
-    HIPCHK(hipEventRecord(ev[EV_ACF_S], e->stream2));
+    HIPCHK(hipEventRecord(ev[EV_ACF_S], bs));
     slai_next_launch_span(SPAN_SLOT(e, c, 2));
     RCCHK(sla_hip_launch_ltm_acf(RES1(e), e->stride, da, ng, fft_size, (const double*)e->d_twiddle.ptr,
                                  (double*)e->d_acf_scratch.ptr, slots,
-                                 (double*)e->d_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD, SLAI_LTM_ACF_HEAD, e->stream2));
-    HIPCHK(hipEventRecord(ev[EV_ACF_E], e->stream2));
+                                 (double*)e->d_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD, SLAI_LTM_ACF_HEAD, bs));
+    HIPCHK(hipEventRecord(ev[EV_ACF_E], bs));
     if (e->device_ltm) {
       /* pitch + taps into the job table k_tail reads; the tail follows on the same stream, no host in between */
       RCCHK(sla_hip_launch_ltm_solve((const double*)e->d_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD, dg, ng,
-                                     e->encode_param.longterm_order, (sla_hip_tail_job*)e->d_jobs.ptr + k->bg_lo, e->stream2));
+                                     e->encode_param.longterm_order, (sla_hip_tail_job*)e->d_jobs.ptr + k->bg_lo, bs));
       if (!e->single_tail) { RCCHK(tail_enqueue(e, a, c, k->bg_lo, k->bg_hi)); }
+      else { HIPCHK(hipEventRecord(ev[EV_SOLVED], bs)); }
     } else {
       HIPCHK(hipStreamWaitEvent(e->stream_down, ev[EV_ACF_E], 0));
       HIPCHK(hipMemcpyAsync((double*)e->h_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD, (double*)e->d_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD,
                             sizeof(double) * (size_t)ng * SLAI_LTM_ACF_HEAD, hipMemcpyDeviceToHost, e->stream_down));
     }
   } else {
-    HIPCHK(hipEventRecord(ev[EV_LPCB_E], e->stream2));
+    HIPCHK(hipEventRecord(ev[EV_LPCB_E], bs));
     HIPCHK(hipEventRecord(ev[EV_LPC_DOWN], e->stream_down));
-    HIPCHK(hipEventRecord(ev[EV_LAT_E], e->stream2));
-    HIPCHK(hipEventRecord(ev[EV_ACF_S], e->stream2));
-    HIPCHK(hipEventRecord(ev[EV_ACF_E], e->stream2));
+    HIPCHK(hipEventRecord(ev[EV_LAT_E], bs));
+    HIPCHK(hipEventRecord(ev[EV_ACF_S], bs));
+    HIPCHK(hipEventRecord(ev[EV_ACF_E], bs));
     if (e->device_ltm && !e->single_tail) { RCCHK(tail_enqueue(e, a, c, k->bg_lo, k->bg_lo)); }
   }
   HIPCHK(hipStreamWaitEvent(e->stream_down, ev[EV_ACF_E], 0));
@@ -1704,6 +1715,7 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   else if (strcmp(name, "stream_piece") == 0)      { OPT_RANGE(1024, 1 << 30); e->stream_piece = (uint32_t)iv; }
   else if (strcmp(name, "stream_lanes") == 0)      { OPT_RANGE(1, 4); e->stream_lanes = (uint32_t)iv; }
   else if (strcmp(name, "first_chunk") == 0)       { OPT_RANGE(0, 999); e->first_chunk = (uint32_t)iv; }
+  else if (strcmp(name, "alt_streams") == 0)       { OPT_RANGE(0, 1); e->alt_streams = (int)iv; }
   else if (strcmp(name, "device_ltm") == 0)        { OPT_RANGE(0, 1); e->device_ltm = (int)iv; }
   else if (strcmp(name, "fuse_lattice") == 0)      { OPT_RANGE(0, 1); e->fuse_lattice = (int)iv && !e->tune.lpc_blocks_chains; }
   else if (strcmp(name, "threads") == 0) {

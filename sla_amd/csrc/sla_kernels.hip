@@ -2580,6 +2580,25 @@ __device__ __forceinline__ uint32_t golomb_len(uint32_t v, uint32_t m)
 // instructions one after the other, so every instruction that is not on the recurrence costs as much as one that is:
 // the code lengths -- a function of (value, k0, k1), no state -- are left to k_rice_bits (a 10-second clip: 0.83 ->
 // see DESIGN.md ms for the two kernels).
+// One step of the walk in 32-bit arithmetic.  A parameter never leaves 32 bits (it starts as (uint32)(init << 8) and
+// every step maps p to < 119/128 p + 2^25), but 119 p does: with p = 128 q + r and c = 128 cq + cr
+//   (119 p + c + 64) >> 7  =  119 q + cq + ((119 r + cr + 64) >> 7),
+// every term below 2^32.  c = (uint32)(9 (code << 8)) depends on the sample alone, so only the four operations of the
+// second line sit on the serial chain.
+__device__ __forceinline__ uint32_t rice_adapt32(uint32_t p, uint32_t code)
+{
+  // (measured: spelling 9 x and 119 q as opaque shift-adds instead of the multiplies the compiler picks is slower)
+  const uint32_t c = 9u * (code << 8);
+  const uint32_t q = p >> 7, r = p & 127u;
+  return 119u * q + (c >> 7) + ((119u * r + (c & 127u) + 64u) >> 7);
+}
+__device__ __forceinline__ uint32_t rice_k32(uint32_t p)
+{
+  uint32_t v = ((p >> 1) + 128u) >> 8;
+  v = v ? v : 1u;
+  return ceil_log2_u32(v);
+}
+
 __global__ __launch_bounds__(64)
 void k_rice_k(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_rice_job* __restrict__ jobs,
               uint32_t num_jobs, uint16_t* __restrict__ kk)
@@ -2591,31 +2610,34 @@ void k_rice_k(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_ri
   const int32_t* in = res + (uint64_t)job.channel * stride + job.blk_off;
   uint16_t* ko = kk + (uint64_t)job.channel * stride + job.blk_off;
   const uint32_t n = job.blk_len;
-  uint64_t p0 = (uint64_t)(uint32_t)(job.rice_init << 8), p1 = p0;
+  uint32_t p0 = (uint32_t)(job.rice_init << 8), p1 = p0;
+  // one sample: both moduli as they stand, then the adaptation (the second parameter only when the first stage passes
+  // the value on -- a select, the lanes of a wave walk different blocks)                          src/SLACoder.c:120-138
+  auto step = [&](int32_t sample) -> uint32_t {
+    const uint32_t v = fold_u32(sample);
+    const uint32_t k0 = rice_k32(p0), k1 = rice_k32(p1);
+    const uint32_t m0 = 1u << k0;
+    const uint32_t n1 = rice_adapt32(p1, v - m0);
+    p0 = rice_adapt32(p0, v);
+    p1 = (v >= m0) ? n1 : p1;
+    return k0 | (k1 << 8);
+  };
   uint32_t s = 0;
-  for (; s + 8 <= n; s += 8) {
-    int32_t v8[8];
-    uint16_t k8[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) { v8[u] = in[s + u]; }       // loads first: the walk below is a serial chain
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const uint32_t v = fold_u32(v8[u]);
-      const uint32_t k0 = rice_k(p0), k1 = rice_k(p1);
-      k8[u] = (uint16_t)(k0 | (k1 << 8));
-      p0 = rice_adapt(p0, v);
-      if (v >= (1u << k0)) { p1 = rice_adapt(p1, v - (1u << k0)); }
+  // up to the first sample whose residual and k addresses are both 16-byte aligned (block starts usually are)
+  while (s < n && (((uintptr_t)(in + s) & 15u) != 0 || ((uintptr_t)(ko + s) & 15u) != 0) && s < 8) { ko[s] = (uint16_t)step(in[s]); s++; }
+  if ((((uintptr_t)(in + s) & 15u) == 0) && (((uintptr_t)(ko + s) & 15u) == 0)) {
+    for (; s + 8 <= n; s += 8) {
+      const int4 a = *reinterpret_cast<const int4*>(in + s);          // a lane reads its own line: 16 bytes per access,
+      const int4 b = *reinterpret_cast<const int4*>(in + s + 4);      // not 4, and one 16-byte store for 8 samples
+      uint4 o;
+      o.x = step(a.x); o.x |= step(a.y) << 16;
+      o.y = step(a.z); o.y |= step(a.w) << 16;
+      o.z = step(b.x); o.z |= step(b.y) << 16;
+      o.w = step(b.z); o.w |= step(b.w) << 16;
+      *reinterpret_cast<uint4*>(ko + s) = o;
     }
-#pragma unroll
-    for (int u = 0; u < 8; u++) { ko[s + u] = k8[u]; }
   }
-  for (; s < n; s++) {
-    const uint32_t v = fold_u32(in[s]);
-    const uint32_t k0 = rice_k(p0), k1 = rice_k(p1);
-    ko[s] = (uint16_t)(k0 | (k1 << 8));
-    p0 = rice_adapt(p0, v);
-    if (v >= (1u << k0)) { p1 = rice_adapt(p1, v - (1u << k0)); }
-  }
+  for (; s < n; s++) { ko[s] = (uint16_t)step(in[s]); }
 }
 
 // total body bits of every (block, channel): one wave per job, lanes stride over the samples

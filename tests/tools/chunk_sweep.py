@@ -16,12 +16,15 @@ import sla_amd        # noqa: E402
 
 SETTINGS = [
     {},
-    {"tail_lanes": 2},
-    {"tail_waves": 2},
-    {"tail_waves": 4},
-    {"tail_lanes": 2, "tail_waves": 2},
+    {"alt_streams": 1},
+    {"alt_streams": 1, "first_chunk": 400},
+    {"alt_streams": 1, "first_chunk": 500},
+    {"alt_streams": 1, "chunks": 3},
+    {"alt_streams": 1, "chunks": 4},
+    {"alt_streams": 1, "chunks": 4, "first_chunk": 250},
+    {"alt_streams": 1, "chunks": 6, "first_chunk": 166},
 ]
-DEFAULTS = {"chunks": 2, "first_chunk": 0, "single_tail": 1, "device_ltm": 1, "tail_lanes": 0, "tail_waves": 0}
+DEFAULTS = {"chunks": 2, "first_chunk": 0, "single_tail": 1, "device_ltm": 1, "tail_lanes": 0, "tail_waves": 0, "alt_streams": 0}
 
 
 def main():
