@@ -328,10 +328,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
       || hipEventCreate(&e->ev_prep) != hipSuccess) { goto fail; }
   for (i = 0; i < 4; i++) { if (hipEventCreate(&e->ev_pack[i]) != hipSuccess) { goto fail; } }
   /* every knob is read here, once; sla_hip_encoder_set_option changes them afterwards */
-  /* one chunk: every stage of the pipeline ends in a kernel whose duration is one block's serial chain (LMS, Rice walk),
-   * paid once per chunk; A/B on one box in round 2 -- C2 3.34 / 3.44 / 3.90 ms per step with 1 / 2 / 3 chunks, C3-600 s
-   * 6.71 / 7.21, C5-120 s 12.8 / 13.3 -- after the partition search stopped being the long stage that a second chunk's
-   * host work could hide behind */
+  /* two chunks of 25 % / 75 % that share one k_tail (the figures are at the chunk cuts in run_pipeline) */
   e->chunks = 2;
   e->single_tail = 1;
   e->device_ltm = 1;

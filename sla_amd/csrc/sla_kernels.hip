@@ -2462,10 +2462,10 @@ static int launch_tail_impl(const int32_t* d_res_in, int32_t* d_res_out, uint64_
   /* One tap per lane (k_tail) has the shorter dependent chain per sample -- one quarter-rate 32-bit multiply instead of
    * two -- and wins while the SIMDs hold a few waves each (C2: 1.7 waves per SIMD, 0.44 against 0.59 ms; C5-120 s: 1.30
    * against 1.48); two taps per lane (k_tail2) halve the waves and win once instruction issue is the limit (C3-600 s:
-   * 6.9 waves per SIMD, 1.01 -> 0.79 ms).  Automatic: k_tail2 above five one-tap waves per SIMD of an MI355X. */
+   * 3.4 waves per SIMD, 1.01 -> 0.79 ms).  Automatic: k_tail2 above three one-tap waves per SIMD of an MI355X. */
   const uint32_t one_tap_waves = (num_jobs + (64 / (2 * lms_order)) - 1) / (64 / (2 * lms_order));
   const uint32_t lanes_knob = tuning().tail_lanes;
-  if (lanes_knob == 1 || (lanes_knob == 0 && one_tap_waves > 5u * 1024u)) {      /* two taps per lane: `order` lanes per job */
+  if (lanes_knob == 1 || (lanes_knob == 0 && one_tap_waves > 3u * 1024u)) {      /* two taps per lane: `order` lanes per job */
     const uint32_t jpb = tail_waves * (64 / lms_order);
     dim3 grid2((num_jobs + jpb - 1) / jpb), block2(64 * tail_waves);
     switch (lms_order) {
