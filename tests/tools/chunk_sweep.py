@@ -16,15 +16,12 @@ import sla_amd        # noqa: E402
 
 SETTINGS = [
     {},
-    {"alt_streams": 1},
-    {"alt_streams": 1, "first_chunk": 400},
-    {"alt_streams": 1, "first_chunk": 500},
-    {"alt_streams": 1, "chunks": 3},
-    {"alt_streams": 1, "chunks": 4},
-    {"alt_streams": 1, "chunks": 4, "first_chunk": 250},
-    {"alt_streams": 1, "chunks": 6, "first_chunk": 166},
+    {"lpc_pack": 1},
+    {"lpc_pack": 2},
+    {"lpc_pack": 3},
+    {"lpc_pack": 4},
 ]
-DEFAULTS = {"chunks": 2, "first_chunk": 0, "single_tail": 1, "device_ltm": 1, "tail_lanes": 0, "tail_waves": 0, "alt_streams": 0}
+DEFAULTS = {"chunks": 2, "first_chunk": 0, "single_tail": 1, "device_ltm": 1, "tail_lanes": 0, "tail_waves": 0, "alt_streams": 0, "lpc_pack": 0}
 
 
 def main():
