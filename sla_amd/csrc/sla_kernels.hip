@@ -1070,6 +1070,7 @@ void k_acf_tiles(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
 // else (not positive definite, not finite, cert <= 0) is flagged -- NaN in r[0], or an infinite width -- and redone
 // as serial chains.
 #define XF_BATCH 64          // candidates one pass of the wave takes (at most)
+#define XF_GROUPS 16         // groups one wave takes (at most)
 
 // Final prediction error e_p of the Toeplitz system (r0, rc[1..order]) by the Schur recursion, both generator vectors
 // in registers (static indices: the lower one moves down one slot per stage instead of the upper one moving up).
@@ -1083,60 +1084,95 @@ __device__ __forceinline__ double schur_error(const double* __restrict__ rc, dou
 #pragma unroll
   for (int i = 0; i <= P; i++) { const double x = ((uint32_t)i <= order && i >= 1) ? rc[i] : 0.0; u[i] = (i == 0) ? r0 : x; v[i] = x; }
   v[P + 1] = 0.0;
-  for (uint32_t m = 1; m <= order; m++) {
-    if (!(u[0] > 0.0)) { return nan; }
-    const double k = -v[1] / u[0];
-    if (!(fabs(k) < 1.0)) { return nan; }
+  bool bad = false;
+  // stage m only has to renew the entries the later stages still read: u[0 .. P-m], v[0 .. P-m] (the result's cone of
+  // dependence shrinks by one index per stage) -- half the multiply-adds of a square sweep; stages and indices are
+  // unrolled, so both generator vectors stay in registers
 #pragma unroll
-    for (int i = 0; i < P; i++) {
-      const double t = v[i + 1], ui = u[i];
-      u[i] = __builtin_fma(k, t, ui);
-      v[i] = __builtin_fma(k, ui, t);
+  for (int m = 1; m <= P; m++) {
+    if ((uint32_t)m <= order) {
+      bad = bad || !(u[0] > 0.0);
+      const double k = -v[1] / u[0];
+      bad = bad || !(fabs(k) < 1.0);
+#pragma unroll
+      for (int i = 0; i <= P - m; i++) {
+        const double t = v[i + 1], ui = u[i];
+        u[i] = __builtin_fma(k, t, ui);
+        v[i] = __builtin_fma(k, ui, t);
+      }
     }
   }
-  return (u[0] > 0.0) ? u[0] : nan;
+  return (!bad && u[0] > 0.0) ? u[0] : nan;
 }
 
+// One wave takes `gpw` groups at once when their candidates fit its lanes (a 4096-sample window has 10 candidates: six
+// groups per wave instead of one wave with 10 busy lanes per group -- the kernel is bound by instruction issue); a
+// group with more than 64 candidates (windows above 8192 samples) takes several passes of one wave.
+// LDS: r[lanes][order+1] | a[lanes][order+2] | v[lanes][order+2] (work space of the exact windows' Levinson recursion)
 template <int P>           // P >= order: 16, 32, 48, 64; 0 = no certificate (cert <= 0, or an order above 64)
 __global__ __launch_bounds__(64)
-void k_search_finish(uint32_t order, uint32_t lags, uint32_t batch,
-                     const sla_hip_lpc_group* __restrict__ groups, const sla_hip_lpc_cand* __restrict__ cands,
-                     const double* __restrict__ tile_sums, double* __restrict__ out, double exact_limit, double cert)
+void k_search_finish(uint32_t order, uint32_t lags, uint32_t gpw, uint32_t per,
+                     const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, const sla_hip_lpc_cand* __restrict__ cands,
+                     const double* __restrict__ tile_sums, double* __restrict__ out, double exact_limit, double cert, uint32_t mode)
 {
+  // mode 0: every group; 1: only the groups over the exactness limit (no Levinson work space in LDS: three times the
+  // waves per CU at order 48); 2: only the groups below it.  Material that may have both kinds is launched as 1 + 2.
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ sla_hip_lpc_group s_g[XF_GROUPS];
+  __shared__ double s_energy[XF_GROUPS];
+  __shared__ uint32_t s_skip[XF_GROUPS];
+  __shared__ uint32_t s_cmax;
   const uint32_t O1 = order + 1, O2 = order + 2;
-  const sla_hip_lpc_group g = groups[blockIdx.x];
-  const uint32_t N = g.num_samples;
-  const uint32_t ntiles = (N + SLA_HIP_XTILE - 1) / SLA_HIP_XTILE;
-  const double* ts = tile_sums + (uint64_t)blockIdx.x * SLA_HIP_XTILES * 2 * lags;
-  double energy = 0.0;
-  for (uint32_t t = 0; t < ntiles; t++) { energy += ts[(uint64_t)t * 2 * lags]; }
-  const bool exact = (energy < exact_limit);
-  double* r = lds;                                   // [batch][O1]
-  double* av = lds + (size_t)batch * O1;             // [batch][O2]
-  double* vv = av + (size_t)batch * O2;              // [batch][O2]
+  const uint32_t lane = threadIdx.x;
+  const uint32_t g0 = blockIdx.x * gpw;
+  const uint32_t ngr = (num_groups - g0 < gpw) ? (num_groups - g0) : gpw;
+  const uint32_t slots = gpw * per;                  // lanes in use, <= 64
+  if (lane == 0) { s_cmax = 0; }
+  __syncthreads();
+  if (lane < ngr) {
+    const sla_hip_lpc_group g = groups[g0 + lane];
+    const uint32_t ntiles = (g.num_samples + SLA_HIP_XTILE - 1) / SLA_HIP_XTILE;
+    const double* ts = tile_sums + (uint64_t)(g0 + lane) * SLA_HIP_XTILES * 2 * lags;
+    double energy = 0.0;
+    for (uint32_t t = 0; t < ntiles; t++) { energy += ts[(uint64_t)t * 2 * lags]; }
+    const bool skip = (mode == 1 && energy < exact_limit) || (mode == 2 && !(energy < exact_limit));
+    s_g[lane] = g; s_energy[lane] = energy; s_skip[lane] = skip ? 1u : 0u;
+    if (!skip) { atomicMax(&s_cmax, g.cand_count); }
+  }
+  __syncthreads();
+  const uint32_t cmax = s_cmax;
+  double* r = lds;                                   // [slots][O1]
+  double* av = lds + (size_t)slots * O1;             // [slots][O2]
+  double* vv = av + (size_t)slots * O2;              // [slots][O2]
   const double inf = __longlong_as_double(0x7FF0000000000000ll);
-  for (uint32_t c0 = 0; c0 < g.cand_count; c0 += batch) {
-    const uint32_t nb = (g.cand_count - c0 < batch) ? (g.cand_count - c0) : batch;
-    for (uint32_t q = threadIdx.x; q < nb * O1; q += blockDim.x) {
-      const uint32_t ci = q / O1, lag = q - ci * O1;
-      const sla_hip_lpc_cand cd = cands[g.cand_first + c0 + ci];
-      const uint32_t end = cd.start + cd.len;
-      double sum = 0.0;
-      if (lag < cd.len) {
-        const uint32_t tl = (end - 1) / SLA_HIP_XTILE;
-        for (uint32_t t = cd.start / SLA_HIP_XTILE; t <= tl; t++) { sum += ts[(uint64_t)t * 2 * lags + lag]; }
-        sum -= ts[(uint64_t)tl * 2 * lags + lags + lag];
+  for (uint32_t c0 = 0; c0 < cmax; c0 += per) {
+    const uint32_t total = ngr * per * O1;
+    for (uint32_t q = lane; q < total; q += 64) {
+      const uint32_t gl = q / (per * O1), rem = q - gl * per * O1;
+      const uint32_t cl = rem / O1, lag = rem - cl * O1, ci = c0 + cl;
+      if (ci < s_g[gl].cand_count && !s_skip[gl]) {
+        const sla_hip_lpc_cand cd = cands[s_g[gl].cand_first + ci];
+        const double* ts = tile_sums + (uint64_t)(g0 + gl) * SLA_HIP_XTILES * 2 * lags;
+        const uint32_t end = cd.start + cd.len;
+        double sum = 0.0;
+        if (lag < cd.len) {
+          const uint32_t tl = (end - 1) / SLA_HIP_XTILE;
+          for (uint32_t t = cd.start / SLA_HIP_XTILE; t <= tl; t++) { sum += ts[(uint64_t)t * 2 * lags + lag]; }
+          sum -= ts[(uint64_t)tl * 2 * lags + lags + lag];
+        }
+        r[(gl * per + cl) * O1 + lag] = sum;
       }
-      r[ci * O1 + lag] = sum;
     }
     __syncthreads();
-    for (uint32_t ci = threadIdx.x; ci < nb; ci += blockDim.x) {
-      const sla_hip_lpc_cand cd = cands[g.cand_first + c0 + ci];
-      double* o = out + ((uint64_t)g.slot_first + c0 + ci) * O2;
-      const double* rc = r + ci * O1;
-      if (exact) {
-        levinson_out(rc, av + ci * O2, vv + ci * O2, o, order, cd.len);
+    const uint32_t gl = lane / per, cl = lane - gl * per, ci = c0 + cl;
+    if (gl < ngr && ci < s_g[gl].cand_count && !s_skip[gl]) {
+      const sla_hip_lpc_group g = s_g[gl];
+      const double energy = s_energy[gl];
+      const sla_hip_lpc_cand cd = cands[g.cand_first + ci];
+      double* o = out + ((uint64_t)g.slot_first + ci) * O2;
+      const double* rc = r + (size_t)lane * O1;
+      if (energy < exact_limit) {
+        if (mode != 1) { levinson_out(rc, av + (size_t)lane * O2, vv + (size_t)lane * O2, o, order, cd.len); }
       } else if (P == 0) {
         o[0] = __longlong_as_double(0x7FF8000000000000ll);          // flagged: rerun as serial chains
       } else {
@@ -1147,9 +1183,15 @@ void k_search_finish(uint32_t order, uint32_t lags, uint32_t batch,
         if (cd.len >= order && r0 > 2.0 * (double)FLT_EPSILON) {     // (the reference zeroes the coefficients below FLT_EPSILON, src/SLAPredictor.c:274)
           const double delta = ((double)cd.len * u) * r0 + (48.0 * u) * energy;
           const double d = cert * (double)(2 * order + 1) * delta;
-          const double e_mid = schur_error<(P > 0) ? P : 1>(rc, r0, order);
-          const double e_hi = schur_error<(P > 0) ? P : 1>(rc, r0 + d, order);
-          const double e_lo = (r0 - d > (double)FLT_EPSILON) ? schur_error<(P > 0) ? P : 1>(rc, r0 - d, order) : (e_hi - e_hi) / (e_hi - e_hi);
+          // one copy of the unrolled recursion, run three times (three inlined copies do not fit the instruction cache)
+          double e3[3];
+#pragma unroll 1
+          for (int bk = 0; bk < 3; bk++) {
+            const double rb = (bk == 0) ? r0 : (bk == 1) ? (r0 + d) : (r0 - d);
+            e3[bk] = (bk == 2 && !(r0 - d > (double)FLT_EPSILON)) ? __longlong_as_double(0x7FF8000000000000ll)
+                                                                  : schur_error<(P > 0) ? P : 1>(rc, rb, order);
+          }
+          const double e_mid = e3[0], e_hi = e3[1], e_lo = e3[2];
           if (e_mid > 0.0 && e_lo > 0.0 && e_hi >= e_mid && e_mid >= e_lo && e_hi < inf) {
             const double up = log2(e_hi / e_mid), dn = log2(e_mid / e_lo);
             w = ((up > dn) ? up : dn) * 1.000001 + 1e-11;         // (device log2: a few ulp)
@@ -2322,14 +2364,29 @@ extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { return hip_rc(e); }
-  const uint32_t batch = (max_cands_per_group < XF_BATCH) ? max_cands_per_group : XF_BATCH;
-  const size_t lds = sizeof(double) * (size_t)batch * ((order + 1) + 2 * (size_t)(order + 2));
+  // lanes = (group, candidate): `per` candidate slots per group and pass, `gpw` groups per wave
+  const uint32_t per = (max_cands_per_group < XF_BATCH) ? max_cands_per_group : XF_BATCH;
+  uint32_t gpw = XF_BATCH / per;
+  if (gpw > XF_GROUPS) { gpw = XF_GROUPS; }
+  if (gpw < 1) { gpw = 1; }
+  const size_t lds_r = sizeof(double) * (size_t)gpw * per * (order + 1);
+  const size_t lds = lds_r + sizeof(double) * (size_t)gpw * per * 2 * (size_t)(order + 2);
+  // |x| < 2 in the search's unit (mid/side: side = l - r), so a window's energy stays below 4 x its length: when even
+  // that is under the limit (16-bit material) every group takes the exact path and one launch does
+  const bool all_exact = (exact_limit >= 4.0 * (double)max_window);
   const int pclass = !(cert_safety > 0.0) ? 0 : (order <= 16) ? 16 : (order <= 32) ? 32 : (order <= 48) ? 48 : (order <= 64) ? 64 : 0;
 #define SLA_FINISH(PP) do { \
     e = ensure_dynamic_lds((const void*)k_search_finish<PP>, lds); \
     if (e != hipSuccess) { return hip_rc(e); } \
-    hipLaunchKernelGGL(k_search_finish<PP>, dim3(num_groups), dim3(64), lds, st, order, lags, batch, \
-                       d_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety); } while (0)
+    if (all_exact) { \
+      hipLaunchKernelGGL(k_search_finish<PP>, dim3((num_groups + gpw - 1) / gpw), dim3(64), lds, st, order, lags, gpw, per, \
+                         d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety, 0u); \
+    } else { \
+      hipLaunchKernelGGL(k_search_finish<PP>, dim3((num_groups + gpw - 1) / gpw), dim3(64), lds_r, st, order, lags, gpw, per, \
+                         d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety, 1u); \
+      hipLaunchKernelGGL(k_search_finish<PP>, dim3((num_groups + gpw - 1) / gpw), dim3(64), lds, st, order, lags, gpw, per, \
+                         d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety, 2u); \
+    } } while (0)
   switch (pclass) {
     case 16: SLA_FINISH(16); break;
     case 32: SLA_FINISH(32); break;

@@ -16,11 +16,7 @@ import sla_amd        # noqa: E402
 
 SETTINGS = [
     {},
-    {"lpc_blocks_chains": 1},
-    {"lpc_blocks_chains": 1, "lpc_pack": 1},
-    {"lpc_blocks_chains": 1, "lpc_pack": 2},
-    {"lpc_blocks_chains": 1, "lpc_pack": 1, "lpc_threads": 256},
-    {"lpc_blocks_chains": 1, "lpc_pack": 2, "lpc_threads": 256},
+    {"chunks": 1},
 ]
 DEFAULTS = {"chunks": 2, "first_chunk": 0, "single_tail": 1, "device_ltm": 1, "tail_lanes": 0, "tail_waves": 0, "alt_streams": 0, "lpc_pack": 0, "lpc_blocks_chains": 0, "lpc_threads": 0}
 
