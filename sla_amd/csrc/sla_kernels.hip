@@ -947,6 +947,65 @@ __device__ __forceinline__ double wave_sum_f64(double v)
   return (r0 + r1) + (r2 + r3);
 }
 
+// Sums over the 64 lanes of M values per lane at once (M = 16, 32, 64; callers pad with zeros): a butterfly that halves
+// the number of live values at every step -- a lane keeps the half selected by one of its lane-number bits and hands
+// the other half to the partner that differs in that bit -- so the whole job costs M - 1 exchange-and-add operations
+// instead of M separate 6-step wave sums.  The first (widest) steps use the cheap in-row DPP exchanges (xor 1, xor 2,
+// xor 8 = rotate by 8 inside a row of 16), the narrow ones ds_swizzle / bpermute.  On return lane L holds the total of
+// value `index` (every index < M exactly once among the lanes `writer` marks).  Callers' sums are exact or certified
+// for any order of the additions.
+__device__ __forceinline__ double swz_f64_xor4(double v)
+{
+  return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x101F), __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x101F));
+}
+__device__ __forceinline__ double swz_f64_xor16(double v)
+{
+  return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F), __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401F));
+}
+__device__ __forceinline__ double shfl_f64_xor32(double v)
+{
+  return __hiloint2double(__shfl_xor(__double2hiint(v), 32), __shfl_xor(__double2loint(v), 32));
+}
+template <int STEP>
+__device__ __forceinline__ double lane_exchange(double v)       // partner = lane ^ {1, 2, 8, 4, 16, 32}[STEP]
+{
+  if (STEP == 0) { return dpp_f64<0xB1>(v); }
+  if (STEP == 1) { return dpp_f64<0x4E>(v); }
+  if (STEP == 2) { return dpp_f64<0x128>(v); }                  // row_ror:8
+  if (STEP == 3) { return swz_f64_xor4(v); }
+  if (STEP == 4) { return swz_f64_xor16(v); }
+  return shfl_f64_xor32(v);
+}
+template <int M, int STEP>
+__device__ __forceinline__ void transpose_step(double (&v)[M], uint32_t lane)
+{
+  constexpr int K = M >> STEP;                                  // live values before this step
+  constexpr uint32_t BIT = (STEP == 0) ? 1u : (STEP == 1) ? 2u : (STEP == 2) ? 8u : (STEP == 3) ? 4u : (STEP == 4) ? 16u : 32u;
+  const bool up = (lane & BIT) != 0;
+  if (K >= 2) {
+#pragma unroll
+    for (int j = 0; j < K / 2; j++) {
+      const double lo = v[j], hi = v[j + K / 2];
+      const double send = up ? lo : hi, keep = up ? hi : lo;
+      v[j] = keep + lane_exchange<STEP>(send);
+    }
+  } else {
+    v[0] += lane_exchange<STEP>(v[0]);                          // one value left: plain sum over the remaining lane bits
+  }
+}
+template <int M>
+__device__ __forceinline__ double wave_transpose_sum(double (&v)[M], uint32_t lane, uint32_t& index, bool& writer)
+{
+  transpose_step<M, 0>(v, lane); transpose_step<M, 1>(v, lane); transpose_step<M, 2>(v, lane);
+  transpose_step<M, 3>(v, lane); transpose_step<M, 4>(v, lane); transpose_step<M, 5>(v, lane);
+  const uint32_t b0 = lane & 1u, b1 = (lane >> 1) & 1u, b2 = (lane >> 2) & 1u, b3 = (lane >> 3) & 1u, b4 = (lane >> 4) & 1u, b5 = (lane >> 5) & 1u;
+  // step k keeps the half selected by its bit: the bits spell the index from the top (M/2, M/4, ..)
+  if (M == 64) { index = b0 * 32 + b1 * 16 + b3 * 8 + b2 * 4 + b4 * 2 + b5; writer = true; }
+  else if (M == 32) { index = b0 * 16 + b1 * 8 + b3 * 4 + b2 * 2 + b4; writer = (b5 == 0); }
+  else { index = b0 * 8 + b1 * 4 + b3 * 2 + b2; writer = (b4 == 0 && b5 == 0); }
+  return v[0];
+}
+
 typedef int32_t i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 
 // 4 consecutive raw samples of one plane, zero from `limit` on
@@ -1031,11 +1090,14 @@ void k_acf_tiles(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
     }
   }
   double* dst = tile_sums + ((uint64_t)gi * SLA_HIP_XTILES + tile) * (2 * LAGS);
+  {
+    constexpr int M = (LAGS <= 16) ? 16 : (LAGS <= 32) ? 32 : 64;
+    double tv[M];
 #pragma unroll
-  for (int i = 0; i < (int)LAGS; i++) {
-    double v = acc[i];
-    v = wave_sum_f64(v);
-    if (lane == 0) { dst[i] = v; }
+    for (int i = 0; i < M; i++) { tv[i] = (i < (int)LAGS) ? acc[i] : 0.0; }
+    uint32_t index; bool writer;
+    const double total = wave_transpose_sum<M>(tv, lane, index, writer);
+    if (writer && index < LAGS) { dst[index] = total; }
   }
   // pairs that straddle t1: lane = lag
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
