@@ -69,7 +69,8 @@ struct SLAEncoder {
   int      chunks_forced;           /* the caller chose the chunk count: no short-file rule */
   uint32_t first_chunk;             /* 1/1000 of the super-frames in chunk 0 (0: built-in shares) */
   int      single_tail;             /* 1: one k_tail launch for all chunks (default) */
-  int      alt_streams;             /* 1: the block stages of odd and even chunks on two streams */
+  int      alt_streams;             /* option: 0 never, 1 always, 2 (default) for big files -- the block stages of odd and even chunks on two streams */
+  int      alt_now;                 /* this run's decision */
   int      device_ltm;              /* 1: pitch + taps solved on the device, the block stage runs lattice -> tail without the host (default) */
   int      trace;                   /* host-side timeline on stderr (SLA_HIP_TRACE) */
   sla_hip_tuning tune;              /* launcher knobs, named to the launchers at every API entry */
@@ -330,6 +331,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   /* every knob is read here, once; sla_hip_encoder_set_option changes them afterwards */
   /* two chunks of 25 % / 75 % that share one k_tail (the figures are at the chunk cuts in run_pipeline) */
   e->chunks = 2;
+  e->alt_streams = 2;
   e->single_tail = 1;
   e->device_ltm = 1;
   env = getenv("SLA_HIP_LTM");
@@ -1173,7 +1175,7 @@ static int tail_enqueue(struct SLAEncoder* e, actx_t* a, uint32_t c, uint32_t lo
   if (!e->single_tail) {
     HIPCHK(hipEventRecord(ev[EV_SOLVED], e->stream2));
     HIPCHK(hipStreamWaitEvent(ts, ev[EV_SOLVED], 0));
-  } else if (e->alt_streams) {
+  } else if (e->alt_now) {
     uint32_t cc;
     for (cc = 1; cc < a->nchunks; cc += 2) {
       if (a->ck[cc].bg_hi > a->ck[cc].bg_lo) { HIPCHK(hipStreamWaitEvent(ts, a->ev[(size_t)cc * EV_PER_CHUNK + EV_SOLVED], 0)); }
@@ -1216,7 +1218,7 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
   const int fused = (e->fuse_lattice && order <= 64);
   /* option alt_streams: odd chunks run their block stage on the third stream, beside the even chunks' (not when the FFT
    * works in the shared global scratch) */
-  hipStream_t bs = (e->alt_streams && e->device_ltm && e->single_tail && (c & 1u)
+  hipStream_t bs = (e->alt_now && e->device_ltm && e->single_tail && (c & 1u)
                     && sizeof(double) * (size_t)fft_size <= SLA_HIP_LDS_BUDGET) ? e->stream3 : e->stream2;
   const size_t slot_lo = (size_t)k->blk_lo * C, nsl = (size_t)(k->blk_hi - k->blk_lo) * C;
 
@@ -1524,6 +1526,12 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   if (want_chunks > MAX_CHUNKS) { want_chunks = MAX_CHUNKS; }
   if (want_chunks < 1) { want_chunks = 1; }
   a.nchunks = want_chunks;
+  /* big files (throughput-bound kernels): the block stages of the two chunks on two streams, so that one chunk's lattice /
+   * FFT kernels fill the gaps of the other's k_lpc_blocks -- C3-600 s 5.29 -> 5.13 ms, C5-120 s 11.12 -> 10.74 with a
+   * 40 % first chunk; a ten-minute mono file loses (2.32 -> 2.43 ms: its kernels are too short to share the device) */
+  e->alt_now = (e->alt_streams == 1)
+            || (e->alt_streams == 2 && (uint64_t)e->num_samples * C * e->encode_param.parcor_order >= 1000000000ull);
+  if (!(e->device_ltm && e->single_tail) || a.nchunks < 2) { e->alt_now = 0; }
   /* chunk boundaries in 1/1000 of the super-frames: equal parts unless SLA_HIP_CHUNK_SPLIT gave the shares */
   if (e->first_chunk != 0 && a.nchunks >= 2) {
     /* option first_chunk: that many 1/1000 of the super-frames in chunk 0, the others share the rest equally */
@@ -1535,7 +1543,7 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
      * kernels.  With one k_tail for the file (device long-term solve) 25 % / 75 % is best: 2.32 / 5.94 / 11.97 ms
      * against 2.46 / 6.23 / 12.24 ms in one chunk; a third chunk only adds launches.  With a k_tail per chunk
      * (host solve) every chunk costs one more serial LMS chain, and 40 % / 60 % was the best cut. */
-    e->chunk_cut[0] = 0; e->chunk_cut[1] = (e->device_ltm && e->single_tail) ? 250 : 400; e->chunk_cut[2] = 1000;
+    e->chunk_cut[0] = 0; e->chunk_cut[1] = (e->device_ltm && e->single_tail && !e->alt_now) ? 250 : 400; e->chunk_cut[2] = 1000;
   } else if (e->split_count != a.nchunks && a.nchunks == 3) {
     e->chunk_cut[0] = 0; e->chunk_cut[1] = 250; e->chunk_cut[2] = 625; e->chunk_cut[3] = 1000;
   } else if (e->split_count != a.nchunks) {
@@ -1712,7 +1720,7 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   else if (strcmp(name, "stream_piece") == 0)      { OPT_RANGE(1024, 1 << 30); e->stream_piece = (uint32_t)iv; }
   else if (strcmp(name, "stream_lanes") == 0)      { OPT_RANGE(1, 4); e->stream_lanes = (uint32_t)iv; }
   else if (strcmp(name, "first_chunk") == 0)       { OPT_RANGE(0, 999); e->first_chunk = (uint32_t)iv; }
-  else if (strcmp(name, "alt_streams") == 0)       { OPT_RANGE(0, 1); e->alt_streams = (int)iv; }
+  else if (strcmp(name, "alt_streams") == 0)       { OPT_RANGE(0, 2); e->alt_streams = (int)iv; }
   else if (strcmp(name, "device_ltm") == 0)        { OPT_RANGE(0, 1); e->device_ltm = (int)iv; }
   else if (strcmp(name, "fuse_lattice") == 0)      { OPT_RANGE(0, 1); e->fuse_lattice = (int)iv && !e->tune.lpc_blocks_chains; }
   else if (strcmp(name, "threads") == 0) {

@@ -16,9 +16,10 @@ import sla_amd        # noqa: E402
 
 SETTINGS = [
     {},
-    {"chunks": 1},
+    {"alt_streams": 0},
+    {"alt_streams": 1},
 ]
-DEFAULTS = {"chunks": 2, "first_chunk": 0, "single_tail": 1, "device_ltm": 1, "tail_lanes": 0, "tail_waves": 0, "alt_streams": 0, "lpc_pack": 0, "lpc_blocks_chains": 0, "lpc_threads": 0}
+DEFAULTS = {"chunks": 2, "first_chunk": 0, "single_tail": 1, "device_ltm": 1, "tail_lanes": 0, "tail_waves": 0, "alt_streams": 2, "lpc_pack": 0, "lpc_blocks_chains": 0, "lpc_threads": 0}
 
 
 def main():
