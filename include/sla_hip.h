@@ -129,6 +129,7 @@ typedef struct sla_hip_tuning {
   uint32_t lpc_threads;         /* 256 or 512 threads per k_lpc workgroup, 0 = automatic                             */
   uint32_t lpc_blocks_chains;   /* 1: chosen blocks through k_lpc's serial chains instead of k_lpc_blocks            */
   uint32_t tail_waves;          /* waves per k_tail workgroup (1..4), 0 = automatic (1)                              */
+  uint32_t lpc_tile;            /* steps per tile of k_lpc_blocks' wide packs: 24, or 0 / 48 = 48 where it fits         */
   uint32_t tail_lanes;          /* lanes per tail job in units of the LMS order: 1 = one (k_tail2, two taps per lane), 2 = two (k_tail, one tap per lane), 0 = by the number of jobs */
   double   plan_margin;         /* certification margin of k_plan, 0 = 1e-4 (tests raise it to force the host plan)  */
 } sla_hip_tuning;

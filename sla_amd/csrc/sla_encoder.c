@@ -1707,6 +1707,7 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   if (strcmp(name, "lpc_pack") == 0)               { OPT_RANGE(0, 4); e->tune.lpc_pack = (uint32_t)iv; }
   else if (strcmp(name, "lpc_threads") == 0)       { if (iv != 0 && iv != 256 && iv != 512) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.lpc_threads = (uint32_t)iv; }
   else if (strcmp(name, "tail_waves") == 0)        { OPT_RANGE(0, 4); e->tune.tail_waves = (uint32_t)iv; }
+  else if (strcmp(name, "lpc_tile") == 0)          { if (iv != 0 && iv != 24 && iv != 48) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.lpc_tile = (uint32_t)iv; }
   else if (strcmp(name, "tail_lanes") == 0)        { OPT_RANGE(0, 2); e->tune.tail_lanes = (uint32_t)iv; }
   else if (strcmp(name, "lpc_blocks_chains") == 0) { OPT_RANGE(0, 1); e->tune.lpc_blocks_chains = (uint32_t)iv; if (iv) { e->fuse_lattice = 0; } }
   else if (strcmp(name, "plan_margin") == 0)       { if (value < 0.0) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.plan_margin = value; }

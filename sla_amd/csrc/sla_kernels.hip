@@ -584,7 +584,7 @@ __device__ __forceinline__ uint32_t stage_window(const int32_t* __restrict__ pcm
 
 #define LB_ROW (LB_K + 2)     // terms of one chain and tile, padded: 16-byte aligned rows that spread over the banks
 
-template <int S>              // producer lanes per chain: 6 or 12
+template <int S, int LBK>     // producer lanes per chain: 6 or 12; steps per tile: 24 or 48 (longer tiles pay for wide packs: fewer barriers, more operand reuse)
 __global__ __launch_bounds__(LB_THREADS)
 void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
                   const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, uint32_t pack,
@@ -593,7 +593,7 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
                   uint32_t x_region, uint32_t nch, uint32_t clk, unsigned long long* exec_span,
                   int32_t* __restrict__ lat_residual, uint32_t defer_levinson)
 {
-  constexpr uint32_t Q = LB_K / S;              // consecutive terms a producer lane makes per tile
+  constexpr uint32_t Q = LBK / S;              // consecutive terms a producer lane makes per tile
   extern __shared__ __attribute__((aligned(16))) double lds[];
   span_begin(exec_span);
   const unsigned long long t_start = clk ? clock64() : 0;
@@ -610,9 +610,9 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
   }
   if (tid == 0) { s_tiles = 0; }
   __syncthreads();
-  double* terms = lds + (size_t)pack * x_region;            // [2][nch][LB_ROW]
-  double* sq = terms + (size_t)2 * nch * LB_ROW;            // [2][pack][2*LB_K]
-  double* r = sq + (size_t)2 * 2 * LB_K * pack;             // [pack][O1]
+  double* terms = lds + (size_t)pack * x_region;            // [2][nch][(LBK + 2)]
+  double* sq = terms + (size_t)2 * nch * (LBK + 2);            // [2][pack][2*LBK]
+  double* r = sq + (size_t)2 * 2 * LBK * pack;             // [pack][O1]
 
   // ---- stage the windows: convert, mid/side, window, pre-emphasis (as k_lpc) -------------------------
   for (uint32_t k = 0; k < ng; k++) {
@@ -639,8 +639,8 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
   const uint32_t total = (has_chain && lag < n) ? (npair + (n - span - lag)) : 0;     // terms of this chain
   const double* xs = lds + (size_t)ck * x_region;
   {
-    uint32_t need = (total + LB_K - 1) / LB_K;
-    if (tid < ng) { const uint32_t e = (s_g[tid].num_samples + 2 * LB_K - 1) / (2 * LB_K); need = (e > need) ? e : need; }
+    uint32_t need = (total + LBK - 1) / LBK;
+    if (tid < ng) { const uint32_t e = (s_g[tid].num_samples + 2 * LBK - 1) / (2 * LBK); need = (e > need) ? e : need; }
     need = umax_wave(need);
     if (lane == 0) { atomicMax(&s_tiles, need); }
   }
@@ -649,13 +649,13 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
   const unsigned long long t_staged = clk ? clock64() : 0;
   unsigned long long t_prod = 0, t_cons = 0;
 
-  // producer position: term kk = tile*LB_K + j*Q sits at (run pi, step pg) while it is a pair term
+  // producer position: term kk = tile*LBK + j*Q sits at (run pi, step pg) while it is a pair term
   uint32_t kk = j * Q;
   uint32_t pi = (grp != 0) ? (kk / grp) : 0, pg = (grp != 0) ? (kk - (kk / grp) * grp) : 0;
   uint32_t ppos = pi + pg * lag2;                           // sample index of a of that term
-  // energy producer: lane e < 2*LB_K*ng makes the square of sample tile*2*LB_K + es of window ew
-  const uint32_t nsq = 2 * LB_K * ng;
-  const uint32_t ew = pl / (2 * LB_K), es = pl - ew * (2 * LB_K);      // 2*LB_K*LPC_MAX_PACK = 192 <= LB_PRODUCERS
+  // energy producer: lane e < 2*LBK*ng makes the square of sample tile*2*LBK + es of window ew
+  const uint32_t nsq = 2 * LBK * ng;
+  const uint32_t ew = pl / (2 * LBK), es = pl - ew * (2 * LBK);      // 2*LBK*LPC_MAX_PACK = 192 <= LB_PRODUCERS
 
   double acc = 0.0;
   for (uint32_t t = 0; t <= ntiles; t++) {
@@ -666,7 +666,7 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
       const bool plain = !has_chain || (kk + Q <= npair && pg + Q <= grp);
       if (__all(plain)) {
         if (has_chain) {
-          double* dst = terms + ((size_t)(t & 1) * nch + ch) * LB_ROW + j * Q;
+          double* dst = terms + ((size_t)(t & 1) * nch + ch) * (LBK + 2) + j * Q;
           const double* p = xs + ppos;
           double va[Q + 1], vc[Q];
 #pragma unroll
@@ -676,7 +676,7 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
           for (int q = 0; q < (int)Q; q++) { dst[q] = vc[q] * (va[q] + va[q + 1]); }
         }
       } else if (has_chain) {
-        double* dst = terms + ((size_t)(t & 1) * nch + ch) * LB_ROW + j * Q;
+        double* dst = terms + ((size_t)(t & 1) * nch + ch) * (LBK + 2) + j * Q;
         uint32_t ii = pi, gg = pg, pos = ppos;
         uint32_t ia[Q]; bool pr[Q], vl[Q];
 #pragma unroll
@@ -699,34 +699,34 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
         }
       }
       if (has_chain) {
-        kk += LB_K;
-        if (grp != 0) { pg += LB_K; ppos += LB_K * lag2; while (pg >= grp) { pg -= grp; pi++; ppos += 1 - span; } }
+        kk += LBK;
+        if (grp != 0) { pg += LBK; ppos += LBK * lag2; while (pg >= grp) { pg -= grp; pi++; ppos += 1 - span; } }
       }
-      double* dq = sq + (size_t)(t & 1) * 2 * LB_K * pack;
+      double* dq = sq + (size_t)(t & 1) * 2 * LBK * pack;
       if (pl < nsq) {
-        const uint32_t idx = t * 2 * LB_K + es;
+        const uint32_t idx = t * 2 * LBK + es;
         const double v = (idx < s_g[ew].num_samples) ? lds[(size_t)ew * x_region + idx] : 0.0;
-        dq[ew * 2 * LB_K + es] = v * v;
+        dq[ew * 2 * LBK + es] = v * v;
       }
     }
     const unsigned long long t_b = clk ? clock64() : 0;
     if (t >= 1) {
       if (wv == 0 && has_chain) {
-        const double2* src = (const double2*)(terms + ((size_t)((t - 1) & 1) * nch + ch) * LB_ROW);
-        double2 v[LB_K / 2];
+        const double2* src = (const double2*)(terms + ((size_t)((t - 1) & 1) * nch + ch) * (LBK + 2));
+        double2 v[LBK / 2];
 #pragma unroll
-        for (int q = 0; q < LB_K / 2; q++) { v[q] = src[q]; }
+        for (int q = 0; q < LBK / 2; q++) { v[q] = src[q]; }
         __builtin_amdgcn_sched_barrier(0);          // every load of the tile is in flight before the first add waits
 #pragma unroll
-        for (int q = 0; q < LB_K / 2; q++) { acc += v[q].x; acc += v[q].y; }
+        for (int q = 0; q < LBK / 2; q++) { acc += v[q].x; acc += v[q].y; }
       } else if (wv == 1 && lane < ng) {
-        const double2* src = (const double2*)(sq + (size_t)((t - 1) & 1) * 2 * LB_K * pack + lane * 2 * LB_K);
-        double2 v[LB_K];
+        const double2* src = (const double2*)(sq + (size_t)((t - 1) & 1) * 2 * LBK * pack + lane * 2 * LBK);
+        double2 v[LBK];
 #pragma unroll
-        for (int q = 0; q < LB_K; q++) { v[q] = src[q]; }
+        for (int q = 0; q < LBK; q++) { v[q] = src[q]; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < LB_K; q++) { acc += v[q].x; acc += v[q].y; }
+        for (int q = 0; q < LBK; q++) { acc += v[q].x; acc += v[q].y; }
       }
     }
     if (clk) { const unsigned long long t_c = clock64(); t_prod += t_b - t_a; t_cons += t_c - t_b; }
@@ -2320,10 +2320,17 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
       uint32_t nch = 16;
       while (nch < p * order) { nch <<= 1; }
       const size_t xr = ((size_t)max_window + 1) & ~(size_t)1;       // even: the term rows behind the windows are read as 16-byte pairs
-      const size_t bytes = sizeof(double) * ((size_t)p * xr + (size_t)2 * LB_ROW * nch + (size_t)2 * 2 * LB_K * p + (size_t)p * (order + 1));
-      if (bytes > SLA_HIP_LDS_BUDGET) { continue; }
       const uint32_t spl = (nch <= 32) ? 12 : 6;                    // producer lanes per chain: nch * spl <= LB_PRODUCERS
-      const void* fn = (spl == 12) ? (const void*)k_lpc_blocks<12> : (const void*)k_lpc_blocks<6>;
+      // steps per tile: 48 for the wide packs (64 chains, 6 producer lanes each: C5-120 s 10.7 -> 10.3 ms per step, a
+      // ten-minute order-16 file loses with them: 2.31 -> 2.46 ms) when the longer tiles still fit, else 24
+      uint32_t lbk = (spl == 6 && 2u * 48u * p <= LB_PRODUCERS && tune.lpc_tile != 24u) ? 48u : 24u;
+      size_t bytes = sizeof(double) * ((size_t)p * xr + (size_t)2 * (lbk + 2) * nch + (size_t)2 * 2 * lbk * p + (size_t)p * (order + 1));
+      if (bytes > SLA_HIP_LDS_BUDGET && lbk == 48u) {
+        lbk = 24u;
+        bytes = sizeof(double) * ((size_t)p * xr + (size_t)2 * (lbk + 2) * nch + (size_t)2 * 2 * lbk * p + (size_t)p * (order + 1));
+      }
+      if (bytes > SLA_HIP_LDS_BUDGET) { continue; }
+      const void* fn = (spl == 12) ? (const void*)k_lpc_blocks<12, 24> : (lbk == 48u) ? (const void*)k_lpc_blocks<6, 48> : (const void*)k_lpc_blocks<6, 24>;
       hipError_t e = ensure_dynamic_lds(fn, bytes);
       if (e != hipSuccess) { return hip_rc(e); }
       const dim3 grid((num_groups + p - 1) / p), block(LB_THREADS);
@@ -2337,10 +2344,13 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
       // (it needs the coefficients inside the workgroup)
       const uint32_t defer = (d_lat_residual == nullptr && order <= 64) ? 1u : 0u;
       if (spl == 12) {
-        hipLaunchKernelGGL(k_lpc_blocks<12>, grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
+        hipLaunchKernelGGL((k_lpc_blocks<12, 24>), grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
+                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span, d_lat_residual, defer);
+      } else if (lbk == 48u) {
+        hipLaunchKernelGGL((k_lpc_blocks<6, 48>), grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
                            d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span, d_lat_residual, defer);
       } else {
-        hipLaunchKernelGGL(k_lpc_blocks<6>, grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
+        hipLaunchKernelGGL((k_lpc_blocks<6, 24>), grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
                            d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span, d_lat_residual, defer);
       }
       if (defer) {
