@@ -336,6 +336,8 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   e->device_ltm = 1;
   env = getenv("SLA_HIP_LTM");
   if (env != NULL) { e->device_ltm = (strcmp(env, "host") != 0); }
+  env = getenv("SLA_HIP_ALT_STREAMS");
+  if (env != NULL && atoi(env) >= 0 && atoi(env) <= 2) { e->alt_streams = atoi(env); }
   env = getenv("SLA_HIP_SINGLE_TAIL");
   if (env != NULL) { e->single_tail = (atoi(env) != 0); }
   env = getenv("SLA_HIP_CHUNKS");

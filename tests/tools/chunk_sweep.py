@@ -16,9 +16,9 @@ import sla_amd        # noqa: E402
 
 SETTINGS = [
     {},
-    {"lpc_tile": 24},
-    {"lpc_tile": 48},
-    {"lpc_tile": 24, "lpc_pack": 1},
+    {"lpc_pack": 3},
+    {"lpc_pack": 3, "lpc_tile": 24},
+    {"lpc_pack": 4},
 ]
 DEFAULTS = {"chunks": 2, "first_chunk": 0, "single_tail": 1, "device_ltm": 1, "tail_lanes": 0, "tail_waves": 0, "alt_streams": 2, "lpc_pack": 0, "lpc_blocks_chains": 0, "lpc_threads": 0, "lpc_tile": 0}
 
