@@ -301,8 +301,14 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
             t = enc.analyze_device(d_pcm.data_ptr(), stride, n_file)
         else:
             # one file over the ranks (include/sla_hip.h): scan, exchange, bounds, the hot path on the own range
-            orw, piece = enc.shard_scan(d_pcm.data_ptr(), stride, hi0 - lo0)
-            file_or, mask = sdist.exchange_scan(orw, piece, n_file, dev_comm)
+            # (12 bytes per rank when no piece has an all-zero mask word -- no silence run can move a super-frame start then --
+            # and the 1-bit mask of the whole file only otherwise)
+            orw, zero_words = enc.shard_scan_counts(d_pcm.data_ptr(), stride, hi0 - lo0)
+            file_or, zeros = sdist.exchange_counts(orw, zero_words, dev_comm)
+            mask = None
+            if zeros != 0:
+                orw, piece = enc.shard_scan(d_pcm.data_ptr(), stride, hi0 - lo0)
+                file_or, mask = sdist.exchange_scan(orw, piece, n_file, dev_comm)
             bounds = sla_amd.shard_bounds(n_file, maxb, mask, world)
             lo, hi = bounds[rank], bounds[rank + 1]
             state["own"], state["file_or"] = (lo, hi), file_or

@@ -439,8 +439,14 @@ int sla_hip_analyze_batch_device(struct SLAEncoder* encoder, const int32_t* d_pc
  * The result is byte-identical to SLAEncoder_EncodeWhole of the whole file on one GPU. */
 int sla_hip_shard_scan(struct SLAEncoder* encoder, const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_samples,
                        uint32_t* or_word, uint64_t* nz_mask /* host, ceil(num_samples / 64) words */);
-int sla_hip_shard_bounds(uint32_t num_samples, uint32_t max_num_block_samples, const uint64_t* nz_mask, uint32_t world,
-                         uint32_t* bounds /* world + 1 entries */);
+/* Steps 1-3 without the mask when the file has no silence (the usual case): the scan only brings home the OR word and
+ * the number of all-zero 64-sample mask words of the piece; a silence run moves a super-frame start only when it is at
+ * least 2048 samples long, so if NO rank counts an all-zero word the hop is plain (nz_mask = NULL below) and the
+ * ranks all-gather 8 bytes each instead of N/8 in total.  Otherwise fall back to sla_hip_shard_scan + the mask. */
+int sla_hip_shard_scan_counts(struct SLAEncoder* encoder, const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_samples,
+                              uint32_t* or_word, uint32_t* zero_mask_words);
+int sla_hip_shard_bounds(uint32_t num_samples, uint32_t max_num_block_samples, const uint64_t* nz_mask /* NULL: no silence */,
+                         uint32_t world, uint32_t* bounds /* world + 1 entries */);
 int sla_hip_shard_analyze(struct SLAEncoder* encoder, const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_samples,
                           uint32_t file_or_word, float* timing_ms);
 int sla_hip_shard_header(const uint8_t* const* shard_headers /* world x 43 bytes */, uint32_t world, uint8_t* data, uint32_t data_size);

@@ -136,6 +136,7 @@ def lib():
         L.sla_hip_encoder_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         L.sla_hip_shard_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, u32p, C.POINTER(C.c_uint64)]
         L.sla_hip_shard_bounds.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint32, u32p]
+        L.sla_hip_shard_scan_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, u32p, u32p]
         L.sla_hip_shard_analyze.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
         L.sla_hip_shard_header.argtypes = [C.POINTER(u8p), C.c_uint32, u8p, C.c_uint32]
         L.sla_hip_encode_batch.argtypes = [C.c_void_p, C.POINTER(BatchItem), C.c_uint32]
@@ -179,7 +180,7 @@ EXPORTED_SYMBOLS = [
     "sla_hip_search_exact_lags", "sla_hip_launch_plan", "sla_hip_last_counters", "sla_hip_launch_lpc_rerun", "sla_hip_last_kernel_ms", "sla_hip_launch_lpc_blocks",
     "sla_hip_launch_lpc_f64", "sla_hip_launch_lattice_raw", "sla_hip_launch_tail_stages", "sla_hip_launch_emphasis_i32",
     "sla_hip_launch_emphasis_f64", "sla_hip_use_tuning", "sla_hip_launch_lattice_groups", "sla_hip_launch_ltm_solve",
-    "sla_hip_encoder_set_option", "sla_hip_shard_scan", "sla_hip_shard_bounds", "sla_hip_shard_analyze", "sla_hip_shard_header",
+    "sla_hip_encoder_set_option", "sla_hip_shard_scan", "sla_hip_shard_scan_counts", "sla_hip_shard_bounds", "sla_hip_shard_analyze", "sla_hip_shard_header",
     # include/SLAPredictor.h, include/SLACoder.h (per-call API of the reference, encode side)
     "SLALPCCalculator_Create", "SLALPCCalculator_Destroy", "SLALPCCalculator_CalculatePARCORCoefDouble",
     "SLALPCCalculator_EstimateCodeLength", "SLALPCSynthesizer_Create", "SLALPCSynthesizer_Destroy", "SLALPCSynthesizer_Reset",
@@ -377,6 +378,13 @@ class Encoder:
                                                  mask.ctypes.data_as(C.POINTER(C.c_uint64))), "sla_hip_shard_scan")
         return int(orw.value), mask
 
+    def shard_scan_counts(self, device_ptr, plane_stride, num_samples):
+        """sla_hip_shard_scan_counts: (OR of every sample word, number of all-zero 64-sample mask words) of a piece"""
+        orw, zw = C.c_uint32(0), C.c_uint32(0)
+        self._check(self._lib.sla_hip_shard_scan_counts(self._h, C.c_void_p(device_ptr), plane_stride, num_samples,
+                                                        C.byref(orw), C.byref(zw)), "sla_hip_shard_scan_counts")
+        return int(orw.value), int(zw.value)
+
     def shard_analyze(self, device_ptr, plane_stride, num_samples, file_or_word):
         """sla_hip_shard_analyze: the hot path on a range of a longer file whose OR word is `file_or_word`"""
         timing = (C.c_float * 12)()
@@ -430,12 +438,16 @@ class Encoder:
 def shard_bounds(num_samples, max_num_block_samples, nz_mask, world):
     """sla_hip_shard_bounds: [bounds[r], bounds[r+1]) = the samples rank r of `world` encodes, every bound a super-frame
     start of the whole file's hop over silence runs.  Pure host arithmetic of the library (no GPU needed)."""
-    mask = np.ascontiguousarray(nz_mask, np.uint64)
-    if len(mask) < (num_samples + 63) // 64:
-        raise ValueError("mask too short")
     bounds = np.zeros(world + 1, np.uint32)
+    if nz_mask is None:            # no rank counted an all-zero mask word (shard_scan_counts): nothing is silent
+        ptr = None
+    else:
+        mask = np.ascontiguousarray(nz_mask, np.uint64)
+        if len(mask) < (num_samples + 63) // 64:
+            raise ValueError("mask too short")
+        ptr = mask.ctypes.data_as(C.POINTER(C.c_uint64))
     rc = lib().sla_hip_shard_bounds(C.c_uint32(num_samples), C.c_uint32(max_num_block_samples),
-                                    mask.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_uint32(world), bounds.ctypes.data_as(u32p))
+                                    ptr, C.c_uint32(world), bounds.ctypes.data_as(u32p))
     if rc != 0:
         raise SlaError(rc, "sla_hip_shard_bounds")
     return [int(b) for b in bounds]

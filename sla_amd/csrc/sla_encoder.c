@@ -1806,13 +1806,41 @@ int sla_hip_shard_scan(struct SLAEncoder* e, const int32_t* d_pcm, uint64_t plan
   return 0;
 }
 
+/* The cheap form of the scan: OR word and the number of all-zero 64-sample mask words of the piece, 8 bytes home
+ * instead of num_samples / 8.  A silence run only moves a super-frame start when it is at least SLAI_MIN_BLOCK (2048)
+ * samples long, i.e. contains all-zero mask words: when no rank counts any, sla_hip_shard_bounds needs no mask at all
+ * (nz_mask = NULL) and the ranks exchange 12 bytes each instead of the mask -- the usual case. */
+int sla_hip_shard_scan_counts(struct SLAEncoder* e, const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_samples,
+                              uint32_t* or_word, uint32_t* zero_mask_words)
+{
+  const uint64_t nwords = ((uint64_t)num_samples + 63) / 64;
+  uint32_t ms;
+  if (e == NULL || d_pcm == NULL || or_word == NULL || zero_mask_words == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  RCCHK(check_ready(e));
+  if (plane_stride < num_samples) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  *or_word = 0; *zero_mask_words = 0;
+  if (num_samples == 0) { return 0; }
+  RCCHK(enter(e));
+  ms = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
+  RCCHK(dev_reserve(&e->d_or, 64));
+  RCCHK(dev_reserve(&e->d_nz, (size_t)(nwords + 2) * 8));
+  RCCHK(sla_hip_launch_prepass(d_pcm, plane_stride, e->wave_format.num_channels, num_samples, e->wave_format.bit_per_sample, ms,
+                               (uint32_t*)e->d_or.ptr, (uint64_t*)e->d_nz.ptr, e->stream));
+  HIPCHK(hipMemcpyAsync(e->h_or, e->d_or.ptr, 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  *or_word = e->h_or[0];
+  *zero_mask_words = e->h_or[1];
+  return 0;
+}
+
 /* The super-frame hop of the whole file (src/SLAEncoder.c:846-869 with the silence shortcut of :392-408), on the
  * host from the 1-bit mask; bounds[r] = the first super-frame start at or behind sample r * N / world. */
 int sla_hip_shard_bounds(uint32_t num_samples, uint32_t max_num_block_samples, const uint64_t* nz_mask, uint32_t world,
                          uint32_t* bounds)
 {
   uint32_t pos = 0, r = 1;
-  if (bounds == NULL || world == 0 || max_num_block_samples < SLAI_MIN_BLOCK || (nz_mask == NULL && num_samples != 0)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  /* nz_mask == NULL: no rank saw an all-zero mask word (sla_hip_shard_scan_counts), nothing is silent */
+  if (bounds == NULL || world == 0 || max_num_block_samples < SLAI_MIN_BLOCK) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   bounds[0] = 0;
   while (pos < num_samples && r < world) {
     const uint32_t remain = num_samples - pos;

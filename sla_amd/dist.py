@@ -86,6 +86,21 @@ def exchange_scan(or_word, mask_piece, num_samples, device="cpu"):
     return file_or, mask
 
 
+def exchange_counts(or_word, zero_words, device="cpu"):
+    """the cheap form of step 2 (sla_hip_shard_scan_counts): 12 bytes per rank -- the file's OR word and the number of
+    all-zero 64-sample mask words anywhere in it.  0 of those: no silence run can move a super-frame start, the bounds
+    need no mask (sla_amd.shard_bounds(..., None, ...))."""
+    world = dist.get_world_size()
+    t = torch.tensor([or_word & 0x7FFFFFFF, or_word >> 31, min(int(zero_words), 0x7FFFFFFF)], dtype=torch.int32, device=device)
+    allt = torch.empty(3 * world, dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(allt, t)
+    file_or, zeros = 0, 0
+    for lo, hi, zw in allt.cpu().numpy().reshape(world, 3):
+        file_or |= int(lo) | (int(hi) << 31)
+        zeros += int(zw)
+    return file_or, zeros
+
+
 def gather_images(image, device="cpu"):
     """step 5: every rank's image on every rank (sizes, then the padded bytes; one all-gather each)"""
     world = dist.get_world_size()
@@ -107,8 +122,15 @@ def encode_sharded(backend, num_samples, max_num_block_samples, device="cpu"):
     import sla_amd
     world, rank = dist.get_world_size(), dist.get_rank()
     lo0, hi0 = scan_piece(num_samples, world, rank)
-    or_word, piece = backend.scan(lo0, hi0)
-    file_or, mask = exchange_scan(or_word, piece, num_samples, device)
+    mask = None
+    if hasattr(backend, "scan_counts"):                       # usual case, no silence: 12 bytes per rank instead of the mask
+        or_word, zero_words = backend.scan_counts(lo0, hi0)
+        file_or, zeros = exchange_counts(or_word, zero_words, device)
+    else:
+        zeros = 1
+    if zeros != 0:
+        or_word, piece = backend.scan(lo0, hi0)
+        file_or, mask = exchange_scan(or_word, piece, num_samples, device)
     bounds = sla_amd.shard_bounds(num_samples, max_num_block_samples, mask, world)
     image = backend.encode_range(bounds[rank], bounds[rank + 1], file_or)
     images = gather_images(image, device)
@@ -120,11 +142,18 @@ def encode_sharded_serial(backends, num_samples, max_num_block_samples):
     GPU tests run on a single-GPU box, and a way to rehearse a sharding without launching ranks"""
     import sla_amd
     world = len(backends)
-    scans = [backends[r].scan(*scan_piece(num_samples, world, r)) for r in range(world)]
-    file_or = 0
-    for orw, _ in scans:
-        file_or |= orw
-    mask = np.concatenate([np.asarray(m, np.uint64) for _, m in scans]) if scans else np.zeros(0, np.uint64)
+    file_or, zeros, mask = 0, 1, None
+    if backends and all(hasattr(b, "scan_counts") for b in backends):
+        counts = [backends[r].scan_counts(*scan_piece(num_samples, world, r)) for r in range(world)]
+        zeros = sum(z for _, z in counts)
+        for orw, _ in counts:
+            file_or |= orw
+    if zeros != 0:
+        scans = [backends[r].scan(*scan_piece(num_samples, world, r)) for r in range(world)]
+        file_or = 0
+        for orw, _ in scans:
+            file_or |= orw
+        mask = np.concatenate([np.asarray(m, np.uint64) for _, m in scans]) if scans else np.zeros(0, np.uint64)
     bounds = sla_amd.shard_bounds(num_samples, max_num_block_samples, mask, world)
     images = [backends[r].encode_range(bounds[r], bounds[r + 1], file_or) for r in range(world)]
     return sla_amd.shard_join(images), bounds
@@ -139,7 +168,9 @@ class HipShardBackend:
         self.enc, self.pcm, self.maxb = encoder, pcm, max_num_block_samples
         self.base, self.dev = 0, None
 
-    def scan(self, lo, hi):
+    def _upload(self, lo, hi):
+        if self.dev is not None and self.base == lo:
+            return
         n = self.pcm.shape[1]
         top = min(n, hi + self.maxb)
         self.base = lo
@@ -149,6 +180,13 @@ class HipShardBackend:
         if top > lo:
             self.dev[:, :top - lo] = torch.from_numpy(np.ascontiguousarray(self.pcm[:, lo:top])).cuda()
         torch.cuda.synchronize()
+
+    def scan_counts(self, lo, hi):
+        self._upload(lo, hi)
+        return self.enc.shard_scan_counts(self.dev.data_ptr(), self.stride, hi - lo)
+
+    def scan(self, lo, hi):
+        self._upload(lo, hi)
         return self.enc.shard_scan(self.dev.data_ptr(), self.stride, hi - lo)
 
     def encode_range(self, lo, hi, file_or):

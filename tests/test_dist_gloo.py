@@ -195,3 +195,19 @@ def test_shard_bounds_follow_the_silence_hop():
         for r in range(1, world):
             target = (n * r + world - 1) // world
             assert b[r] == min([s for s in starts if s >= target] + [n])
+
+
+def test_shard_bounds_without_a_mask_when_nothing_is_silent():
+    """sla_hip_shard_scan_counts path: no rank counted an all-zero mask word -> sla_hip_shard_bounds(NULL) = the hop of a
+    file without silence = what the full mask gives when it has no silence run of a minimum block"""
+    import sla_amd
+    for n, maxb in ((100000, 4096), (5000, 4096), (4096 * 7, 4096), (123457, 16384), (3, 2048)):
+        bits = np.ones((n + 63) // 64 * 64, np.uint8)
+        bits[n:] = 0
+        # short zero runs (below a mask word, and a whole word or two but below the 2048-sample minimum block)
+        if n > 70000:
+            bits[50000:50060] = 0
+            bits[64 * 1000:64 * 1002] = 0
+        mask = np.packbits(bits.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).ravel()
+        for world in (1, 2, 3, 8):
+            assert sla_amd.shard_bounds(n, maxb, None, world) == sla_amd.shard_bounds(n, maxb, mask, world)

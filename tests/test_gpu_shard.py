@@ -79,3 +79,40 @@ def test_range_with_foreign_or_word_is_refused(hip):
             enc.shard_analyze(d.data_ptr(), 8192, 8192, 0x00F00000)       # the samples have bits outside that word
     finally:
         enc.close()
+
+
+def test_scan_counts_decide_whether_the_mask_is_needed(oracle, hip):
+    """sla_hip_shard_scan_counts: OR word + number of all-zero mask words of a piece; a file without such words takes the
+    12-byte exchange (encode_sharded_serial does, through HipShardBackend.scan_counts), one with a silence run the mask"""
+    import torch
+    from sla_amd import dist as sdist
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096, cap=(2, 4096, 16, 1, 8))
+    loud = S.synth_pcm(2, 60000, 16, 48000, seed=3)
+    loud[loud == 0] = 1 << 16
+    gap = loud.copy()
+    gap[:, 20000:26000] = 0
+    for pcm, silent in ((loud, False), (gap, True)):
+        pcm = np.ascontiguousarray(pcm)
+        enc = _encoder(hip, p)
+        try:
+            n = pcm.shape[1]
+            stride = (n + 63) // 64 * 64
+            d = torch.zeros((2, stride), dtype=torch.int32, device="cuda")
+            d[:, :n] = torch.from_numpy(pcm).cuda()
+            torch.cuda.synchronize()
+            orw, zeros = enc.shard_scan_counts(d.data_ptr(), stride, n)
+            orw2, mask = enc.shard_scan(d.data_ptr(), stride, n)
+            assert orw == orw2 and zeros == int((mask[:n // 64] == 0).sum()) + (1 if n % 64 and mask[n // 64] == 0 else 0)
+            assert (zeros != 0) == silent
+        finally:
+            enc.close()
+        ret, want = oracle.encode_whole(p, pcm)
+        assert ret == 0
+        for world in (2, 3):
+            encs = [_encoder(hip, p) for _ in range(world)]
+            try:
+                got, _ = sdist.encode_sharded_serial([sdist.HipShardBackend(e, pcm, 4096) for e in encs], pcm.shape[1], 4096)
+                assert got == want
+            finally:
+                for e in encs:
+                    e.close()
