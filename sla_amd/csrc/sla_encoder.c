@@ -1842,6 +1842,16 @@ int sla_hip_shard_bounds(uint32_t num_samples, uint32_t max_num_block_samples, c
   /* nz_mask == NULL: no rank saw an all-zero mask word (sla_hip_shard_scan_counts), nothing is silent */
   if (bounds == NULL || world == 0 || max_num_block_samples < SLAI_MIN_BLOCK) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   bounds[0] = 0;
+  if (nz_mask == NULL) {
+    /* no silence: the hop visits every multiple of the block length -- the first one at or behind each target */
+    for (r = 1; r < world; r++) {
+      const uint64_t target = ((uint64_t)num_samples * r + world - 1) / world;
+      const uint64_t at = (target + max_num_block_samples - 1) / max_num_block_samples * max_num_block_samples;
+      bounds[r] = (at < num_samples) ? (uint32_t)at : num_samples;
+    }
+    bounds[world] = num_samples;
+    return 0;
+  }
   while (pos < num_samples && r < world) {
     const uint32_t remain = num_samples - pos;
     const uint32_t window = (max_num_block_samples < remain) ? max_num_block_samples : remain;
