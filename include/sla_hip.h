@@ -466,7 +466,8 @@ int sla_hip_get_trace(struct SLAEncoder* encoder, sla_hip_trace* trace);
 
 /* Options of one encoder handle, by name (the environment variable of the same meaning, read once in
  * SLAEncoder_Create, is given in brackets).  Layout knobs: "lpc_pack" [SLA_HIP_LPC_PACK], "lpc_threads"
- * [SLA_HIP_LPC_THREADS], "tail_waves" [SLA_HIP_TAIL_WAVES], "chunks" [SLA_HIP_CHUNKS],
+ * [SLA_HIP_LPC_THREADS], "lpc_tile" (24 / 48 / 0 = automatic), "tail_waves" [SLA_HIP_TAIL_WAVES], "tail_lanes" (1: two
+ * taps per lane, 2: one tap per lane, 0: by the number of jobs), "chunks" [SLA_HIP_CHUNKS],
  * "threads" (host pool) [SLA_HIP_THREADS].  Route switches -- every route gives the same bytes; tests force the
  * slower exact ones through these: "search_exact" (0: no tile-sum search) [SLA_HIP_SEARCH=chain], "exact_bits"
  * (log2 of the tile-sum energy limit, 1..53) [SLA_HIP_EXACT_BITS], "cert_safety" (safety factor of the certificate for
