@@ -121,6 +121,7 @@ struct SLAEncoder {
   uint32_t stream_lanes;            /* worker lanes (1..4) */
   struct SLAEncoder* lane[4];
   int      is_lane;
+  struct slai_pool* upload_pool;    /* a lane's staging copies of its upload run on the parent's (otherwise idle, larger) pool: uploads take turns */
   int      streamed;                /* the last EncodeWhole ran on the lanes: this handle holds no analysis tables */
 
   /* last analysis */
@@ -2345,7 +2346,7 @@ static int upload_pass(struct SLAEncoder* e, const int32_t* const* input, uint32
       ctx.src = input[ch] + o; ctx.count = count;
       ctx.dst16 = mode16 ? (int16_t*)e->h_stage[slot].ptr : NULL;
       ctx.dst32 = mode16 ? NULL : (int32_t*)e->h_stage[slot].ptr;
-      parallel_for(e->pool, (uint32_t)((count + XFER_GRAIN - 1) / XFER_GRAIN), stage_in_one, &ctx);
+      parallel_for(e->upload_pool != NULL ? e->upload_pool : e->pool, (uint32_t)((count + XFER_GRAIN - 1) / XFER_GRAIN), stage_in_one, &ctx);
       if (mode16) {
         HIPCHK(hipMemcpyAsync(e->d_stage[slot].ptr, e->h_stage[slot].ptr, count * 2, hipMemcpyHostToDevice, e->stream));
         RCCHK(sla_hip_launch_unpack16((const int16_t*)e->d_stage[slot].ptr, dst, count, e->stream));
@@ -2542,7 +2543,9 @@ static void* stream_lane_main(void* varg)
     if (sc->failed != 0) { break; }
     sc->stamp[r][0] = now_ms() - sc->t0;
     for (ch = 0; ch < C; ch++) { planes[ch] = sc->input[ch] + lo; }
+    e->upload_pool = sc->parent->pool;
     rc = (enter(e) != 0) ? SLA_APIRESULT_NG : upload_pcm(e, planes, cnt);
+    e->upload_pool = NULL;
     pthread_mutex_lock(&sc->mu);
     sc->upload_turn = r + 1;
     pthread_cond_broadcast(&sc->cv);
