@@ -16,9 +16,7 @@ import sla_amd        # noqa: E402
 
 SETTINGS = [
     {},
-    {"lpc_pack": 3},
-    {"lpc_pack": 3, "lpc_tile": 24},
-    {"lpc_pack": 4},
+    {"chunks": 1},
 ]
 DEFAULTS = {"chunks": 2, "first_chunk": 0, "single_tail": 1, "device_ltm": 1, "tail_lanes": 0, "tail_waves": 0, "alt_streams": 2, "lpc_pack": 0, "lpc_blocks_chains": 0, "lpc_threads": 0, "lpc_tile": 0}
 
