@@ -504,6 +504,82 @@ __device__ __forceinline__ void lattice_chunk_wave(const int32_t* __restrict__ p
   }
 }
 
+// The same wave, with its samples and its results crossing global memory coalesced.  A lane owns LAT_T = 16 consecutive
+// samples, so when every lane loads and stores its own run, one access of the wave touches 64 different cache lines --
+// 2048 line transactions per wave for 8 KB of traffic, as many cycles on the CU's one address path as the lattice takes
+// on the wave's SIMD.  Here the wave reads its 1025 contiguous samples 64 at a time (4 transactions per access) into an
+// LDS tile padded by one word per 16 (lane stride 17: conflict-free when the lanes then pick up their runs), and the
+// residuals go back the same way.
+#define LAT_TILE_WORDS 1104         // 1025 samples + one pad word per 16, rounded up
+__device__ __forceinline__ uint32_t lat_pad(uint32_t p) { return p + (p >> 4); }
+
+__device__ __forceinline__ void lattice_chunk_wave_lds(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
+                                                       uint64_t blk_off, uint32_t blk_len, uint32_t chunk_start, uint32_t count,
+                                                       uint32_t channel, uint32_t int_shift, const int32_t* __restrict__ kc,
+                                                       int32_t* __restrict__ residual, uint32_t lane, bool raw, int32_t* __restrict__ tile)
+{
+  const uint32_t halo_lanes = (order + LAT_T - 1) / LAT_T;
+  const int64_t base = (int64_t)chunk_start - (int64_t)halo_lanes * LAT_T;      // block-relative index of lane 0's first sample
+  // tile slot e holds sample base - 1 + e (e = 0 .. 1024), zero outside the block
+#pragma unroll
+  for (int j = 0; j < 17; j++) {
+    const uint32_t e = (uint32_t)j * 64u + lane;
+    if (e <= (uint32_t)(SLA_WAVE * LAT_T)) {
+      const int64_t p = base - 1 + (int64_t)e;
+      int32_t v = 0;
+      if (p >= 0 && p < (int64_t)blk_len) { v = load_int(pcm, stride, ms, channel, blk_off + (uint64_t)p, int_shift); }
+      tile[lat_pad(e)] = v;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  int32_t f[LAT_T], b[LAT_T];
+  {
+    int32_t prev = tile[lat_pad(lane * LAT_T)];
+#pragma unroll
+    for (int i = 0; i < LAT_T; i++) {
+      const int32_t cur = tile[lat_pad(lane * LAT_T + 1 + (uint32_t)i)];
+      // pre-emphasis y[n] = x[n] - ((x[n-1]*31)>>5); raw: the caller's samples are the lattice input as they are
+      const int32_t y = raw ? cur : (int32_t)((uint32_t)cur - (uint32_t)((int32_t)((uint32_t)prev * 31u) >> 5));
+      f[i] = y; b[i] = y;
+      prev = cur;
+    }
+  }
+  for (uint32_t m = 1; m <= order; m++) {
+    const int32_t k = kc[m];                       // wave-uniform -> scalar load
+    int32_t carry = __shfl_up(b[LAT_T - 1], 1);    // b_{m-1} of the sample just before this lane's run
+    if (lane == 0) { carry = 0; }
+#pragma unroll
+    for (int i = LAT_T - 1; i >= 1; i--) {
+      int32_t nf = (int32_t)((uint32_t)f[i] - (uint32_t)lat_term(k, b[i - 1]));
+      int32_t nb = (int32_t)((uint32_t)b[i - 1] - (uint32_t)lat_term(k, f[i]));
+      f[i] = nf; b[i] = nb;
+    }
+    {
+      int32_t nf = (int32_t)((uint32_t)f[0] - (uint32_t)lat_term(k, carry));
+      int32_t nb = (int32_t)((uint32_t)carry - (uint32_t)lat_term(k, f[0]));
+      f[0] = nf; b[0] = nb;
+    }
+  }
+  // results through the tile (slot e = sample base + e now), stored 64 consecutive samples at a time
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int i = 0; i < LAT_T; i++) { tile[lat_pad(lane * LAT_T + (uint32_t)i)] = f[i]; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  int32_t* dst = residual + (uint64_t)channel * stride + blk_off;
+#pragma unroll
+  for (int j = 0; j < LAT_T; j++) {
+    const uint32_t e = (uint32_t)j * 64u + lane;
+    const int64_t p = base + (int64_t)e;
+    if (p >= (int64_t)chunk_start && p < (int64_t)chunk_start + count) { dst[p] = tile[lat_pad(e)]; }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_lpc_blocks: the chosen blocks (one candidate per group = the whole windowed block).
 //
@@ -1419,13 +1495,14 @@ void k_lattice(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, ui
                const sla_hip_lattice_chunk* __restrict__ chunks, uint32_t num_chunks,
                const int32_t* __restrict__ kint, int32_t* __restrict__ residual, unsigned long long* span, uint32_t raw)
 {
+  __shared__ int32_t s_tile[4][LAT_TILE_WORDS];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t cid = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (cid >= num_chunks) { return; }
   span_begin(span);
   const sla_hip_lattice_chunk ck = chunks[cid];
-  lattice_chunk_wave(pcm, stride, ms, order, ck.blk_off, ck.blk_len, ck.chunk_start, ck.count, ck.channel, ck.int_shift,
-                     kint + (uint64_t)ck.slot * (order + 1), residual, lane, raw != 0);
+  lattice_chunk_wave_lds(pcm, stride, ms, order, ck.blk_off, ck.blk_len, ck.chunk_start, ck.count, ck.channel, ck.int_shift,
+                         kint + (uint64_t)ck.slot * (order + 1), residual, lane, raw != 0, s_tile[threadIdx.x >> 6]);
   span_end(span);
 }
 
@@ -1437,6 +1514,7 @@ void k_lattice_groups(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t
                       const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, uint32_t cpg,
                       const int32_t* __restrict__ kint, int32_t* __restrict__ residual, unsigned long long* span)
 {
+  __shared__ int32_t s_tile[4][LAT_TILE_WORDS];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t gi = w / cpg, c = w - gi * cpg;
@@ -1446,8 +1524,8 @@ void k_lattice_groups(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t
   const uint32_t per = (SLA_WAVE - (order + LAT_T - 1) / LAT_T) * LAT_T;
   const uint32_t at = c * per;
   if (at < g.num_samples) {
-    lattice_chunk_wave(pcm, stride, ms, order, g.pcm_off, g.num_samples, at, (g.num_samples - at < per) ? (g.num_samples - at) : per,
-                       g.channel, g.int_shift, kint + (uint64_t)g.slot_first * (order + 1), residual, lane, false);
+    lattice_chunk_wave_lds(pcm, stride, ms, order, g.pcm_off, g.num_samples, at, (g.num_samples - at < per) ? (g.num_samples - at) : per,
+                           g.channel, g.int_shift, kint + (uint64_t)g.slot_first * (order + 1), residual, lane, false, s_tile[threadIdx.x >> 6]);
   }
   span_end(span);
 }
