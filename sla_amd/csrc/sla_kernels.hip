@@ -1246,18 +1246,58 @@ __device__ __forceinline__ double schur_error(const double* __restrict__ rc, dou
   return (!bad && u[0] > 0.0) ? u[0] : nan;
 }
 
+// Levinson-Durbin of one candidate entirely in registers (the recursion of k_blocks_finish, src/SLAPredictor.c:253-328;
+// stages and coefficient indices unrolled): o = { r0, parcor[0..order] }.  Same operations in the same order as
+// levinson_out, which keeps its vectors in LDS.
+template <int P>
+__device__ __forceinline__ void levinson_regs(const double* __restrict__ rc, double* __restrict__ o, uint32_t order, uint32_t n)
+{
+  double r[P + 1], a[P + 1], par[P + 1];
+#pragma unroll
+  for (int i = 0; i <= P; i++) { r[i] = ((uint32_t)i <= order) ? rc[i] : 0.0; a[i] = 0.0; par[i] = 0.0; }
+  if (!(n < order || fabs(r[0]) < (double)FLT_EPSILON)) {
+    a[0] = 1.0;
+    a[1] = -r[1] / r[0];
+    par[1] = r[1] / r[0];
+    double e = r[0] + r[1] * a[1];
+#pragma unroll
+    for (int d = 1; d < P; d++) {
+      if ((uint32_t)d < order) {
+        double gamma = 0.0;
+#pragma unroll
+        for (int i = 0; i <= d; i++) { gamma += a[i] * r[d + 1 - i]; }
+        gamma /= (-e);
+        e = (1.0 - gamma * gamma) * e;
+        double nw[P + 1];
+#pragma unroll
+        for (int i = 1; i <= d; i++) { nw[i] = a[i] + gamma * a[d + 1 - i]; }
+#pragma unroll
+        for (int i = 1; i <= d; i++) { a[i] = nw[i]; }
+        a[0] = 1.0 + gamma * 0.0;
+        a[d + 1] = 0.0 + gamma * 1.0;
+        par[d + 1] = -gamma;
+      }
+    }
+  }
+  o[0] = r[0];
+#pragma unroll
+  for (int j = 0; j <= P; j++) { if ((uint32_t)j <= order) { o[1 + j] = par[j]; } }
+}
+
 // One wave takes `gpw` groups at once when their candidates fit its lanes (a 4096-sample window has 10 candidates: six
 // groups per wave instead of one wave with 10 busy lanes per group -- the kernel is bound by instruction issue); a
 // group with more than 64 candidates (windows above 8192 samples) takes several passes of one wave.
 // LDS: r[lanes][order+1] | a[lanes][order+2] | v[lanes][order+2] (work space of the exact windows' Levinson recursion)
-template <int P>           // P >= order: 16, 32, 48, 64; 0 = no certificate (cert <= 0, or an order above 64)
+template <int P, int mode>           // P >= order: 16, 32, 48, 64
 __global__ __launch_bounds__(64)
 void k_search_finish(uint32_t order, uint32_t lags, uint32_t gpw, uint32_t per,
                      const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, const sla_hip_lpc_cand* __restrict__ cands,
-                     const double* __restrict__ tile_sums, double* __restrict__ out, double exact_limit, double cert, uint32_t mode)
+                     const double* __restrict__ tile_sums, double* __restrict__ out, double exact_limit, double cert)
 {
-  // mode 0: every group; 1: only the groups over the exactness limit (no Levinson work space in LDS: three times the
-  // waves per CU at order 48); 2: only the groups below it.  Material that may have both kinds is launched as 1 + 2.
+  // mode 0: every group is known to be under the exactness limit (16-bit material): Levinson-Durbin in registers, LDS only
+  // holds r; 1: only the groups over the limit (certificate; LDS only holds r: three times the waves per CU at order 48);
+  // 2: only the groups below it, Levinson-Durbin with its vectors in LDS.  Material that may have both kinds is launched
+  // as 1 + 2.
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ sla_hip_lpc_group s_g[XF_GROUPS];
   __shared__ double s_energy[XF_GROUPS];
@@ -1313,8 +1353,9 @@ void k_search_finish(uint32_t order, uint32_t lags, uint32_t gpw, uint32_t per,
       double* o = out + ((uint64_t)g.slot_first + ci) * O2;
       const double* rc = r + (size_t)lane * O1;
       if (energy < exact_limit) {
-        if (mode != 1) { levinson_out(rc, av + (size_t)lane * O2, vv + (size_t)lane * O2, o, order, cd.len); }
-      } else if (P == 0) {
+        if (mode == 0) { levinson_regs<P>(rc, o, order, cd.len); }
+        else if (mode == 2) { levinson_out(rc, av + (size_t)lane * O2, vv + (size_t)lane * O2, o, order, cd.len); }
+      } else if (mode != 1 || !(cert > 0.0)) {
         o[0] = __longlong_as_double(0x7FF8000000000000ll);          // flagged: rerun as serial chains
       } else {
         // slot layout of a certified candidate: { r0, width, log2(e_p / r0), 0, .. }
@@ -1330,7 +1371,7 @@ void k_search_finish(uint32_t order, uint32_t lags, uint32_t gpw, uint32_t per,
           for (int bk = 0; bk < 3; bk++) {
             const double rb = (bk == 0) ? r0 : (bk == 1) ? (r0 + d) : (r0 - d);
             e3[bk] = (bk == 2 && !(r0 - d > (double)FLT_EPSILON)) ? __longlong_as_double(0x7FF8000000000000ll)
-                                                                  : schur_error<(P > 0) ? P : 1>(rc, rb, order);
+                                                                  : schur_error<P>(rc, rb, order);
           }
           const double e_mid = e3[0], e_hi = e3[1], e_lo = e3[2];
           if (e_mid > 0.0 && e_lo > 0.0 && e_hi >= e_mid && e_mid >= e_lo && e_hi < inf) {
@@ -2527,25 +2568,28 @@ extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_
   // |x| < 2 in the search's unit (mid/side: side = l - r), so a window's energy stays below 4 x its length: when even
   // that is under the limit (16-bit material) every group takes the exact path and one launch does
   const bool all_exact = (exact_limit >= 4.0 * (double)max_window);
-  const int pclass = !(cert_safety > 0.0) ? 0 : (order <= 16) ? 16 : (order <= 32) ? 32 : (order <= 48) ? 48 : (order <= 64) ? 64 : 0;
+  const int pclass = (order <= 16) ? 16 : (order <= 32) ? 32 : (order <= 48) ? 48 : 64;      // (lags != 0: order <= 52)
 #define SLA_FINISH(PP) do { \
-    e = ensure_dynamic_lds((const void*)k_search_finish<PP>, lds); \
-    if (e != hipSuccess) { return hip_rc(e); } \
     if (all_exact) { \
-      hipLaunchKernelGGL(k_search_finish<PP>, dim3((num_groups + gpw - 1) / gpw), dim3(64), lds, st, order, lags, gpw, per, \
-                         d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety, 0u); \
+      e = ensure_dynamic_lds((const void*)k_search_finish<PP, 0>, lds_r); \
+      if (e != hipSuccess) { return hip_rc(e); } \
+      hipLaunchKernelGGL((k_search_finish<PP, 0>), dim3((num_groups + gpw - 1) / gpw), dim3(64), lds_r, st, order, lags, gpw, per, \
+                         d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety); \
     } else { \
-      hipLaunchKernelGGL(k_search_finish<PP>, dim3((num_groups + gpw - 1) / gpw), dim3(64), lds_r, st, order, lags, gpw, per, \
-                         d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety, 1u); \
-      hipLaunchKernelGGL(k_search_finish<PP>, dim3((num_groups + gpw - 1) / gpw), dim3(64), lds, st, order, lags, gpw, per, \
-                         d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety, 2u); \
+      e = ensure_dynamic_lds((const void*)k_search_finish<PP, 1>, lds_r); \
+      if (e != hipSuccess) { return hip_rc(e); } \
+      e = ensure_dynamic_lds((const void*)k_search_finish<PP, 2>, lds); \
+      if (e != hipSuccess) { return hip_rc(e); } \
+      hipLaunchKernelGGL((k_search_finish<PP, 1>), dim3((num_groups + gpw - 1) / gpw), dim3(64), lds_r, st, order, lags, gpw, per, \
+                         d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety); \
+      hipLaunchKernelGGL((k_search_finish<PP, 2>), dim3((num_groups + gpw - 1) / gpw), dim3(64), lds, st, order, lags, gpw, per, \
+                         d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety); \
     } } while (0)
   switch (pclass) {
     case 16: SLA_FINISH(16); break;
     case 32: SLA_FINISH(32); break;
     case 48: SLA_FINISH(48); break;
-    case 64: SLA_FINISH(64); break;
-    default: SLA_FINISH(0); break;
+    default: SLA_FINISH(64); break;
   }
 #undef SLA_FINISH
   return hip_rc(hipGetLastError());
