@@ -312,7 +312,7 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
             bounds = sla_amd.shard_bounds(n_file, maxb, mask, world)
             lo, hi = bounds[rank], bounds[rank + 1]
             state["own"], state["file_or"] = (lo, hi), file_or
-            t = enc.shard_analyze(d_pcm.data_ptr() + 4 * (lo - base), stride, hi - lo, file_or)
+            t = enc.shard_analyze(d_pcm.data_ptr() + 4 * (lo - base), stride, hi - lo, file_or, no_silence=(mask is None))
         span_ms[:] += np.array(enc.last_kernel_ms())
         if world > 1:
             if overlap:

@@ -449,6 +449,11 @@ int sla_hip_shard_bounds(uint32_t num_samples, uint32_t max_num_block_samples, c
                          uint32_t world, uint32_t* bounds /* world + 1 entries */);
 int sla_hip_shard_analyze(struct SLAEncoder* encoder, const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_samples,
                           uint32_t file_or_word, float* timing_ms);
+/* sla_hip_shard_analyze when the counts of step 1 showed no all-zero mask word anywhere in the file (and its OR word is
+ * not 0): nothing the range's own prepass could find, so it is skipped (one kernel and one host wait per call less).
+ * The caller vouches for the counts; a range WITH silence analysed through this call gives a valid but different file. */
+int sla_hip_shard_analyze_no_silence(struct SLAEncoder* encoder, const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_samples,
+                                     uint32_t file_or_word, float* timing_ms);
 int sla_hip_shard_header(const uint8_t* const* shard_headers /* world x 43 bytes */, uint32_t world, uint8_t* data, uint32_t data_size);
 
 /* Device pointers of the last analysis (for RCCL gathers / tests). */

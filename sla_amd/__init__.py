@@ -138,6 +138,7 @@ def lib():
         L.sla_hip_shard_bounds.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint32, u32p]
         L.sla_hip_shard_scan_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, u32p, u32p]
         L.sla_hip_shard_analyze.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+        L.sla_hip_shard_analyze_no_silence.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
         L.sla_hip_shard_header.argtypes = [C.POINTER(u8p), C.c_uint32, u8p, C.c_uint32]
         L.sla_hip_encode_batch.argtypes = [C.c_void_p, C.POINTER(BatchItem), C.c_uint32]
         L.sla_hip_analyze_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, u32p, u32p, C.c_uint32,
@@ -180,7 +181,7 @@ EXPORTED_SYMBOLS = [
     "sla_hip_search_exact_lags", "sla_hip_launch_plan", "sla_hip_last_counters", "sla_hip_launch_lpc_rerun", "sla_hip_last_kernel_ms", "sla_hip_launch_lpc_blocks",
     "sla_hip_launch_lpc_f64", "sla_hip_launch_lattice_raw", "sla_hip_launch_tail_stages", "sla_hip_launch_emphasis_i32",
     "sla_hip_launch_emphasis_f64", "sla_hip_use_tuning", "sla_hip_launch_lattice_groups", "sla_hip_launch_ltm_solve",
-    "sla_hip_encoder_set_option", "sla_hip_shard_scan", "sla_hip_shard_scan_counts", "sla_hip_shard_bounds", "sla_hip_shard_analyze", "sla_hip_shard_header",
+    "sla_hip_encoder_set_option", "sla_hip_shard_scan", "sla_hip_shard_scan_counts", "sla_hip_shard_bounds", "sla_hip_shard_analyze", "sla_hip_shard_analyze_no_silence", "sla_hip_shard_header",
     # include/SLAPredictor.h, include/SLACoder.h (per-call API of the reference, encode side)
     "SLALPCCalculator_Create", "SLALPCCalculator_Destroy", "SLALPCCalculator_CalculatePARCORCoefDouble",
     "SLALPCCalculator_EstimateCodeLength", "SLALPCSynthesizer_Create", "SLALPCSynthesizer_Destroy", "SLALPCSynthesizer_Reset",
@@ -385,11 +386,13 @@ class Encoder:
                                                         C.byref(orw), C.byref(zw)), "sla_hip_shard_scan_counts")
         return int(orw.value), int(zw.value)
 
-    def shard_analyze(self, device_ptr, plane_stride, num_samples, file_or_word):
-        """sla_hip_shard_analyze: the hot path on a range of a longer file whose OR word is `file_or_word`"""
+    def shard_analyze(self, device_ptr, plane_stride, num_samples, file_or_word, no_silence=False):
+        """sla_hip_shard_analyze: the hot path on a range of a longer file whose OR word is `file_or_word`
+        (no_silence: sla_hip_shard_analyze_no_silence -- the file's scan counted no all-zero mask word)"""
         timing = (C.c_float * 12)()
-        self._check(self._lib.sla_hip_shard_analyze(self._h, C.c_void_p(device_ptr), plane_stride, num_samples,
-                                                    C.c_uint32(file_or_word), timing), "sla_hip_shard_analyze")
+        fn = self._lib.sla_hip_shard_analyze_no_silence if (no_silence and file_or_word != 0) else self._lib.sla_hip_shard_analyze
+        self._check(fn(self._h, C.c_void_p(device_ptr), plane_stride, num_samples,
+                       C.c_uint32(file_or_word), timing), "sla_hip_shard_analyze")
         self.num_samples = num_samples
         return list(timing)
 

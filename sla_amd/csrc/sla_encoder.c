@@ -106,6 +106,7 @@ struct SLAEncoder {
   /* one file over several GPUs (sla_hip_shard_*): this handle analyses a range of a longer file whose OR word -- hence
    * offset_lshift and sample unit -- is the whole file's, not the range's.  0: off */
   uint32_t file_or_word;
+  int      skip_prepass;            /* with file_or_word: the caller vouches that the file has no all-zero mask word */
 
   /* batch of files in one pass (sla_hip_encode_batch): the files occupy [seg_start, seg_start + seg_len) of the
    * planes, every start a multiple of SLA_HIP_PREPASS_TILE, all with the same offset_lshift.  nsegs == 0: one file
@@ -873,6 +874,18 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
   RCCHK(dev_reserve(&e->d_nz, (size_t)(nwords + 2) * 8));
   RCCHK(pin_reserve(&e->h_nz, (size_t)(nwords + 2) * 8));
   HIPCHK(hipEventRecord(e->ev[0], e->stream));
+  if (e->skip_prepass && e->file_or_word != 0) {
+    /* sla_hip_shard_analyze_no_silence: the caller's scan of the whole file counted no all-zero mask word, and it knows
+     * the file's OR word -- nothing the prepass could add: no super-frame of this range can be silent */
+    HIPCHK(hipEventRecord(e->ev[1], e->stream));
+    e->h_or[0] = e->file_or_word; e->h_or[1] = 0;
+    if (e->nz_ones_cap != e->h_nz.cap) { e->nz_ones_cap = e->h_nz.cap; e->nz_ones_words = 0; }
+    if (e->nz_ones_words < nwords) { memset((uint64_t*)e->h_nz.ptr + e->nz_ones_words, 0xFF, (size_t)(nwords - e->nz_ones_words) * 8); }
+    e->nz_ones_words = nwords;
+    RCCHK(build_tables(e, a, NULL));
+    RCCHK(pipeline_reserve(e, a));
+    RCCHK(upload_search_tables(e, a));
+  } else {
   RCCHK(sla_hip_launch_prepass(e->pcm_dev, e->stride, C, n, bps, ms, (uint32_t*)e->d_or.ptr, (uint64_t*)e->d_nz.ptr, e->stream));
   HIPCHK(hipEventRecord(e->ev[1], e->stream));
   {
@@ -904,6 +917,7 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
       }
       e->nz_ones_words = head_words;       /* the words behind it were just overwritten by the tail copy */
     }
+  }
   }
   nz = (const uint64_t*)e->h_nz.ptr;
   ((uint64_t*)e->h_nz.ptr)[nwords] = 0; ((uint64_t*)e->h_nz.ptr)[nwords + 1] = 0;
@@ -1873,6 +1887,19 @@ int sla_hip_shard_analyze(struct SLAEncoder* e, const int32_t* d_pcm, uint64_t p
   e->file_or_word = file_or_word;
   rc = sla_hip_analyze_device(e, d_pcm, plane_stride, num_samples, NULL, timing_ms);
   e->file_or_word = 0;
+  return rc;
+}
+
+/* sla_hip_shard_analyze for a file whose scan (sla_hip_shard_scan_counts on every rank) counted no all-zero mask word:
+ * with the file's OR word known and no silence anywhere, the range needs no prepass of its own */
+int sla_hip_shard_analyze_no_silence(struct SLAEncoder* e, const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_samples,
+                                     uint32_t file_or_word, float* timing_ms)
+{
+  int rc;
+  if (e == NULL || file_or_word == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  e->file_or_word = file_or_word; e->skip_prepass = 1;
+  rc = sla_hip_analyze_device(e, d_pcm, plane_stride, num_samples, NULL, timing_ms);
+  e->file_or_word = 0; e->skip_prepass = 0;
   return rc;
 }
 

@@ -132,7 +132,7 @@ def encode_sharded(backend, num_samples, max_num_block_samples, device="cpu"):
         or_word, piece = backend.scan(lo0, hi0)
         file_or, mask = exchange_scan(or_word, piece, num_samples, device)
     bounds = sla_amd.shard_bounds(num_samples, max_num_block_samples, mask, world)
-    image = backend.encode_range(bounds[rank], bounds[rank + 1], file_or)
+    image = backend.encode_range(bounds[rank], bounds[rank + 1], file_or, **({"no_silence": True} if mask is None and hasattr(backend, "scan_counts") else {}))
     images = gather_images(image, device)
     return sla_amd.shard_join(images) if rank == 0 else None
 
@@ -155,7 +155,8 @@ def encode_sharded_serial(backends, num_samples, max_num_block_samples):
             file_or |= orw
         mask = np.concatenate([np.asarray(m, np.uint64) for _, m in scans]) if scans else np.zeros(0, np.uint64)
     bounds = sla_amd.shard_bounds(num_samples, max_num_block_samples, mask, world)
-    images = [backends[r].encode_range(bounds[r], bounds[r + 1], file_or) for r in range(world)]
+    extra = {"no_silence": True} if (mask is None and zeros == 0) else {}
+    images = [backends[r].encode_range(bounds[r], bounds[r + 1], file_or, **extra) for r in range(world)]
     return sla_amd.shard_join(images), bounds
 
 
@@ -189,10 +190,10 @@ class HipShardBackend:
         self._upload(lo, hi)
         return self.enc.shard_scan(self.dev.data_ptr(), self.stride, hi - lo)
 
-    def encode_range(self, lo, hi, file_or):
+    def encode_range(self, lo, hi, file_or, no_silence=False):
         if hi <= lo:
             return b""                       # more ranks than super-frames: nothing to encode here
         off = lo - self.base
         assert off >= 0 and hi - self.base <= self.stride
-        self.enc.shard_analyze(self.dev.data_ptr() + 4 * off, self.stride, hi - lo, file_or)
+        self.enc.shard_analyze(self.dev.data_ptr() + 4 * off, self.stride, hi - lo, file_or, no_silence=no_silence)
         return self.enc.pack(8 * self.pcm.shape[0] * (hi - lo) + 65536, on_device=True)
