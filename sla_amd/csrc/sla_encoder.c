@@ -2096,6 +2096,7 @@ static int download_bytes(struct SLAEncoder* e, uint8_t* dst, const uint8_t* d_s
 
 typedef struct {
   struct SLAEncoder* e; sla_hip_pack_block* pb; sla_hip_rice_job* jobs; uint8_t* hdr; const uint32_t* job_of; int bad;
+  int what;                      /* 1: block records + Rice jobs (what the code-length kernels need), 2: header bytes */
 } pack_hdr_ctx_t;
 
 /* header bytes and Rice jobs of one block, at the places pack_device_core laid out */
@@ -2120,21 +2121,24 @@ static void pack_hdr_one(void* vctx, uint32_t b)
     memcpy(&ltm[ch * SLAI_MAX_TAPS], bc->ltm_q, sizeof(int32_t) * SLAI_MAX_TAPS);
   }
   bp.code = e->code + (size_t)b * C * O1; bp.rshift = rshift; bp.pitch = pitch; bp.ltm_q = ltm; bp.rice_init = rice;
-  pb->blk_off = k->start; pb->num_samples = k->nsmpl; pb->type = k->type;
+  if (c->what == 1) {
+    pb->blk_off = k->start; pb->num_samples = k->nsmpl; pb->type = k->type;
+    pb->raw_bits = bp.bps - e->lshift;
+    if (k->type == SLAI_BLK_COMPRESS) {
+      slai_coding_mode(rice, C, pb->golomb_m);
+      for (ch = 0; ch < C; ch++) {
+        sla_hip_rice_job* j = &c->jobs[c->job_of[b] + ch];
+        j->blk_off = k->start; j->blk_len = k->nsmpl; j->channel = ch; j->rice_init = rice[ch]; j->golomb_m = pb->golomb_m[ch];
+      }
+    }
+    return;
+  }
   if (pb->header_bytes >= 16) {
     if (slai_pack_header(&bp, c->hdr + pb->header_off, pb->header_bytes) != pb->header_bytes) { c->bad = 1; return; }
   } else {                                      /* (the packer wants 16 bytes of room: a silent block's header has 11) */
     const uint32_t got = slai_pack_header(&bp, tmp, sizeof(tmp));
     if (got != pb->header_bytes) { c->bad = 1; return; }
     memcpy(c->hdr + pb->header_off, tmp, got);
-  }
-  pb->raw_bits = bp.bps - e->lshift;
-  if (k->type == SLAI_BLK_COMPRESS) {
-    slai_coding_mode(rice, C, pb->golomb_m);
-    for (ch = 0; ch < C; ch++) {
-      sla_hip_rice_job* j = &c->jobs[c->job_of[b] + ch];
-      j->blk_off = k->start; j->blk_len = k->nsmpl; j->channel = ch; j->rice_init = rice[ch]; j->golomb_m = pb->golomb_m[ch];
-    }
   }
 }
 
@@ -2184,9 +2188,8 @@ static int pack_device_core(struct SLAEncoder* e, pack_seg_t* segs, uint32_t nse
       if (k->type == SLAI_BLK_COMPRESS) { njobs += C; }
     }
     if (hdr_used > hdr_cap) { free(job_of); return SLA_APIRESULT_NG; }
-    hc.e = e; hc.pb = pb; hc.jobs = jobs; hc.hdr = hdr; hc.job_of = job_of; hc.bad = 0;
+    hc.e = e; hc.pb = pb; hc.jobs = jobs; hc.hdr = hdr; hc.job_of = job_of; hc.bad = 0; hc.what = 1;
     parallel_for(e->pool, nb, pack_hdr_one, &hc);
-    if (hc.bad) { free(job_of); return SLA_APIRESULT_NG; }
   }
 
   tp1 = now_ms();
@@ -2200,8 +2203,15 @@ static int pack_device_core(struct SLAEncoder* e, pack_seg_t* segs, uint32_t nse
                                  (uint16_t*)e->d_kk.ptr, (uint64_t*)e->d_fold.ptr, e->stream);
     if (rc != 0) { free(job_of); return rc; }
     HIPCHK(hipMemcpyAsync(e->h_fold.ptr, e->d_fold.ptr, sizeof(uint64_t) * njobs, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
   }
+  {
+    /* the header bytes, while the device walks the Rice parameters */
+    pack_hdr_ctx_t hc;
+    hc.e = e; hc.pb = pb; hc.jobs = jobs; hc.hdr = hdr; hc.job_of = job_of; hc.bad = 0; hc.what = 2;
+    parallel_for(e->pool, nb, pack_hdr_one, &hc);
+    if (hc.bad) { free(job_of); (void)hipStreamSynchronize(e->stream); return SLA_APIRESULT_NG; }
+  }
+  if (njobs > 0) { HIPCHK(hipStreamSynchronize(e->stream)); }
 
   tp2 = now_ms();
   /* block sizes -> offsets; a file = 43 header bytes + its blocks */
