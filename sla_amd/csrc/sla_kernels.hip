@@ -1415,7 +1415,16 @@ __device__ __forceinline__ double plan_code_length(double sumsq, uint32_t n, uin
   power = log(power) * l2e - log((double)n) * l2e;
   double gain = 0.0;
   if (width != 0.0) { gain = parcor[1]; }                        // certified candidate: log2(e_p / r0) itself (k_search_finish)
-  else { for (uint32_t ord = 1; ord <= order; ord++) { gain += log(1.0 - parcor[ord] * parcor[ord]) * l2e; } }
+  else {
+    // sum of log(1 - k^2), eight factors per logarithm: the value only has to agree with the host's sum of single
+    // logarithms to within the margin every comparison must clear (1e-4 bytes; this differs by ~1e-11), and a product
+    // of eight factors >= 2^-53 cannot underflow
+    double prod = 1.0;
+    for (uint32_t ord = 1; ord <= order; ord++) {
+      prod *= 1.0 - parcor[ord] * parcor[ord];
+      if ((ord & 7u) == 0 || ord == order) { gain += log(prod) * l2e; prod = 1.0; }
+    }
+  }
   double len = 1.9426950408889634 + 0.5 * (power + gain);
   len /= 8;
   if (!(fabs(len) > 1e-9 + width / 16.0)) { sure = false; }     // too close to the clamp (or NaN)
