@@ -17,6 +17,12 @@ import sla_amd        # noqa: E402
 SETTINGS = [
     {},
     {"chunks": 1},
+    {"chunks": 3},
+    {"first_chunk": 400},
+    {"alt_streams": 0},
+    {"alt_streams": 1},
+    {"lpc_tile": 24},
+    {"device_ltm": 0, "single_tail": 0},
 ]
 DEFAULTS = {"chunks": 2, "first_chunk": 0, "single_tail": 1, "device_ltm": 1, "tail_lanes": 0, "tail_waves": 0, "alt_streams": 2, "lpc_pack": 0, "lpc_blocks_chains": 0, "lpc_threads": 0, "lpc_tile": 0}
 
