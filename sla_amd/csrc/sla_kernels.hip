@@ -2183,120 +2183,158 @@ __device__ __forceinline__ double ext_to_double(ext80 x)
 
 #define LTM_NT 5
 
-__device__ int ltm_lu_factor(double (*A)[LTM_NT], uint32_t dim, uint32_t* perm, double* scale)
+// The solve with the tap count as a template parameter: every loop is unrolled and every index static, so the 5 x 5 work
+// arrays live in registers (with run-time dimensions and the pivot's row index they sat in scratch memory: 66 us per
+// C5 launch for 45 000 tiny solves).  The pivot row and the permuted right-hand side are picked by compare-and-select
+// over the (at most five) candidates; the arithmetic and its order are the host's (sla_ltm.c), operation for operation.
+template <int D>
+__device__ __forceinline__ int ltm_lu_factor_s(double (&A)[D][D], uint32_t (&perm)[D], double (&scale)[D])
 {
-  uint32_t row, col, k, imax;
-  double big, sum;
-  for (row = 0; row < dim; row++) {
-    big = 0.0;
-    for (col = 0; col < dim; col++) { if (fabs(A[row][col]) > big) { big = fabs(A[row][col]); } }
+#pragma unroll
+  for (int row = 0; row < D; row++) {
+    double big = 0.0;
+#pragma unroll
+    for (int col = 0; col < D; col++) { if (fabs(A[row][col]) > big) { big = fabs(A[row][col]); } }
     if (fabs(big) <= (double)FLT_EPSILON) { return -1; }
     scale[row] = 1.0 / big;
   }
-  for (col = 0; col < dim; col++) {
-    for (row = 0; row < col; row++) {
-      sum = A[row][col];
-      for (k = 0; k < row; k++) { sum -= A[row][k] * A[k][col]; }
+  int bad = 0;
+#pragma unroll
+  for (int col = 0; col < D; col++) {
+#pragma unroll
+    for (int row = 0; row < col; row++) {
+      double sum = A[row][col];
+#pragma unroll
+      for (int k = 0; k < row; k++) { sum -= A[row][k] * A[k][col]; }
       A[row][col] = sum;
     }
-    big = 0.0;
-    imax = row;
-    for (row = col; row < dim; row++) {
-      sum = A[row][col];
-      for (k = 0; k < col; k++) { sum -= A[row][k] * A[k][col]; }
+    double big = 0.0;
+    uint32_t imax = (uint32_t)col;
+#pragma unroll
+    for (int row = col; row < D; row++) {
+      double sum = A[row][col];
+#pragma unroll
+      for (int k = 0; k < col; k++) { sum -= A[row][k] * A[k][col]; }
       A[row][col] = sum;
-      if ((scale[row] * fabs(sum)) >= big) { big = scale[row] * fabs(sum); imax = row; }
+      const double t = scale[row] * fabs(sum);
+      if (t >= big) { big = t; imax = (uint32_t)row; }
     }
-    if (col != imax) {
-      for (k = 0; k < dim; k++) { const double t = A[imax][k]; A[imax][k] = A[col][k]; A[col][k] = t; }
-      scale[imax] = scale[col];
+#pragma unroll
+    for (int r = col + 1; r < D; r++) {
+      if (imax == (uint32_t)r) {
+#pragma unroll
+        for (int k = 0; k < D; k++) { const double t = A[r][k]; A[r][k] = A[col][k]; A[col][k] = t; }
+        scale[r] = scale[col];
+      }
     }
     perm[col] = imax;
-    if (fabs(A[col][col]) <= (double)FLT_EPSILON) { return -1; }
-    if (col != dim - 1) {
+    if (fabs(A[col][col]) <= (double)FLT_EPSILON) { bad = 1; }
+    if (!bad && col != D - 1) {
       const double inv = 1.0 / A[col][col];
-      for (row = col + 1; row < dim; row++) { A[row][col] *= inv; }
+#pragma unroll
+      for (int row = col + 1; row < D; row++) { A[row][col] *= inv; }
     }
   }
-  return 0;
+  return bad ? -1 : 0;
 }
 
-__device__ void ltm_lu_substitute(double (*A)[LTM_NT], double* b, uint32_t dim, const uint32_t* perm)
+template <int D>
+__device__ __forceinline__ void ltm_lu_substitute_s(const double (&A)[D][D], double (&b)[D], const uint32_t (&perm)[D])
 {
-  uint32_t row, col, first_nz = 0;
-  double sum;
-  for (row = 0; row < dim; row++) {
+  uint32_t first_nz = 0;
+#pragma unroll
+  for (int row = 0; row < D; row++) {
     const uint32_t pv = perm[row];
-    sum = b[pv];
-    b[pv] = b[row];
+    double sum = b[row];
+#pragma unroll
+    for (int r = 0; r < D; r++) { if (pv == (uint32_t)r) { sum = b[r]; } }
+    const double mine = b[row];
+#pragma unroll
+    for (int r = 0; r < D; r++) { if (pv == (uint32_t)r) { b[r] = mine; } }
     if (first_nz != 0) {
-      for (col = first_nz; col < row; col++) { sum -= A[row][col] * b[col]; }
+#pragma unroll
+      for (int col = 0; col < row; col++) { if ((uint32_t)col >= first_nz) { sum -= A[row][col] * b[col]; } }
     } else if (sum != 0.0) {
-      first_nz = row;
+      first_nz = (uint32_t)row;
     }
     b[row] = sum;
   }
-  for (row = dim; row-- > 0;) {
-    sum = b[row];
-    for (col = row + 1; col < dim; col++) { sum -= A[row][col] * b[col]; }
+#pragma unroll
+  for (int row = D - 1; row >= 0; row--) {
+    double sum = b[row];
+#pragma unroll
+    for (int col = row + 1; col < D; col++) { sum -= A[row][col] * b[col]; }
     b[row] = sum / A[row][row];
   }
 }
 
+template <int D>
 __global__ __launch_bounds__(64)
 void k_ltm_solve(const double* __restrict__ acf, const sla_hip_lpc_group* __restrict__ groups, uint32_t num_jobs,
-                 uint32_t ntaps, sla_hip_tail_job* __restrict__ jobs)
+                 sla_hip_tail_job* __restrict__ jobs)
 {
   const uint32_t j = blockIdx.x * 64 + threadIdx.x;
   if (j >= num_jobs) { return; }
   const double* rec = acf + (uint64_t)j * SLA_HIP_ACF_RECORD;
-  const double* low = rec + 2;
-  const double* mid = rec + 7;
+  double low[5], mid[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) { low[i] = rec[2 + i]; mid[i] = rec[7 + i]; }
   const uint32_t chosen = (uint32_t)rec[1];
   double vec[LTM_NT] = {0.0, 0.0, 0.0, 0.0, 0.0};
   uint32_t pitch = 0;
   int ret = 0;
   if (rec[0] == 0.0) {
     ret = 0;                                               // silent residual: no pitch, zero taps
-  } else if (rec[0] != 1.0 || chosen < ntaps / 2 + 1) {
+  } else if (rec[0] != 1.0 || chosen < (uint32_t)(D / 2 + 1)) {
     ret = 4;
   } else {
-    double R[LTM_NT][LTM_NT], A[LTM_NT][LTM_NT], x[LTM_NT], err[LTM_NT], scale[LTM_NT], b[LTM_NT];
-    uint32_t perm[LTM_NT];
-    for (uint32_t r = 0; r < LTM_NT; r++) { for (uint32_t c = 0; c < LTM_NT; c++) { R[r][c] = 0.0; } }
-    for (uint32_t r = 0; r < ntaps; r++) { for (uint32_t c = 0; c < ntaps; c++) { R[r][c] = low[(r >= c) ? (r - c) : (c - r)]; } }
-    for (uint32_t r = 0; r < LTM_NT; r++) { for (uint32_t c = 0; c < LTM_NT; c++) { A[r][c] = R[r][c]; } }
-    for (uint32_t r = 0; r < ntaps; r++) { b[r] = mid[2 + r - ntaps / 2]; x[r] = b[r]; }
-    if (ltm_lu_factor(A, ntaps, perm, scale) != 0) {
+    double R[D][D], A[D][D], x[D], err[D], scale[D], b[D];
+    uint32_t perm[D];
+#pragma unroll
+    for (int r = 0; r < D; r++) {
+#pragma unroll
+      for (int c = 0; c < D; c++) { R[r][c] = low[(r >= c) ? (r - c) : (c - r)]; A[r][c] = R[r][c]; }
+    }
+#pragma unroll
+    for (int r = 0; r < D; r++) { b[r] = mid[2 + r - D / 2]; x[r] = b[r]; }
+    if (ltm_lu_factor_s<D>(A, perm, scale) != 0) {
       ret = 4;
     } else {
-      ltm_lu_substitute(A, x, ntaps, perm);
-      for (uint32_t it = 0; it < 2; it++) {
-        for (uint32_t r = 0; r < ntaps; r++) {
+      ltm_lu_substitute_s<D>(A, x, perm);
+#pragma unroll 1
+      for (int it = 0; it < 2; it++) {
+#pragma unroll
+        for (int r = 0; r < D; r++) {
           ext80 acc = ext_from_double(-b[r]);
-          for (uint32_t c = 0; c < ntaps; c++) { acc = ext_add(acc, ext_from_double(R[r][c] * x[c])); }
+#pragma unroll
+          for (int c = 0; c < D; c++) { acc = ext_add(acc, ext_from_double(R[r][c] * x[c])); }
           err[r] = ext_to_double(acc);
         }
-        ltm_lu_substitute(A, err, ntaps, perm);
-        for (uint32_t r = 0; r < ntaps; r++) { x[r] -= err[r]; }
+        ltm_lu_substitute_s<D>(A, err, perm);
+#pragma unroll
+        for (int r = 0; r < D; r++) { x[r] -= err[r]; }
       }
       double mag = 0.0;
-      for (uint32_t r = 0; r < ntaps; r++) { mag += fabs(x[r]); }
+#pragma unroll
+      for (int r = 0; r < D; r++) { mag += fabs(x[r]); }
       if (mag >= 1.0) {
-        for (uint32_t r = 0; r < ntaps; r++) { x[r] = 0.0; }
-        x[ntaps / 2] = mid[2] / low[0];
+#pragma unroll
+        for (int r = 0; r < D; r++) { x[r] = 0.0; }
+        x[D / 2] = mid[2] / low[0];
       }
       pitch = chosen;
-      for (uint32_t r = 0; r < ntaps; r++) { vec[r] = x[r]; }
+#pragma unroll
+      for (int r = 0; r < D; r++) { vec[r] = x[r]; }
     }
   }
   if (ret != 0 || pitch >= 256u) { pitch = 0; }            // src/SLAEncoder.c:629-632
   const sla_hip_lpc_group g = groups[j];
   sla_hip_tail_job out;
   out.blk_off = g.pcm_off; out.blk_len = g.num_samples; out.channel = g.channel; out.pitch = pitch;
-  for (uint32_t t = 0; t < LTM_NT; t++) {
+#pragma unroll
+  for (int t = 0; t < LTM_NT; t++) {
     // Round(coef * 2^15) << 16 with the x86 conversion (out of range / NaN -> INT32_MIN)   src/SLAEncoder.c:635-640
-    const double v = ((t < ntaps) ? vec[t] : 0.0) * 32768.0;
+    const double v = ((t < D) ? vec[t] : 0.0) * 32768.0;
     const double rv = (v >= 0.0) ? floor(v + 0.5) : -floor(-v + 0.5);
     const int32_t q = (!(rv > -2147483649.0 && rv < 2147483648.0)) ? INT32_MIN : (int32_t)rv;
     out.ltm_coef[t] = (int32_t)((uint32_t)q << 16);
@@ -2785,8 +2823,10 @@ extern "C" int sla_hip_launch_ltm_solve(const double* d_acf_records, const sla_h
   if (d_acf_records == nullptr || d_groups == nullptr || d_jobs == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (longterm_order == 0 || longterm_order > LTM_NT || (longterm_order & 1u) == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (num_jobs == 0) { return 0; }
-  hipLaunchKernelGGL(k_ltm_solve, dim3((num_jobs + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_acf_records, d_groups, num_jobs,
-                     longterm_order, d_jobs);
+  const dim3 grid((num_jobs + 63) / 64), block(64);
+  if (longterm_order == 1) { hipLaunchKernelGGL(k_ltm_solve<1>, grid, block, 0, (hipStream_t)stream, d_acf_records, d_groups, num_jobs, d_jobs); }
+  else if (longterm_order == 3) { hipLaunchKernelGGL(k_ltm_solve<3>, grid, block, 0, (hipStream_t)stream, d_acf_records, d_groups, num_jobs, d_jobs); }
+  else { hipLaunchKernelGGL(k_ltm_solve<5>, grid, block, 0, (hipStream_t)stream, d_acf_records, d_groups, num_jobs, d_jobs); }
   return hip_rc(hipGetLastError());
 }
 
