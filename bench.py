@@ -426,11 +426,13 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
                 ok &= (int(tr.blk_nsmpl[b]) == int(to.blk_nsmpl[j]) and int(tr.blk_type[b]) == int(to.blk_type[j]))
                 if to.blk_type[j] == 0:
                     s0, s1, ln = int(tr.blk_start[b]), int(to.blk_start[j]), int(to.blk_nsmpl[j])
-                    ok &= bool(np.array_equal(tr.parcor[b].view(np.uint64), to.parcor[j].view(np.uint64))
-                               and np.array_equal(tr.code[b], to.code[j]) and np.array_equal(tr.rice_init[b], to.rice_init[j])
+                    ex = tr.parcor_exact[b].astype(bool)      # exact chain kernel: bit patterns; certified route: the codes decide
+                    ok &= bool(np.array_equal(tr.parcor[b].view(np.uint64)[ex], to.parcor[j].view(np.uint64)[ex])
+                               and np.all(np.abs(tr.parcor[b][~ex] - to.parcor[j][~ex]) <= 1e-9)
+                               and np.array_equal(tr.code[b], to.code[j]) and np.array_equal(tr.kint[b], to.kint[j]) and np.array_equal(tr.rice_init[b], to.rice_init[j])
                                and np.array_equal(tr.res_final[:, s0:s0 + ln], to.res_final[:, s1:s1 + ln]))
                 checked += 1
-        ver.update({"blocks_compared": checked, "fields": "block table, PARCOR bit patterns, codes, Rice parameters, final residual of the first 2 clips"})
+        ver.update({"blocks_compared": checked, "fields": "block table, PARCOR (bit patterns where the exact kernel ran, 1e-9 where certified), codes, Rice parameters, final residual of the first 2 clips"})
     else:
         own_n = own_hi - own_lo
         frames = min(20 if maxb <= 4096 else 8, max(own_n // maxb - 1, 1))
@@ -458,11 +460,11 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
                 pos += int(tr.blk_nsmpl[nblk]); off += int(tr.blk_bytes[nblk]); nblk += 1
             ok &= (nblk > 0 and image[43:off] == want[43:off])
         if to is not None:
-            ok &= bool(np.array_equal(tr.parcor[:nblk].view(np.uint64), to.parcor[:nblk].view(np.uint64))
-                       and np.array_equal(tr.code[:nblk], to.code[:nblk]) and np.array_equal(tr.rice_init[:nblk], to.rice_init[:nblk])
+            ok &= bool(S.parcor_same(tr, to, nblk)
+                       and np.array_equal(tr.code[:nblk], to.code[:nblk]) and np.array_equal(tr.kint[:nblk], to.kint[:nblk]) and np.array_equal(tr.rice_init[:nblk], to.rice_init[:nblk])
                        and np.array_equal(tr.blk_nsmpl[:nblk], to.blk_nsmpl[:nblk]))
         ver.update({"blocks_compared": int(nblk), "fields": "bytes of the first blocks (headers, Rice bodies, CRC16)"
-                    + (", PARCOR bit patterns, codes, Rice parameters" if to is not None else "")})
+                    + (", PARCOR (bit patterns where the exact kernel ran, 1e-9 where certified), codes, Rice parameters" if to is not None else "")})
         # ... and the whole image decodes back to the PCM this rank analysed (size-independent property at full size)
         if lms in (4, 8, 16, 32) and maxb <= 16384:
             dec = sla_amd.Decoder(nch, maxb, order, ltm, lms)

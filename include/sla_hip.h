@@ -167,6 +167,21 @@ int sla_hip_launch_lpc_blocks(const int32_t* d_pcm, uint64_t plane_stride, uint3
                               double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
                               int32_t* d_lattice_residual, sla_hip_stream_t stream);
 
+/* Chosen blocks, certified route (the default of the block stage; option "block_cert"): the autocorrelation of every
+ * windowed block in ANY summation order (k_acf_blocks: FMAs, one wave per block and channel), the reference's
+ * Levinson-Durbin recursion on it and a per-block certificate that the quantised PARCOR codes (reference
+ * src/SLAEncoder.c:567-589) and the RAW decision (:553-565) cannot differ from the reference's although the doubles may
+ * differ in their last bits; blocks that do not certify are appended to d_fallback_list (group indices, count in
+ * *d_fallback_count) and redone by the exact chain kernels of sla_hip_launch_lpc before the call's work on `stream`
+ * ends.  d_cert_flag[slot]: 0 = certified, 2 = exact.  safety >= 1 scales the certificate's bound (the encoder: 16).
+ * Orders above 52 are not covered (SLA_APIRESULT_EXCEED_HANDLE_CAPACITY): use sla_hip_launch_lpc. */
+int sla_hip_launch_lpc_blocks_cert(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                                   const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                                   const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
+                                   double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
+                                   uint32_t* d_cert_flag, uint32_t* d_fallback_list, uint32_t* d_fallback_count,
+                                   double safety, uint32_t bits_per_sample, sla_hip_stream_t stream);
+
 /* sla_hip_launch_lpc restricted to the groups that sla_hip_launch_search_exact flagged (NaN in r[0] of the group's
  * first slot): everything else returns at once and keeps its result.  *d_rerun_counter (may be NULL) is
  * incremented by the number of groups that were analysed. */
@@ -371,6 +386,9 @@ typedef struct sla_hip_trace {
   double*   parcor; int32_t* code; int32_t* kint;
   uint32_t* rshift; uint32_t* pitch; int32_t* ltm_coef; uint32_t* rice_init;
   int32_t*  res_lattice; int32_t* res_final;    /* may be NULL: not copied back */
+  uint32_t* parcor_exact;    /* may be NULL; per (block, channel): 1 = parcor[] are the reference's doubles bit for bit (exact
+                                chain kernel), 0 = certified: code[], kint[] and the RAW decision are the reference's, the
+                                doubles agree to the certificate's bound (option "block_cert") */
 } sla_hip_trace;
 
 /* Hot path on PCM resident in device memory: planar int32 [C][plane_stride],
@@ -500,6 +518,10 @@ int sla_hip_last_timing(const struct SLAEncoder* encoder, float* timing_ms);
  * had to decide (device plan not certified); 1 if the search ran on tile sums; 1 if the device plan is enabled;
  * k_tail launches (1: one for the file, else one per pipeline chunk); 1 if pitch + taps were solved on the device. */
 int sla_hip_last_counters(const struct SLAEncoder* encoder, uint32_t* counters);
+
+/* 2 counters of the last analysis: 1 if the block stage took the certified route (sla_hip_launch_lpc_blocks_cert);
+ * (block, channel) pairs its certificate handed to the exact chain kernels. */
+int sla_hip_last_block_cert(const struct SLAEncoder* encoder, uint32_t* counters);
 
 /* 4 floats [ms]: execution time of k_lpc_blocks, k_lattice, k_ltm_acf, k_tail in the last analysis, summed over
  * its launches and measured ON the device (first wave in to last wave out, constant 100 MHz clock) -- what

@@ -77,7 +77,7 @@ class HipTrace(C.Structure):
         ("blk_start", u32p), ("blk_nsmpl", u32p), ("blk_type", u32p), ("blk_bytes", u32p),
         ("parcor", f64p), ("code", i32p), ("kint", i32p),
         ("rshift", u32p), ("pitch", u32p), ("ltm_coef", i32p), ("rice_init", u32p),
-        ("res_lattice", i32p), ("res_final", i32p)]
+        ("res_lattice", i32p), ("res_final", i32p), ("parcor_exact", u32p)]
 
 
 class BatchItem(C.Structure):
@@ -132,6 +132,7 @@ def lib():
         L.sla_hip_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.sla_hip_last_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.sla_hip_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.sla_hip_last_block_cert.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.sla_hip_search_exact_lags.restype = C.c_uint32
         L.sla_hip_encoder_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         L.sla_hip_shard_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, u32p, C.POINTER(C.c_uint64)]
@@ -178,7 +179,7 @@ EXPORTED_SYMBOLS = [
     "sla_hip_launch_ltm_acf", "sla_hip_launch_rice_len", "sla_hip_launch_rice_write", "sla_hip_pack_device", "sla_hip_launch_unpack16",
     "sla_hip_analyze_device", "sla_hip_pack", "sla_hip_final_residual", "sla_hip_lattice_residual",
     "sla_hip_get_trace", "sla_hip_device_name", "sla_hip_last_timing", "sla_hip_launch_search_exact",
-    "sla_hip_search_exact_lags", "sla_hip_launch_plan", "sla_hip_last_counters", "sla_hip_launch_lpc_rerun", "sla_hip_last_kernel_ms", "sla_hip_launch_lpc_blocks",
+    "sla_hip_search_exact_lags", "sla_hip_launch_plan", "sla_hip_last_counters", "sla_hip_launch_lpc_rerun", "sla_hip_last_kernel_ms", "sla_hip_launch_lpc_blocks", "sla_hip_launch_lpc_blocks_cert", "sla_hip_last_block_cert",
     "sla_hip_launch_lpc_f64", "sla_hip_launch_lattice_raw", "sla_hip_launch_tail_stages", "sla_hip_launch_emphasis_i32",
     "sla_hip_launch_emphasis_f64", "sla_hip_use_tuning", "sla_hip_launch_lattice_groups", "sla_hip_launch_ltm_solve",
     "sla_hip_encoder_set_option", "sla_hip_shard_scan", "sla_hip_shard_scan_counts", "sla_hip_shard_bounds", "sla_hip_shard_analyze", "sla_hip_shard_analyze_no_silence", "sla_hip_shard_header",
@@ -226,6 +227,8 @@ class Trace:
         self.pitch = z((max_blocks, Cn), np.uint32)
         self.ltm_coef = z((max_blocks, Cn, L), np.int32)
         self.rice_init = z((max_blocks, Cn), np.uint32)
+        # 1 = parcor[] are the reference's doubles bit for bit, 0 = certified route (codes / decisions are the reference's)
+        self.parcor_exact = z((max_blocks, Cn), np.uint32)
         ns = max(num_samples, 1)
         self.res_lattice = z((Cn, ns), np.int32) if want_residuals else None
         self.res_final = z((Cn, ns), np.int32) if want_residuals else None
@@ -236,7 +239,8 @@ class Trace:
             p(self.parcor, f64p), p(self.code, i32p), p(self.kint, i32p), p(self.rshift, u32p),
             p(self.pitch, u32p), p(self.ltm_coef, i32p), p(self.rice_init, u32p),
             p(self.res_lattice, i32p) if want_residuals else None,
-            p(self.res_final, i32p) if want_residuals else None)
+            p(self.res_final, i32p) if want_residuals else None,
+            p(self.parcor_exact, u32p))
 
     @property
     def num_blocks(self):
@@ -413,6 +417,12 @@ class Encoder:
         k_tail launches, long-term solve on the device)"""
         c = (C.c_uint32 * 6)()
         self._check(self._lib.sla_hip_last_counters(self._h, c), "sla_hip_last_counters")
+        return tuple(c)
+
+    def last_block_cert(self):
+        """(1 if the block stage took the certified route, (block, channel) pairs redone by the exact kernels)"""
+        c = (C.c_uint32 * 2)()
+        self._check(self._lib.sla_hip_last_block_cert(self._h, c), "sla_hip_last_block_cert")
         return tuple(c)
 
     def bind_residual_planes(self, lattice_ptr, final_ptr, plane_stride):

@@ -73,6 +73,12 @@ struct SLAEncoder {
   int      alt_now;                 /* this run's decision */
   int      device_ltm;              /* 1: pitch + taps solved on the device, the block stage runs lattice -> tail without the host (default) */
   int      trace;                   /* host-side timeline on stderr (SLA_HIP_TRACE) */
+  int      block_cert;              /* 1 (default): chosen blocks through the any-order autocorrelation where their codes and the RAW decision certify,
+                                     * the exact chain kernel for the rest; 0: every block through the exact kernel */
+  double   block_cert_safety;       /* safety factor on the first-order bound of that certificate (16) */
+  volatile int cert_broken;         /* a block flagged by the certificate was not redone (internal error) */
+  int      cert_now;                /* this run's block stage takes the certified route */
+  uint32_t blocks_exact;            /* last analysis: (block, channel) pairs the certificate handed to the exact kernel */
   sla_hip_tuning tune;              /* launcher knobs, named to the launchers at every API entry */
   uint32_t host_planned;            /* last analysis: super-frames whose partition the host had to decide */
   uint32_t fallback_groups;         /* last analysis: search groups that had to take the chain kernel */
@@ -84,11 +90,11 @@ struct SLAEncoder {
   /* device workspace */
   devbuf_t d_pcm, d_res1, d_res2, d_or, d_nz, d_groups, d_cands, d_lpc_out, d_code, d_kint, d_rshift,
            d_winpool, d_chunks, d_jobs, d_fold, d_acf_jobs, d_acf, d_acf_scratch, d_twiddle, d_bgroups, d_bcands, d_blk_out, d_kk, d_pk_jobs, d_pk_blocks, d_pk_hdr, d_image,
-           d_xgroups, d_tile_sums, d_fgroups, d_parts, d_nparts, d_pstatus, d_spans;
+           d_xgroups, d_tile_sums, d_fgroups, d_parts, d_nparts, d_pstatus, d_spans, d_cert_flag, d_fb_list, d_fb_count;
   int twiddle_ready;
   /* pinned host staging */
   pinbuf_t h_nz, h_groups, h_cands, h_lpc_out, h_code, h_kint, h_rshift, h_chunks, h_jobs, h_fold, h_res, h_pcm, h_acf_jobs, h_acf,
-           h_bgroups, h_bcands, h_blk_out, h_pk_jobs, h_pk_blocks, h_pk_hdr, h_xgroups, h_fgroups, h_parts, h_nparts, h_pstatus;
+           h_bgroups, h_bcands, h_blk_out, h_pk_jobs, h_pk_blocks, h_pk_hdr, h_xgroups, h_fgroups, h_parts, h_nparts, h_pstatus, h_cert_flag;
   uint32_t* h_or;
   size_t nz_ones_cap; uint64_t nz_ones_words;    /* h_nz words [0, nz_ones_words) are known to be all ones (h_nz.cap == nz_ones_cap) */
   pinbuf_t h_stage[2]; devbuf_t d_stage[2]; hipEvent_t ev_stage[2];
@@ -133,6 +139,7 @@ struct SLAEncoder {
   blk_t*   blk; uint32_t num_blocks, blk_cap;
   blkch_t* bc;  size_t bc_cap;
   double*  parcor; int32_t* code; int32_t* kint;   /* [num_blocks*C*(order+1)] */
+  uint8_t* parcor_exact;            /* [num_blocks*C]: 1 = parcor[] are the reference's doubles bit for bit, 0 = certified (codes and decisions are the reference's) */
   size_t   coef_cap;
   int      analysed;
   float    timing[12];
@@ -356,6 +363,9 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
     if (e->split_count > 0) { e->chunks = e->split_count; }
   }
   e->search_exact = 1; e->exact_bits = 53; e->device_plan = 1; e->cert_safety = 64.0;
+  e->block_cert = 1; e->block_cert_safety = 16.0;
+  env = getenv("SLA_HIP_BLOCK_CERT");
+  if (env != NULL && atof(env) >= 0.0) { e->block_cert = (atof(env) != 0.0); if (atof(env) >= 16.0) { e->block_cert_safety = atof(env); } }
   e->stream_mode = 1; e->stream_piece = 32u << 20; e->stream_lanes = 4;
   env = getenv("SLA_HIP_STREAM");
   if (env != NULL) { e->stream_mode = (atoi(env) != 0); }
@@ -371,7 +381,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   env = getenv("SLA_HIP_SEARCH");
   if (env != NULL && strcmp(env, "chain") == 0) { e->search_exact = 0; }
   env = getenv("SLA_HIP_CERT");
-  if (env != NULL && atof(env) >= 0.0) { e->cert_safety = atof(env); }
+  if (env != NULL && (atof(env) == 0.0 || atof(env) >= 64.0)) { e->cert_safety = atof(env); }
   env = getenv("SLA_HIP_EXACT_BITS");
   if (env != NULL && atoi(env) > 0 && atoi(env) <= 53) { e->exact_bits = atoi(env); }
   env = getenv("SLA_HIP_PLAN_COPY");
@@ -385,7 +395,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   env = getenv("SLA_HIP_TAIL_WAVES");
   if (env != NULL && atoi(env) >= 1 && atoi(env) <= 4) { e->tune.tail_waves = (uint32_t)atoi(env); }
   env = getenv("SLA_HIP_PLAN_MARGIN");
-  if (env != NULL && atof(env) > 0.0) { e->tune.plan_margin = atof(env); }
+  if (env != NULL && atof(env) >= 1e-4) { e->tune.plan_margin = atof(env); }
   if (hipHostMalloc((void**)&e->h_or, 4096, hipHostMallocDefault) != hipSuccess) { e->h_or = NULL; goto fail; }   /* [0,1] prepass words, [2] rerun counter, +64 B: kernel spans */
   {
     uint32_t fft = 1;
@@ -419,8 +429,8 @@ fail:
 
 void SLAEncoder_Destroy(struct SLAEncoder* e)
 {
-  devbuf_t* d[34];
-  pinbuf_t* h[25];
+  devbuf_t* d[37];
+  pinbuf_t* h[26];
   int i;
   if (e == NULL) { return; }
   for (i = 0; i < 4; i++) { SLAEncoder_Destroy(e->lane[i]); e->lane[i] = NULL; }
@@ -438,13 +448,14 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   d[22] = &e->d_kk; d[23] = &e->d_pk_jobs; d[24] = &e->d_pk_blocks; d[25] = &e->d_pk_hdr; d[26] = &e->d_image;
   d[27] = &e->d_xgroups; d[28] = &e->d_tile_sums; d[29] = &e->d_fgroups;
   d[30] = &e->d_parts; d[31] = &e->d_nparts; d[32] = &e->d_pstatus; d[33] = &e->d_spans;
-  for (i = 0; i < 34; i++) { if (d[i]->ptr != NULL) { (void)hipFree(d[i]->ptr); } }
+  d[34] = &e->d_cert_flag; d[35] = &e->d_fb_list; d[36] = &e->d_fb_count;
+  for (i = 0; i < 37; i++) { if (d[i]->ptr != NULL) { (void)hipFree(d[i]->ptr); } }
   h[0] = &e->h_nz; h[1] = &e->h_groups; h[2] = &e->h_cands; h[3] = &e->h_lpc_out; h[4] = &e->h_code; h[5] = &e->h_kint;
   h[6] = &e->h_rshift; h[7] = &e->h_chunks; h[8] = &e->h_jobs; h[9] = &e->h_fold; h[10] = &e->h_res; h[11] = &e->h_pcm;
   h[12] = &e->h_acf_jobs; h[13] = &e->h_acf; h[14] = &e->h_bgroups; h[15] = &e->h_bcands; h[16] = &e->h_blk_out;
   h[17] = &e->h_pk_jobs; h[18] = &e->h_pk_blocks; h[19] = &e->h_pk_hdr; h[20] = &e->h_xgroups; h[21] = &e->h_fgroups;
-  h[22] = &e->h_parts; h[23] = &e->h_nparts; h[24] = &e->h_pstatus;
-  for (i = 0; i < 25; i++) { if (h[i]->ptr != NULL) { (void)hipHostFree(h[i]->ptr); } }
+  h[22] = &e->h_parts; h[23] = &e->h_nparts; h[24] = &e->h_pstatus; h[25] = &e->h_cert_flag;
+  for (i = 0; i < 26; i++) { if (h[i]->ptr != NULL) { (void)hipHostFree(h[i]->ptr); } }
   if (e->h_or != NULL) { (void)hipHostFree(e->h_or); }
   if (e->d_tile_or.ptr != NULL) { (void)hipFree(e->d_tile_or.ptr); }
   if (e->h_tile_or.ptr != NULL) { (void)hipHostFree(e->h_tile_or.ptr); }
@@ -466,7 +477,7 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   if (e->fft != NULL) { slai_fft_plan_destroy(e->fft); }
   pool_destroy(e->pool);
   free(e->win_host); free(e->win_len); free(e->win_off);
-  free(e->blk); free(e->bc); free(e->parcor); free(e->code); free(e->kint);
+  free(e->blk); free(e->bc); free(e->parcor); free(e->code); free(e->kint); free(e->parcor_exact);
   free(e);
 }
 
@@ -1006,6 +1017,10 @@ static int pipeline_reserve(struct SLAEncoder* e, const actx_t* a)
   RCCHK(dev_reserve(&e->d_code, sizeof(int32_t) * nslots * O1));
   RCCHK(dev_reserve(&e->d_kint, sizeof(int32_t) * nslots * O1));
   RCCHK(dev_reserve(&e->d_rshift, sizeof(uint32_t) * nslots));
+  RCCHK(dev_reserve(&e->d_cert_flag, sizeof(uint32_t) * nslots));
+  RCCHK(dev_reserve(&e->d_fb_list, sizeof(uint32_t) * nslots));
+  RCCHK(dev_reserve(&e->d_fb_count, sizeof(uint32_t) * MAX_CHUNKS));
+  RCCHK(pin_reserve(&e->h_cert_flag, sizeof(uint32_t) * (nslots + MAX_CHUNKS)));
   RCCHK(dev_reserve(&e->d_acf, sizeof(double) * nslots * SLAI_LTM_ACF_HEAD));
   RCCHK(dev_reserve(&e->d_fold, sizeof(uint64_t) * nslots));
   if (sizeof(double) * (size_t)fft_size > SLA_HIP_LDS_BUDGET) {
@@ -1026,8 +1041,9 @@ static int pipeline_reserve(struct SLAEncoder* e, const actx_t* a)
     e->parcor = (double*)realloc(e->parcor, sizeof(double) * e->coef_cap);
     e->code = (int32_t*)realloc(e->code, sizeof(int32_t) * e->coef_cap);
     e->kint = (int32_t*)realloc(e->kint, sizeof(int32_t) * e->coef_cap);
+    e->parcor_exact = (uint8_t*)realloc(e->parcor_exact, e->coef_cap);
   }
-  if (e->bc == NULL || e->parcor == NULL || e->code == NULL || e->kint == NULL) { return SLA_APIRESULT_NG; }
+  if (e->bc == NULL || e->parcor == NULL || e->code == NULL || e->kint == NULL || e->parcor_exact == NULL) { return SLA_APIRESULT_NG; }
   memset(e->bc, 0, sizeof(blkch_t) * nslots);
   /* tables that never change while kernels are in flight */
   if (e->win_dirty) {
@@ -1233,6 +1249,8 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
   hipEvent_t* ev = a->ev + (size_t)c * EV_PER_CHUNK;
   uint32_t b, ch, max_window = 1, ng, nl;
   const int fused = (e->fuse_lattice && order <= 64);
+  const int use_cert = e->cert_now;
+  const size_t cnt_base = (size_t)a->blocks_bound * C + 1;      /* h_cert_flag: per-slot flags, then one fallback count per chunk */
   /* option alt_streams: odd chunks run their block stage on the third stream, beside the even chunks' (not when the FFT
    * works in the shared global scratch) */
   hipStream_t bs = (e->alt_now && e->device_ltm && e->single_tail && (c & 1u)
@@ -1283,6 +1301,14 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
                                       (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
                                       (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
                                       (uint32_t*)e->d_rshift.ptr, RES1(e), bs));
+    } else if (use_cert) {
+      /* any-order autocorrelation + certified quantiser; what does not certify goes through the exact kernels behind it */
+      RCCHK(sla_hip_launch_lpc_blocks_cert(e->pcm_dev, e->stride, ms, order, dg, ng, max_window,
+                                           (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
+                                           (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
+                                           (uint32_t*)e->d_rshift.ptr, (uint32_t*)e->d_cert_flag.ptr,
+                                           (uint32_t*)e->d_fb_list.ptr + k->bg_lo, (uint32_t*)e->d_fb_count.ptr + c,
+                                           e->block_cert_safety, bps, bs));
     } else {
       RCCHK(sla_hip_launch_lpc(e->pcm_dev, e->stride, ms, order, dg, ng, max_window, 1,
                                (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
@@ -1296,6 +1322,10 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     HIPCHK(hipMemcpyAsync((int32_t*)e->h_code.ptr + slot_lo * O1, (int32_t*)e->d_code.ptr + slot_lo * O1, sizeof(int32_t) * nsl * O1, hipMemcpyDeviceToHost, e->stream_down));
     HIPCHK(hipMemcpyAsync((int32_t*)e->h_kint.ptr + slot_lo * O1, (int32_t*)e->d_kint.ptr + slot_lo * O1, sizeof(int32_t) * nsl * O1, hipMemcpyDeviceToHost, e->stream_down));
     HIPCHK(hipMemcpyAsync((uint32_t*)e->h_rshift.ptr + slot_lo, (uint32_t*)e->d_rshift.ptr + slot_lo, sizeof(uint32_t) * nsl, hipMemcpyDeviceToHost, e->stream_down));
+    if (use_cert) {
+      HIPCHK(hipMemcpyAsync((uint32_t*)e->h_cert_flag.ptr + slot_lo, (uint32_t*)e->d_cert_flag.ptr + slot_lo, sizeof(uint32_t) * nsl, hipMemcpyDeviceToHost, e->stream_down));
+      HIPCHK(hipMemcpyAsync((uint32_t*)e->h_cert_flag.ptr + cnt_base + c, (uint32_t*)e->d_fb_count.ptr + c, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream_down));
+    }
     HIPCHK(hipEventRecord(ev[EV_LPC_DOWN], e->stream_down));
     /* pass 2 (k_lpc_blocks is running): lattice chunks and FFT jobs */
     {
@@ -1373,6 +1403,9 @@ static void raw_one(void* vctx, uint32_t rel)
     memcpy(e->code + slot * O1, (const int32_t*)e->h_code.ptr + slot * O1, sizeof(int32_t) * O1);
     memcpy(e->kint + slot * O1, (const int32_t*)e->h_kint.ptr + slot * O1, sizeof(int32_t) * O1);
     e->bc[slot].rshift = ((const uint32_t*)e->h_rshift.ptr)[slot];
+    /* certified route: 0 = certified doubles, 2 = redone by the exact kernels (1 would be a block the fallback missed) */
+    e->parcor_exact[slot] = (uint8_t)(e->cert_now ? (((const uint32_t*)e->h_cert_flag.ptr)[slot] == 2u) : 1u);
+    if (e->cert_now && ((const uint32_t*)e->h_cert_flag.ptr)[slot] == 1u) { e->cert_broken = 1; }
     est = slai_code_length(o[0], blk->nsmpl, bps, o + 1, order);
     est = (8 * est) / bps;
     if (est >= SLAI_RAW_THRESHOLD) { blk->type = SLAI_BLK_RAW; break; }
@@ -1499,7 +1532,9 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   memset(&a, 0, sizeof(a));
   a.ev = e->ev + 2;
 
-  e->fallback_groups = 0; e->host_planned = 0;
+  e->fallback_groups = 0; e->host_planned = 0; e->blocks_exact = 0; e->cert_broken = 0;
+  e->cert_now = (e->block_cert && !(e->fuse_lattice && e->encode_param.parcor_order <= 64) && !e->tune.lpc_blocks_chains
+                 && sla_hip_search_exact_lags(e->encode_param.parcor_order) != 0);
   if (!preset_blocks) {
     e->num_blocks = 0;
     if ((rc = pipeline_prepare(e, &a)) != 0) { actx_free(&a); return rc; }
@@ -1663,6 +1698,11 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
       || hipStreamSynchronize(e->stream_up) != hipSuccess || hipStreamSynchronize(e->stream_down) != hipSuccess
       || hipStreamSynchronize(e->stream3) != hipSuccess) { if (rc == 0) { rc = SLA_APIRESULT_NG; } }
   if (rc == 0 && !preset_blocks) { e->fallback_groups = e->h_or[2]; }
+  if (rc == 0 && e->cert_now) {
+    const uint32_t* cnt = (const uint32_t*)e->h_cert_flag.ptr + (size_t)a.blocks_bound * C + 1;
+    for (c = 0; c < a.nchunks; c++) { if (a.ck[c].bg_hi > a.ck[c].bg_lo) { e->blocks_exact += cnt[c]; } }
+    if (e->cert_broken) { rc = SLA_APIRESULT_NG; }
+  }
   memset(e->kernel_ms, 0, sizeof(e->kernel_ms));
   if (rc == 0) {
     const unsigned long long* sp = sp_host;
@@ -1727,11 +1767,14 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   else if (strcmp(name, "lpc_tile") == 0)          { if (iv != 0 && iv != 24 && iv != 48) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.lpc_tile = (uint32_t)iv; }
   else if (strcmp(name, "tail_lanes") == 0)        { OPT_RANGE(0, 2); e->tune.tail_lanes = (uint32_t)iv; }
   else if (strcmp(name, "lpc_blocks_chains") == 0) { OPT_RANGE(0, 1); e->tune.lpc_blocks_chains = (uint32_t)iv; if (iv) { e->fuse_lattice = 0; } }
-  else if (strcmp(name, "plan_margin") == 0)       { if (value < 0.0) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.plan_margin = value; }
+  /* the certification margins may only be widened: below the built-in values byte-identity is no longer guaranteed */
+  else if (strcmp(name, "plan_margin") == 0)       { if (value != 0.0 && !(value >= 1e-4)) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.plan_margin = value; }
   else if (strcmp(name, "chunks") == 0)            { OPT_RANGE(1, 8); e->chunks = (uint32_t)iv; e->split_count = 0; e->chunks_forced = 1; }
   else if (strcmp(name, "search_exact") == 0)      { OPT_RANGE(0, 1); e->search_exact = (int)iv; }
   else if (strcmp(name, "exact_bits") == 0)        { OPT_RANGE(1, 53); e->exact_bits = (int)iv; }
-  else if (strcmp(name, "cert_safety") == 0)       { if (value < 0.0 || value > 1e30) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->cert_safety = value; }
+  else if (strcmp(name, "cert_safety") == 0)       { if ((value != 0.0 && value < 64.0) || value > 1e30) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->cert_safety = value; }
+  else if (strcmp(name, "block_cert") == 0)        { OPT_RANGE(0, 1); e->block_cert = (int)iv; }
+  else if (strcmp(name, "block_cert_safety") == 0) { if (!(value >= 16.0) || value > 1e30) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->block_cert_safety = value; }
   else if (strcmp(name, "device_plan") == 0)       { OPT_RANGE(0, 1); e->device_plan = (int)iv; }
   else if (strcmp(name, "single_tail") == 0)       { OPT_RANGE(0, 1); e->single_tail = (int)iv; }
   else if (strcmp(name, "stream") == 0)            { OPT_RANGE(0, 1); e->stream_mode = (int)iv; }
@@ -1937,6 +1980,13 @@ int sla_hip_last_counters(const struct SLAEncoder* e, uint32_t* counters)
   counters[0] = e->fallback_groups; counters[1] = e->host_planned;
   counters[2] = (uint32_t)e->timing[11]; counters[3] = (uint32_t)e->device_plan;
   counters[4] = e->tail_launches; counters[5] = (uint32_t)e->device_ltm;
+  return 0;
+}
+
+int sla_hip_last_block_cert(const struct SLAEncoder* e, uint32_t* counters)
+{
+  if (e == NULL || counters == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  counters[0] = (uint32_t)e->cert_now; counters[1] = e->blocks_exact;
   return 0;
 }
 
@@ -3154,6 +3204,7 @@ int sla_hip_get_trace(struct SLAEncoder* e, sla_hip_trace* tr)
         tr->kint[slot * tr->order_stride + t] = e->kint[slot * O1 + t];
       }
       tr->rshift[slot] = bc->rshift; tr->pitch[slot] = bc->pitch; tr->rice_init[slot] = bc->rice_init;
+      if (tr->parcor_exact != NULL) { tr->parcor_exact[slot] = e->parcor_exact[slot]; }
       for (t = 0; t < e->encode_param.longterm_order; t++) { tr->ltm_coef[slot * tr->ltm_stride + t] = bc->ltm_q[t]; }
     }
   }

@@ -664,27 +664,25 @@ __device__ __forceinline__ uint32_t stage_window(const int32_t* __restrict__ pcm
 #define LB_ROW (LB_K + 2)     // terms of one chain and tile, padded: 16-byte aligned rows that spread over the banks
 
 template <int S, int LBK>     // producer lanes per chain: 6 or 12; steps per tile: 24 or 48 (longer tiles pay for wide packs: fewer barriers, more operand reuse)
-__global__ __launch_bounds__(LB_THREADS)
-void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
+__device__ __forceinline__
+void lpc_blocks_body(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
                   const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, uint32_t pack,
                   const double* __restrict__ window_pool, double* __restrict__ out,
                   int32_t* __restrict__ out_code, int32_t* __restrict__ out_kint, uint32_t* __restrict__ out_rshift,
-                  uint32_t x_region, uint32_t nch, uint32_t clk, unsigned long long* exec_span,
-                  int32_t* __restrict__ lat_residual, uint32_t defer_levinson)
+                  uint32_t x_region, uint32_t nch, uint32_t clk,
+                  int32_t* __restrict__ lat_residual, uint32_t defer_levinson, uint32_t g0, const uint32_t* __restrict__ list)
 {
   constexpr uint32_t Q = LBK / S;              // consecutive terms a producer lane makes per tile
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  span_begin(exec_span);
   const unsigned long long t_start = clk ? clock64() : 0;
   __shared__ sla_hip_lpc_group s_g[LPC_MAX_PACK];
   __shared__ uint32_t s_maxabs[LPC_MAX_PACK];
   __shared__ uint32_t s_tiles;
   const uint32_t O1 = order + 1, O2 = order + 2;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const uint32_t g0 = blockIdx.x * pack;
   const uint32_t ng = (num_groups - g0 < pack) ? (num_groups - g0) : pack;
   if (tid < LPC_MAX_PACK) {
-    if (tid < ng) { s_g[tid] = groups[g0 + tid]; }
+    if (tid < ng) { s_g[tid] = groups[(list != nullptr) ? list[g0 + tid] : (g0 + tid)]; }
     s_maxabs[tid] = 0;
   }
   if (tid == 0) { s_tiles = 0; }
@@ -830,7 +828,6 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
         out_rshift[g.slot_first] = (bitwidth > 16) ? (bitwidth - 16) : 0;
       }
     }
-    span_end(exec_span);
     return;
   }
   // ---- Levinson-Durbin, one wave per window, lane j = coefficient j   src/SLAPredictor.c:253-328 ------
@@ -899,7 +896,6 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
       first_chunk += nchunks;
     }
   }
-  span_end(exec_span);
   if (clk && lane == 0) {
     const unsigned long long t_end = clock64();
     if (wv == 0) {
@@ -911,6 +907,28 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
   }
 }
 
+// list mode (list != NULL): the groups are list[0 .. *list_count) -- the blocks k_blocks_finish<.., true> could not
+// certify -- and a fixed grid walks them (the count is only known on the device).
+template <int S, int LBK>
+__global__ __launch_bounds__(LB_THREADS)
+void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
+                  const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, uint32_t pack,
+                  const double* __restrict__ window_pool, double* __restrict__ out,
+                  int32_t* __restrict__ out_code, int32_t* __restrict__ out_kint, uint32_t* __restrict__ out_rshift,
+                  uint32_t x_region, uint32_t nch, uint32_t clk, unsigned long long* exec_span,
+                  int32_t* __restrict__ lat_residual, uint32_t defer_levinson,
+                  const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count)
+{
+  span_begin(exec_span);
+  const uint32_t total = (list != nullptr) ? *list_count : num_groups;
+  for (uint32_t g0 = blockIdx.x * pack; g0 < total; g0 += gridDim.x * pack) {
+    lpc_blocks_body<S, LBK>(pcm, stride, ms, order, groups, total, pack, window_pool, out, out_code, out_kint, out_rshift,
+                            x_region, nch, clk, lat_residual, defer_levinson, g0, list);
+    __syncthreads();
+  }
+  span_end(exec_span);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_blocks_finish: Levinson-Durbin (src/SLAPredictor.c:253-328) and the coefficient quantiser (src/SLAEncoder.c:567-589)
 // of the chosen blocks, one LANE per (block, channel).  Inside k_lpc_blocks the recursion ran lane-parallel on one wave
@@ -920,15 +938,39 @@ void k_lpc_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
 // cross-lane traffic at all, and 64 windows share a wave; the loops are unrolled over the stage and the coefficient
 // index so that every register index is static (the reversed vector v[i] = a[d+1-i] is just another register).
 // In: slot = { -, r[0..order] } as k_lpc_blocks left it, rshift.  Out: slot = { r0, parcor[0..order] }, code, kint.
+//
+// CERT = true: r[] came from k_acf_blocks (any summation order), so the doubles are NOT the reference's bit for bit --
+// but what reaches the bit stream are the quantised codes (16 bits for the first three coefficients, 8 bits for the
+// rest, src/SLAEncoder.c:573-589) and the RAW decision (src/SLAEncoder.c:553-565).  Both are certified per block:
+//   * |r_ref[j] - r[j]| <= delta = (n + 64) * 2^-53 * r[0]: the reference adds <= n/2 + 2 terms c*(a+b) one after the
+//     other (each term two roundings, sum|terms| <= sum|x_i x_(i+lag)| <= r0), k_acf_blocks <= 48 (lane chain, wave tree);
+//   * to first order the reflection coefficient of stage m moves by
+//        dk_m = -(B' dR A)/e + k_m (A' dR A)/e,   A = (1, a_1 .. a_(m-1), 0), B = A reversed, e = e_(m-1)
+//     (the optimal predictors make the variation of A and B drop out: R A and R B vanish in the middle rows), hence
+//        |dk_m| <= ||a^(m-1)||_1^2 * (1 + |k_m|) / e_(m-1) * max_j |dr_j|;
+//   * the rounding of the recursion itself (the reference's run and this one) enters stage m through its sum
+//     num_m = sum a_i r_(m-i), <= (m+2) 2^-53 ||a||_1 r0 per run: it is put through the same sensitivity;
+//   * `safety` (16) multiplies the whole bound: tests/tools/cert_study.py and tests/test_gpu_cert.py measure the
+//     largest |k - k_ref| at 0.6 % of the UNscaled bound over tones with noise floors down to -140 dB, music-like and
+//     full-scale material at orders 16/32/48.
+// A block is certified when every k_m * 2^(q-1) keeps its distance from the rounding boundaries (half-integers, and
+// the two clip limits) and the estimated code length keeps its distance from the RAW threshold; everything else --
+// non-finite values, |k| >= 1, r0 near FLT_EPSILON -- is flagged: its group index goes to fb_list and the exact kernels
+// (k_lpc_blocks + k_blocks_finish<.., false> in list mode) redo it on the same stream.
+// list mode (list != NULL): the groups to finish are list[0 .. *list_count).
 // ---------------------------------------------------------------------------------------------
-template <int P>           // P >= order
+template <int P, bool CERT>           // P >= order
 __global__ __launch_bounds__(64)
 void k_blocks_finish(const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, uint32_t order,
                      double* __restrict__ out, int32_t* __restrict__ out_code, int32_t* __restrict__ out_kint,
-                     const uint32_t* __restrict__ out_rshift)
+                     const uint32_t* __restrict__ out_rshift,
+                     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
+                     uint32_t* __restrict__ cert_flag, uint32_t* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
+                     double safety, uint32_t bps)
 {
-  const uint32_t gi = blockIdx.x * 64 + threadIdx.x;
-  if (gi >= num_groups) { return; }
+  const uint32_t total = (list != nullptr) ? *list_count : num_groups;
+  for (uint32_t li = blockIdx.x * 64 + threadIdx.x; li < total; li += gridDim.x * 64) {
+  const uint32_t gi = (list != nullptr) ? list[li] : li;
   const uint32_t O1 = order + 1, O2 = order + 2;
   const sla_hip_lpc_group g = groups[gi];
   const uint64_t slot = g.slot_first;
@@ -936,17 +978,51 @@ void k_blocks_finish(const sla_hip_lpc_group* __restrict__ groups, uint32_t num_
   double r[P + 1], a[P + 1], par[P + 1];
 #pragma unroll
   for (int i = 0; i <= P; i++) { r[i] = ((uint32_t)i <= order) ? o[1 + i] : 0.0; a[i] = 0.0; par[i] = 0.0; }
+  const uint32_t rshift = out_rshift[slot];
+  const double u = 1.1102230246251565e-16;      // 2^-53
+  const double delta = CERT ? ((double)g.num_samples + 64.0) * u * r[0] : 0.0;
+  bool sure = true;
+  double gain = 0.0, gain_w = 0.0;              // sum log2(1 - k^2) and its half width
+  // margin test of one coefficient: does Round(k * 2^(q-1)) (half-integers away from zero, then clipped) keep its value
+  // for every k within +-eps?
+#define SLA_CERT_COEF(m, kk, eps) do { \
+    const double lim_ = ((m) < 4) ? 32768.0 : 128.0; \
+    const double v_ = (kk) * lim_, w_ = (eps) * lim_ * 1.0000001 + 1e-12; \
+    if (!(w_ < 0.25) || !(fabs(v_) < lim_ + 2.0)) { sure = false; } \
+    else if (v_ >= lim_ - 1.5) { if (!(v_ - w_ > lim_ - 1.5)) { sure = false; } } \
+    else if (v_ <= -lim_ + 0.5) { if (!(v_ + w_ < -lim_ + 0.5)) { sure = false; } } \
+    else { \
+      const double f_ = fabs(v_) + 0.5, d_ = f_ - floor(f_); \
+      if (!(d_ > w_ && 1.0 - d_ > w_)) { sure = false; } \
+      if (!(v_ + w_ < lim_ - 1.5) && !(v_ - w_ > lim_ - 1.5)) { sure = false; } \
+      if (!(v_ - w_ > -lim_ + 0.5) && !(v_ + w_ < -lim_ + 0.5)) { sure = false; } \
+    } \
+    { const double om_ = 1.0 - (kk) * (kk); \
+      if (!(om_ > 0.0)) { sure = false; } \
+      else { gain += log2(om_); gain_w += 2.0 * fabs(kk) * (eps) / om_ * 1.4426950408889634; } } \
+  } while (0)
+  if (CERT && g.num_samples >= order && !(fabs(r[0]) - (double)FLT_EPSILON > 2.0 * delta) && !((double)FLT_EPSILON - fabs(r[0]) > 2.0 * delta)) { sure = false; }
   if (!(g.num_samples < order || fabs(r[0]) < (double)FLT_EPSILON)) {
     a[0] = 1.0;
     a[1] = -r[1] / r[0];
     par[1] = r[1] / r[0];
     double e = r[0] + r[1] * a[1];
+    if (CERT) {
+      const double eps = safety * (1.0 + fabs(par[1])) / r[0] * (delta + 6.0 * u * r[0]);
+      SLA_CERT_COEF(1, par[1], eps);
+    }
 #pragma unroll
     for (int d = 1; d < P; d++) {
       if ((uint32_t)d < order) {
         double gamma = 0.0;
 #pragma unroll
         for (int i = 0; i <= d; i++) { gamma += a[i] * r[d + 1 - i]; }
+        double n1 = 0.0;
+        if (CERT) {
+#pragma unroll
+          for (int i = 0; i <= d; i++) { n1 += fabs(a[i]); }
+        }
+        const double e_prev = e;
         gamma /= (-e);
         e = (1.0 - gamma * gamma) * e;
         // a[i] <- a[i] + gamma * v[i],  v = (0, a[d], a[d-1], .., a[1], 1),  a[0] = 1, a[d+1] = 0 beforehand
@@ -958,10 +1034,16 @@ void k_blocks_finish(const sla_hip_lpc_group* __restrict__ groups, uint32_t num_
         a[0] = 1.0 + gamma * 0.0;
         a[d + 1] = 0.0 + gamma * 1.0;
         par[d + 1] = -gamma;
+        if (CERT) {
+          if (!(e_prev > 0.0) || !(fabs(gamma) < 1.0)) { sure = false; }
+          const double lev = 2.0 * (double)(d + 3) * u * n1 * r[0];
+          const double eps = safety * n1 * n1 * (1.0 + fabs(gamma)) / e_prev * (delta + lev);
+          SLA_CERT_COEF(d + 1, -gamma, eps);
+        }
       }
     }
   }
-  const uint32_t rshift = out_rshift[slot];
+#undef SLA_CERT_COEF
   o[0] = r[0];
   out_code[slot * O1] = 0; out_kint[slot * O1] = 0;
 #pragma unroll
@@ -980,6 +1062,23 @@ void k_blocks_finish(const sla_hip_lpc_group* __restrict__ groups, uint32_t num_
         out_kint[slot * O1 + j] = (int32_t)((uint32_t)code << (16u - qb)) >> rshift;
       }
     }
+  }
+  if (CERT) {
+    // RAW decision of the host (slai_code_length, src/SLAPredictor.c:416-468; threshold (double)0.95f on 8*bytes/bps):
+    // bits = 1.94.. + (log2(r0 * 2^(2(bps-1)) / n) + sum log2(1 - k^2)) / 2, known here to +- half the widths
+    const double power = r[0] * ldexp(1.0, (int)(2 * (bps - 1)));
+    if (power > (double)FLT_MIN * 1.000001) {
+      const double bits = 1.9426950408889634 + 0.5 * (log2(power) - log2((double)g.num_samples) + gain);
+      const double half = 0.5 * (delta / r[0] * 1.4426950408889634 * 2.0 + gain_w) * 1.000001 + 1e-9;
+      const double thr = (double)0.95f * (double)bps;
+      if (!(fabs(bits - thr) > half)) { sure = false; }
+    } else if (!(power < (double)FLT_MIN * 0.999999)) { sure = false; }
+    if (!(r[0] == r[0]) || !(fabs(r[0]) < 1e300)) { sure = false; }
+    cert_flag[slot] = sure ? 0u : 1u;
+    if (!sure) { fb_list[atomicAdd(fb_count, 1u)] = gi; }
+  } else if (cert_flag != nullptr) {
+    cert_flag[slot] = 2u;                       // exact: the reference's doubles bit for bit
+  }
   }
 }
 
@@ -1188,6 +1287,120 @@ void k_acf_tiles(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
     for (uint32_t j = 0; j < lane; j++) { x = __builtin_fma(e[LAGS - lane + j], e[LAGS + j], x); }
     dst[LAGS + lane] = x;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_acf_blocks: autocorrelation of the CHOSEN blocks' analysis windows in any summation order (the certified route of
+// the block stage, see k_blocks_finish<.., true>).  One wave per (block, channel) walks the whole window in passes of
+// (64 - NB) * 4 samples with k_acf_tiles' scheme: a lane owns 4 consecutive samples, the partners x[m + lag] of lag block
+// 4k..4k+3 arrive from lanes t+k, t+k+1 by one-lane DPP shifts, 16 FMAs per 8 shifted dwords; the accumulators live
+// in registers across the passes and are reduced over the lanes ONCE per block.  The samples are staged as the
+// reference stages them -- x[s] = w[s]*in[s] - 0.96875 * w[s-1]*in[s-1] (src/SLAEncoder.c:505-515, 540-543,
+// src/SLAPredictor.c:1803-1809): the previous windowed sample comes from the lane below (from the last owning lane of
+// the pass before for lane 0).  Out: slot = { -, r[0..order] } and the quantiser's shift, exactly what k_lpc_blocks hands
+// to k_blocks_finish -- but r[] is the correctly ordered sum only up to the rounding errors of ~48 additions.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double shr1_f64(double v, double first)       // lane t <- lane t-1, lane 0 <- first
+{
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(first), __double2loint(v), 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(first), __double2hiint(v), 0x138, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+template <int NB, bool MS>
+__global__ __launch_bounds__(256)
+void k_acf_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t order,
+                  const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups,
+                  const double* __restrict__ window_pool, double* __restrict__ out, uint32_t* __restrict__ out_rshift,
+                  unsigned long long* exec_span)
+{
+  constexpr uint32_t OL = 64 - NB;             // lanes of a pass that own samples
+  constexpr uint32_t STEP = OL * 4, LAGS = NB * 4;
+  span_begin(exec_span);
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t gi = blockIdx.x * 4 + wv;
+  if (gi >= num_groups) { span_end(exec_span); return; }
+  const sla_hip_lpc_group g = groups[gi];
+  const uint32_t N = g.num_samples;
+  const double scale = 4.656612873077392578125e-10;   // 2^-31, exact
+  const int32_t* p0 = pcm + (MS ? 0 : (uint64_t)g.channel * stride);
+  const int32_t* p1 = pcm + stride;
+  const double* win = window_pool + g.win_off;
+
+  double acc[LAGS];
+#pragma unroll
+  for (int i = 0; i < (int)LAGS; i++) { acc[i] = 0.0; }
+  uint32_t maxabs = 0;
+  double carry = 0.0;                          // windowed sample right before the pass (0 before the block: src/SLAPredictor.c:1729-1738)
+  for (uint32_t s0 = 0; s0 < N; s0 += STEP) {
+    const uint32_t idx = s0 + 4 * lane;
+    int32_t ra[4], rb[4];
+    double w[4];
+    load4_raw(p0, g.pcm_off, idx, N, ra);
+    if (MS) { load4_raw(p1, g.pcm_off, idx, N, rb); }
+#pragma unroll
+    for (int q = 0; q < 4; q++) { w[q] = (idx + q < N) ? win[idx + q] : 0.0; }
+    double y[4], cur[4], own[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      double v;
+      int32_t iv;
+      if (MS) {
+        const double l = (double)ra[q] * scale, r = (double)rb[q] * scale;
+        v = (g.channel == 0) ? ((l + r) / 2) : (l - r);
+        const int32_t li = ra[q] >> g.int_shift, ri = rb[q] >> g.int_shift;
+        iv = (g.channel == 0) ? ((int32_t)((uint32_t)li + (uint32_t)ri) >> 1) : (int32_t)((uint32_t)li - (uint32_t)ri);
+      } else {
+        v = (double)ra[q] * scale;
+        iv = ra[q] >> g.int_shift;
+      }
+      y[q] = v * w[q];
+      const uint32_t a = (iv > 0) ? (uint32_t)iv : (0u - (uint32_t)iv);
+      maxabs = (a > maxabs) ? a : maxabs;        // (samples past the block are zero)
+    }
+    const double below = shr1_f64(y[3], carry);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const double pv = (q == 0) ? below : y[q - 1];
+      const double x = y[q] - pv * 0.96875;
+      cur[q] = (idx + q < N) ? x : 0.0;
+      own[q] = (lane < OL) ? cur[q] : 0.0;
+    }
+    carry = readlane_f64(y[3], (int)OL - 1);
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      double nxt[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) { nxt[q] = shl1_f64(cur[q]); }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const double partner = (q + j < 4) ? cur[q + j] : nxt[q + j - 4];
+          acc[4 * k + j] = __builtin_fma(own[q], partner, acc[4 * k + j]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) { cur[q] = nxt[q]; }
+    }
+  }
+  double* o = out + (uint64_t)g.slot_first * (order + 2);
+  {
+    constexpr int M = (LAGS <= 16) ? 16 : (LAGS <= 32) ? 32 : 64;
+    double tv[M];
+#pragma unroll
+    for (int i = 0; i < M; i++) { tv[i] = (i < (int)LAGS) ? acc[i] : 0.0; }
+    uint32_t index; bool writer;
+    const double total = wave_transpose_sum<M>(tv, lane, index, writer);
+    if (writer && index <= order) { o[1 + index] = total; }
+  }
+  maxabs = umax_wave(maxabs);
+  if (lane == 0) {
+    const uint32_t l2c = (maxabs > 1) ? (32u - (uint32_t)__builtin_clz(maxabs - 1u)) : 0u;    // src/SLAUtility.c:677-696
+    const uint32_t bitwidth = (maxabs > 0) ? (l2c + 1u) : 1u;
+    out_rshift[g.slot_first] = (bitwidth > 16) ? (bitwidth - 16) : 0;
+  }
+  span_end(exec_span);
 }
 
 // k_search_finish: one wave per group.  r[lag] of candidate [start, end) = P of its tiles minus X of its
@@ -2355,13 +2568,20 @@ static inline unsigned long long* take_span() { unsigned long long* p = t_next_s
 // Tuning knobs of the launchers (include/sla_hip.h: sla_hip_tuning).  They belong to an encoder handle, which reads
 // them ONCE (environment at SLAEncoder_Create, sla_hip_encoder_set_option afterwards) and names its copy to the
 // launchers of its host thread; nothing on the launch path reads the environment.
-static thread_local const sla_hip_tuning* t_tuning = nullptr;
-extern "C" void sla_hip_use_tuning(const sla_hip_tuning* tuning) { t_tuning = tuning; }
+// The thread keeps a COPY: a handle may be destroyed (or used on another thread) while this thread goes on calling
+// launchers directly, and a stale pointer would then read freed memory.
+static thread_local sla_hip_tuning t_tuning_val;
+static thread_local bool t_tuning_set = false;
+extern "C" void sla_hip_use_tuning(const sla_hip_tuning* tuning)
+{
+  if (tuning != nullptr) { t_tuning_val = *tuning; t_tuning_set = true; } else { t_tuning_set = false; }
+}
 static inline sla_hip_tuning tuning()
 {
   sla_hip_tuning t;
   memset(&t, 0, sizeof(t));
-  if (t_tuning != nullptr) { t = *t_tuning; }
+  if (t_tuning_set) { t = t_tuning_val; }
+  if (!(t.plan_margin >= PLAN_MARGIN)) { t.plan_margin = 0.0; }      // below the built-in margin: not a valid setting
   return t;
 }
 
@@ -2387,6 +2607,9 @@ static hipError_t ensure_dynamic_lds(const void* fn, size_t bytes)
 }
 
 static inline int hip_rc(hipError_t e) { return (e == hipSuccess) ? 0 : -(int)e; }
+
+#define LIST_LPC_GRID 512u        // list mode of k_lpc_blocks: workgroups that walk the list of uncertified blocks
+#define LIST_FINISH_GRID 64u      // list mode of k_blocks_finish
 
 static int launch_prepass_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_channels,
                                uint32_t num_samples, uint32_t bits_per_sample, uint32_t mid_side,
@@ -2432,7 +2655,8 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
                            uint32_t max_cands_per_group,
                            const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
                            double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
-                           sla_hip_stream_t stream, uint32_t mode_flags, uint32_t* d_rerun_counter, int32_t* d_lat_residual);
+                           sla_hip_stream_t stream, uint32_t mode_flags, uint32_t* d_rerun_counter, int32_t* d_lat_residual,
+                           const uint32_t* list = nullptr, const uint32_t* list_count = nullptr, uint32_t* d_cert_flag = nullptr);
 
 extern "C" int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
                                   const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
@@ -2456,6 +2680,51 @@ extern "C" int sla_hip_launch_lpc_blocks(const int32_t* d_pcm, uint64_t plane_st
                          d_window_pool, d_out, d_code, d_kint, d_rshift, stream, 0u, nullptr, d_lattice_residual);
 }
 
+extern "C" int sla_hip_launch_lpc_blocks_cert(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                                              const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                                              const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
+                                              double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
+                                              uint32_t* d_cert_flag, uint32_t* d_fallback_list, uint32_t* d_fallback_count,
+                                              double safety, uint32_t bits_per_sample, sla_hip_stream_t stream)
+{
+  if (d_pcm == nullptr || d_groups == nullptr || d_cands == nullptr || d_window_pool == nullptr || d_out == nullptr || d_code == nullptr
+      || d_kint == nullptr || d_rshift == nullptr || d_cert_flag == nullptr || d_fallback_list == nullptr || d_fallback_count == nullptr) {
+    return SLA_APIRESULT_INVALID_ARGUMENT;
+  }
+  if (order < 1 || max_window == 0 || bits_per_sample == 0 || bits_per_sample > 32 || !(safety >= 1.0)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  const uint32_t lags = sla_hip_search_exact_lags(order);
+  if (lags == 0) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }      // orders above 52: the exact kernels only
+  if (num_groups == 0) { return 0; }
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(d_fallback_count, 0, sizeof(uint32_t), st);
+  if (e != hipSuccess) { return hip_rc(e); }
+  unsigned long long* span = take_span();
+  const dim3 grid((num_groups + 3) / 4), block(256);
+#define SLA_ACFB(NBB) do { \
+    if (mid_side) { hipLaunchKernelGGL((k_acf_blocks<NBB, true>), grid, block, 0, st, d_pcm, plane_stride, order, d_groups, num_groups, d_window_pool, d_out, d_rshift, span); } \
+    else { hipLaunchKernelGGL((k_acf_blocks<NBB, false>), grid, block, 0, st, d_pcm, plane_stride, order, d_groups, num_groups, d_window_pool, d_out, d_rshift, span); } } while (0)
+  switch (lags) {
+    case 12: SLA_ACFB(3); break;
+    case 20: SLA_ACFB(5); break;
+    case 36: SLA_ACFB(9); break;
+    default: SLA_ACFB(13); break;
+  }
+#undef SLA_ACFB
+  e = hipGetLastError();
+  if (e != hipSuccess) { return hip_rc(e); }
+  const dim3 fgrid((num_groups + 63) / 64), fblock(64);
+#define SLA_FINC(PP) hipLaunchKernelGGL((k_blocks_finish<PP, true>), fgrid, fblock, 0, st, d_groups, num_groups, order, d_out, d_code, d_kint, \
+                                        d_rshift, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_cert_flag, d_fallback_list, d_fallback_count, safety, bits_per_sample)
+  if (order <= 16) { SLA_FINC(16); } else if (order <= 32) { SLA_FINC(32); } else if (order <= 48) { SLA_FINC(48); } else { SLA_FINC(64); }
+#undef SLA_FINC
+  e = hipGetLastError();
+  if (e != hipSuccess) { return hip_rc(e); }
+  // whatever could not be certified: the exact kernels over the list the finish kernel left (usually empty)
+  return launch_lpc_impl(d_pcm, plane_stride, mid_side, order, d_groups, num_groups, max_window, 1, d_cands,
+                         d_window_pool, d_out, d_code, d_kint, d_rshift, stream, 0u, nullptr, nullptr,
+                         d_fallback_list, d_fallback_count, d_cert_flag);
+}
+
 extern "C" int sla_hip_launch_lpc_rerun(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
                                         const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
                                         uint32_t max_cands_per_group, const sla_hip_lpc_cand* d_cands,
@@ -2470,7 +2739,8 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
                            uint32_t max_cands_per_group,
                            const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
                            double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
-                           sla_hip_stream_t stream, uint32_t mode_flags, uint32_t* d_rerun_counter, int32_t* d_lat_residual)
+                           sla_hip_stream_t stream, uint32_t mode_flags, uint32_t* d_rerun_counter, int32_t* d_lat_residual,
+                           const uint32_t* list, const uint32_t* list_count, uint32_t* d_cert_flag)
 {
   if (d_pcm == nullptr || d_groups == nullptr || d_cands == nullptr || d_out == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (order < 1 || order > 255 || max_window == 0 || max_cands_per_group == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
@@ -2478,7 +2748,8 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
   if (d_code != nullptr && max_cands_per_group != 1) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (num_groups == 0) { return 0; }
   const sla_hip_tuning tune = tuning();
-  if (d_code != nullptr && order <= 64 && !tune.lpc_blocks_chains) {
+  if (list != nullptr && (d_code == nullptr || order > 64 || d_cert_flag == nullptr)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (d_code != nullptr && order <= 64 && (!tune.lpc_blocks_chains || list != nullptr)) {
     // chosen blocks: term tiles + lane-parallel Levinson (k_lpc_blocks)
     if (d_window_pool == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
     uint32_t pmax = 64 / order;
@@ -2502,7 +2773,8 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
       const void* fn = (spl == 12) ? (const void*)k_lpc_blocks<12, 24> : (lbk == 48u) ? (const void*)k_lpc_blocks<6, 48> : (const void*)k_lpc_blocks<6, 24>;
       hipError_t e = ensure_dynamic_lds(fn, bytes);
       if (e != hipSuccess) { return hip_rc(e); }
-      const dim3 grid((num_groups + p - 1) / p), block(LB_THREADS);
+      // list mode: a fixed grid walks the list (two workgroups per CU hold what the device can run at once)
+      const dim3 grid((list != nullptr) ? LIST_LPC_GRID : (num_groups + p - 1) / p), block(LB_THREADS);
       unsigned long long* span = take_span();
 #ifdef SLA_HIP_DEBUG
       const uint32_t clk = (uint32_t)(getenv("SLA_HIP_LPC_CLK") != nullptr);
@@ -2514,20 +2786,20 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
       const uint32_t defer = (d_lat_residual == nullptr && order <= 64) ? 1u : 0u;
       if (spl == 12) {
         hipLaunchKernelGGL((k_lpc_blocks<12, 24>), grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
-                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span, d_lat_residual, defer);
+                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span, d_lat_residual, defer, list, list_count);
       } else if (lbk == 48u) {
         hipLaunchKernelGGL((k_lpc_blocks<6, 48>), grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
-                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span, d_lat_residual, defer);
+                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span, d_lat_residual, defer, list, list_count);
       } else {
         hipLaunchKernelGGL((k_lpc_blocks<6, 24>), grid, block, bytes, (hipStream_t)stream, d_pcm, plane_stride, mid_side, order,
-                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span, d_lat_residual, defer);
+                           d_groups, num_groups, p, d_window_pool, d_out, d_code, d_kint, d_rshift, (uint32_t)xr, nch, clk, span, d_lat_residual, defer, list, list_count);
       }
       if (defer) {
-        const dim3 fgrid((num_groups + 63) / 64), fblock(64);
-        if (order <= 16) { hipLaunchKernelGGL(k_blocks_finish<16>, fgrid, fblock, 0, (hipStream_t)stream, d_groups, num_groups, order, d_out, d_code, d_kint, d_rshift); }
-        else if (order <= 32) { hipLaunchKernelGGL(k_blocks_finish<32>, fgrid, fblock, 0, (hipStream_t)stream, d_groups, num_groups, order, d_out, d_code, d_kint, d_rshift); }
-        else if (order <= 48) { hipLaunchKernelGGL(k_blocks_finish<48>, fgrid, fblock, 0, (hipStream_t)stream, d_groups, num_groups, order, d_out, d_code, d_kint, d_rshift); }
-        else { hipLaunchKernelGGL(k_blocks_finish<64>, fgrid, fblock, 0, (hipStream_t)stream, d_groups, num_groups, order, d_out, d_code, d_kint, d_rshift); }
+        const dim3 fgrid((list != nullptr) ? LIST_FINISH_GRID : (num_groups + 63) / 64), fblock(64);
+#define SLA_FIN(PP) hipLaunchKernelGGL((k_blocks_finish<PP, false>), fgrid, fblock, 0, (hipStream_t)stream, d_groups, num_groups, order, d_out, d_code, d_kint, \
+                                       d_rshift, list, list_count, d_cert_flag, (uint32_t*)nullptr, (uint32_t*)nullptr, 0.0, 0u)
+        if (order <= 16) { SLA_FIN(16); } else if (order <= 32) { SLA_FIN(32); } else if (order <= 48) { SLA_FIN(48); } else { SLA_FIN(64); }
+#undef SLA_FIN
       }
 #ifdef SLA_HIP_DEBUG
       if (clk) {

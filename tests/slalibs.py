@@ -355,6 +355,22 @@ def ref():
     return _cache["ref"]
 
 
+def parcor_same(tg, to, nb, comp=None, tol=1e-9, gslice=None):
+    """PARCOR doubles of a HIP trace against the oracle's trace: bit patterns for the (block, channel) pairs the exact
+    chain kernels analysed (tg.parcor_exact == 1), |difference| <= tol for the certified ones (their codes, kint and RAW
+    decisions are compared bit for bit by the callers).  gslice: the HIP trace's block range (default [0, nb))."""
+    gs = gslice if gslice is not None else slice(0, nb)
+    a, b = tg.parcor[gs], to.parcor[:nb]
+    ex = tg.parcor_exact[gs].astype(bool)
+    if comp is not None:
+        a, b, ex = a[comp], b[comp], ex[comp]
+    if a.size == 0:
+        return True
+    bits_ok = np.array_equal(a.view(np.uint64)[ex], b.view(np.uint64)[ex])
+    near_ok = bool(np.all(np.abs(a[~ex] - b[~ex]) <= tol))
+    return bits_ok and near_ok
+
+
 # ---- deterministic inputs -------------------------------------------------
 
 def read_wav(path):

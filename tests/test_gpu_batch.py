@@ -154,7 +154,7 @@ def test_batch_analysis_on_device_resident_planes(oracle, hip):
             assert np.array_equal(tr.blk_start[b:b + k], to.blk_start[:k] + s0)
             assert np.array_equal(tr.blk_nsmpl[b:b + k], to.blk_nsmpl[:k]) and np.array_equal(tr.blk_type[b:b + k], to.blk_type[:k])
             comp = to.blk_type[:k] == 0
-            assert np.array_equal(tr.parcor[b:b + k].view(np.uint64)[comp], to.parcor[:k].view(np.uint64)[comp])
+            assert S.parcor_same(tr, to, k, comp, gslice=slice(b, b + k))
             for f in ("code", "kint", "rshift", "pitch", "rice_init"):
                 assert np.array_equal(getattr(tr, f)[b:b + k][comp], getattr(to, f)[:k][comp]), f
             for j in np.nonzero(comp)[0]:

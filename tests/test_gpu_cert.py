@@ -1,0 +1,162 @@
+"""GPU tests of the block stage's certified route (sla_hip_launch_lpc_blocks_cert, option "block_cert"): chosen
+blocks are analysed with any-order autocorrelation sums, the quantised PARCOR codes (reference
+src/SLAEncoder.c:567-589) and the RAW decision (:553-565) are certified per block, the rest is redone by the exact
+chain kernels.  What must hold: the bytes, codes, lattice coefficients and residuals are the oracle's on every route;
+the doubles of certified blocks sit well inside the certificate's bound; ill-conditioned material falls back."""
+import numpy as np
+import pytest
+
+import certlib
+import slalibs as S
+import waveforms as W
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    torch.cuda.init()
+    import sla_amd
+    sla_amd.lib()
+    return sla_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return S.oracle()
+
+
+def encode(hip, p, pcm, **options):
+    enc = hip.Encoder(p.cap_channels, p.cap_block_samples, p.cap_parcor_order, p.cap_longterm_order, p.cap_lms_order)
+    try:
+        enc.set_wave_format(p.num_channels, p.bits_per_sample, p.sampling_rate)
+        enc.set_encode_parameter(p.parcor_order, p.longterm_order, p.lms_order, p.ch_process_method,
+                                 p.window_type, p.max_block_samples)
+        enc.set_option("stream", 0)
+        for k, v in options.items():
+            enc.set_option(k, v)
+        data = enc.encode_whole(pcm)
+        return data, enc.trace(), enc.last_block_cert()
+    finally:
+        enc.close()
+
+
+def tones(n, bits, floor_db, seed, nch=1, rate=48000.0):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n, dtype=np.float64)
+    out = np.zeros((nch, n), np.int32)
+    for ch in range(nch):
+        x = 0.5 * np.sin(2 * np.pi * (997.0 + 31 * ch) * t / rate) + 0.3 * np.sin(2 * np.pi * 61.0 * t / rate + ch)
+        x += (10.0 ** (floor_db / 20.0)) * rng.standard_normal(n)
+        full = float(1 << (bits - 1))
+        q = np.clip(np.rint(x * full), -full, full - 1).astype(np.int64)
+        out[ch] = ((q << (32 - bits)).astype(np.int64)).astype(np.int32)
+    return out
+
+
+def material(name, nch, n, bits, seed):
+    if name == "bench":
+        return S.synth_pcm(nch, n, bits, seed=12345 + seed)
+    if name == "music":
+        return W.music_like(nch, n, bits, seed=seed + 1)
+    if name.startswith("tones"):
+        return tones(n, bits, float(name[5:]), seed, nch)
+    return W.gen(name, nch, n, bits, seed=seed)
+
+
+def check_against_oracle(oracle, p, pcm, data, tr):
+    ret, want, to = oracle.encode_trace(p, pcm)
+    assert ret == 0
+    nb = to.num_blocks
+    assert tr.num_blocks == nb
+    for f in ("blk_start", "blk_nsmpl", "blk_type", "blk_bytes"):
+        assert np.array_equal(getattr(tr, f)[:nb], getattr(to, f)[:nb]), f
+    comp = to.blk_type[:nb] == 0
+    for f in ("code", "kint", "rshift", "pitch", "rice_init"):
+        assert np.array_equal(getattr(tr, f)[:nb][comp], getattr(to, f)[:nb][comp]), f
+    assert S.parcor_same(tr, to, nb, comp)
+    assert data == want
+    return to, comp
+
+
+CASES = [
+    # name, channels, bits, order, max block, ms
+    ("bench", 1, 16, 16, 4096, 0), ("bench", 2, 24, 32, 4096, 1), ("bench", 3, 24, 48, 8192, 0),
+    ("music", 2, 16, 16, 4096, 1), ("music", 1, 24, 32, 8192, 0), ("music", 2, 24, 48, 16384, 0),
+    ("white", 1, 16, 8, 4096, 0), ("gauss", 2, 24, 20, 4096, 1), ("chirp", 1, 24, 32, 8192, 0),
+    ("sine", 1, 16, 16, 4096, 0), ("nyquist", 1, 16, 16, 4096, 0), ("posconst", 2, 24, 12, 4096, 0),
+    ("tones-20", 1, 24, 32, 4096, 0), ("tones-60", 2, 24, 48, 8192, 0), ("tones-100", 1, 24, 32, 4096, 0),
+    ("tones-140", 1, 32, 48, 8192, 0), ("tones-60", 1, 32, 16, 2048, 0), ("silence", 2, 16, 16, 4096, 0),
+    ("bench", 1, 8, 4, 2048, 0), ("music", 1, 16, 52, 8192, 0),
+]
+
+
+@pytest.mark.parametrize("name,nch,bits,order,maxb,ms", CASES)
+def test_certified_route_is_the_oracle(hip, oracle, name, nch, bits, order, maxb, ms):
+    """default route (certificate + exact fallback), forced-exact route and everything-flagged route: same bytes,
+    codes and residuals as the oracle; the doubles are the oracle's bit for bit wherever the exact kernels ran"""
+    n = 5 * maxb + 1234
+    pcm = material(name, nch, n, bits, seed=order + maxb // 1024)
+    p = S.make_params(nch, bits, 48000, order, 3 if order > 16 else 1, 8, ms, 1, maxb, cap=(nch, 16384, 52, 3, 8))
+    data, tr, (on, redone) = encode(hip, p, pcm)
+    assert on == 1
+    to, comp = check_against_oracle(oracle, p, pcm, data, tr)
+    nslots = int((to.blk_type[:to.num_blocks] != 1).sum()) * nch      # every non-silent (block, channel) is analysed, RAW ones too
+    assert int(tr.parcor_exact[:to.num_blocks][comp].sum()) <= redone <= nslots
+    # every block through the exact kernels: option off, and certificate on but so strict that nothing certifies
+    d2, t2, (on2, _) = encode(hip, p, pcm, block_cert=0)
+    assert on2 == 0 and d2 == data and bool(t2.parcor_exact[:to.num_blocks][comp].all())
+    assert np.array_equal(t2.parcor[:to.num_blocks].view(np.uint64)[comp], to.parcor[:to.num_blocks].view(np.uint64)[comp])
+    d3, t3, (on3, redone3) = encode(hip, p, pcm, block_cert_safety=1e30)
+    assert on3 == 1 and d3 == data
+    if name != "silence":
+        assert redone3 == nslots and bool(t3.parcor_exact[:to.num_blocks][comp].all())
+        assert np.array_equal(t3.parcor[:to.num_blocks].view(np.uint64)[comp], to.parcor[:to.num_blocks].view(np.uint64)[comp])
+
+
+def test_ill_conditioned_material_falls_back(hip, oracle):
+    """two pure tones over a -140 dB floor: the Toeplitz system is singular to working precision, no code of the high
+    stages can be certified -- the blocks take the exact kernels and the bytes stay the oracle's"""
+    pcm = tones(6 * 8192, 24, -140.0, 3)
+    p = S.make_params(1, 24, 48000, 48, 3, 8, 0, 1, 8192, cap=(1, 8192, 48, 3, 8))
+    data, tr, (on, redone) = encode(hip, p, pcm)
+    to, comp = check_against_oracle(oracle, p, pcm, data, tr)
+    assert on == 1 and redone >= int(comp.sum()) // 2
+    benign = S.synth_pcm(1, 6 * 8192, 24)
+    data, tr, (on, redone) = encode(hip, p, benign)
+    check_against_oracle(oracle, p, benign, data, tr)
+    assert on == 1 and redone == 0
+
+
+@pytest.mark.parametrize("order,maxb,bits", [(16, 4096, 16), (32, 4096, 24), (48, 8192, 24), (32, 2048, 32)])
+def test_certified_doubles_sit_inside_the_bound(hip, oracle, order, maxb, bits):
+    """conditioning sweep (applied to the block certificate): tones over noise floors from -20 to
+    -120 dB, bench and music-like material.  For every certified (block, channel): |k - k_ref| <= 25 % of the
+    certificate's eps_m (safety 16), recomputed here from the oracle's autocorrelation of the same windowed block."""
+    win_cache = {}
+    worst = 0.0
+    certified = flagged = 0
+    for si, (name, floor) in enumerate([("bench", 0), ("music", 0)] + [("tones", f) for f in (-20, -40, -60, -80, -100, -120)]):
+        n = 12 * maxb
+        pcm = tones(n, bits, float(floor), 100 + si) if name == "tones" else material(name, 1, n, bits, seed=si)
+        p = S.make_params(1, bits, 48000, order, 1, 8, 0, 1, maxb, cap=(1, maxb, order, 1, 8))
+        data, tr, (on, redone) = encode(hip, p, pcm)
+        to, comp = check_against_oracle(oracle, p, pcm, data, tr)
+        for b in np.nonzero(comp)[0]:
+            if tr.parcor_exact[b, 0]:
+                flagged += 1
+                continue
+            s, nb = int(to.blk_start[b]), int(to.blk_nsmpl[b])
+            if nb not in win_cache:
+                win_cache[nb] = oracle.window(1, nb)
+            x = oracle.preemph_f64(pcm[0, s:s + nb].astype(np.float64) * 2.0 ** -31 * win_cache[nb])
+            r = oracle.autocorr(x, order + 1)
+            if r[0] < certlib.FLT_EPSILON:
+                continue
+            _, eps = certlib.eps_bound(r, nb, order, safety=16.0)
+            dk = np.abs(tr.parcor[b, 0, 1:] - to.parcor[b, 0, 1:])
+            assert np.all(np.isfinite(eps[1:]))
+            worst = max(worst, float(np.max(dk / eps[1:])))
+            certified += 1
+    assert certified >= 40 and worst <= 0.25, (certified, flagged, worst)

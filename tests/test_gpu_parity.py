@@ -62,7 +62,7 @@ def assert_same_as_oracle(oracle, hip, p, pcm, roundtrip=True):
     for f in ("blk_start", "blk_nsmpl", "blk_type", "blk_bytes"):
         assert np.array_equal(getattr(tg, f)[:nb], getattr(to, f)[:nb]), f
     comp = to.blk_type[:nb] == 0
-    assert np.array_equal(tg.parcor[:nb].view(np.uint64)[comp], to.parcor[:nb].view(np.uint64)[comp])
+    assert S.parcor_same(tg, to, nb, comp)
     for f in ("code", "kint", "rshift", "pitch", "rice_init"):
         assert np.array_equal(getattr(tg, f)[:nb][comp], getattr(to, f)[:nb][comp]), f
     used = (to.pitch[:nb] >= 3) & comp[:, None]
@@ -926,7 +926,7 @@ def _full_size_check(oracle, hip, p, pcm, prefix_frames):
     ret, want, to = oracle.encode_trace(p, np.ascontiguousarray(pcm[:, :m]))
     assert ret == 0 and to.offset_lshift == tr.offset_lshift
     assert want[43:] == got[43:len(want)]
-    assert np.array_equal(tr.parcor[:to.num_blocks].view(np.uint64), to.parcor[:to.num_blocks].view(np.uint64))
+    assert S.parcor_same(tr, to, to.num_blocks)
 
 
 def test_full_size_c2(oracle, hip):

@@ -33,7 +33,11 @@ def check_trace_against_golden(g, tr, data):
     for f in ("blk_start", "blk_nsmpl", "blk_type"):
         assert np.array_equal(getattr(tr, f)[:nb], g[f]), f
     comp = g["blk_type"] == 0
-    assert np.array_equal(tr.parcor[:nb].view(np.uint64)[comp], g["parcor_bits"][comp])
+    ex = getattr(tr, "parcor_exact", None)      # HIP trace: 1 where the exact chain kernel ran, 0 where the block was certified
+    ex = np.ones_like(comp[:, None] & (tr.rshift[:nb] >= 0)) if ex is None else ex[:nb].astype(bool)
+    want = g["parcor_bits"].view(np.float64)
+    assert np.array_equal(tr.parcor[:nb].view(np.uint64)[comp & ex.all(axis=1)], g["parcor_bits"][comp & ex.all(axis=1)])
+    assert np.all(np.abs(tr.parcor[:nb][comp] - want[comp]) <= 1e-9)
     for f in ("code", "kint", "rshift", "pitch", "rice_init"):
         assert np.array_equal(getattr(tr, f)[:nb][comp], g[f][comp]), f
     used = (g["pitch"] >= 3) & comp[:, None]
