@@ -11,12 +11,16 @@ N = 1: the configuration BASELINE.json's metric is quoted on (C2 unless --config
 carries `other_configs` -- C3 and C5 at their FULL length and the C4 clip batch -- each with its own roofline,
 verification and CPU baseline.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): ONE file N times as long as the configuration's, its
-super-frames sharded over the ranks exactly as include/sla_hip.h ("one file, several GPUs") prescribes: every step
-scans the rank's piece, all-reduces the OR word and all-gathers the silence mask over RCCL, derives the bounds, runs
-the hot path on the rank's own range with the file's OR word, and re-assembles the residual stream with one RCCL
-all-gather over xGMI (the north star's collective; it travels while the next step is analysed).  Per-GPU work is
-fixed as N grows -> "weak" scaling of one sharded job.
+N > 1, one rank per GPU -- launched by torch.distributed.run, or by this script itself: `python bench.py --gpus N`
+without WORLD_SIZE in the environment starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
+child process (the parent never touches the GPU), relays rank 0's JSON line and exits with the child's code; inside the
+ranks WORLD_SIZE must equal --gpus.  ONE file, its super-frames sharded over the ranks exactly as include/sla_hip.h
+("one file, several GPUs") prescribes: every step scans the rank's piece, exchanges the OR word / zero-word count (and
+the silence mask when there is silence) over RCCL, derives the bounds, runs the hot path on the rank's own range with
+the file's OR word, and re-assembles the residual stream with one RCCL all-gather over xGMI (the north star's
+collective; it travels while the next step is analysed).  --scaling weak (default): the file is N times as long as the
+configuration's, per-GPU work fixed; --scaling strong: the configuration's own length (C4: --total-clips clips) split
+over the N ranks (BASELINE configs 4 and 5 are fixed totals over 8 GPUs).
 
 After the timed loop the buffers the LAST TIMED STEP left on the device are checked: block table, PARCOR bit patterns,
 codes, residuals and bytes of the first super-frames against the oracle, and the packed image round-trips through the
@@ -235,25 +239,28 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
         # 1024-sample boundaries and analysed in ONE pipeline pass (sla_hip_analyze_batch_device)
         clip_n, tile = n_cfg, 1024
         pitch = (clip_n + tile - 1) // tile * tile
-        distinct = [S.synth_pcm(nch, clip_n, bits, rate, seed=4000 + 16 * rank + k) for k in range(min(16, args.clips))]
-        clips = [distinct[k % len(distinct)] for k in range(args.clips)]
-        batch = {"starts": np.arange(args.clips, dtype=np.uint32) * pitch, "lens": np.full(args.clips, clip_n, np.uint32),
-                 "clips": clips, "span": args.clips * pitch}
-        n_own = clip_n * args.clips                      # samples per channel that are audio
+        # weak: --clips per GPU and step; strong: --total-clips round-robin over the ranks (C4 = 1000 clips over 8 GPUs)
+        nclips = args.clips if args.scaling == "weak" else len(range(rank, args.total_clips, world))
+        distinct = [S.synth_pcm(nch, clip_n, bits, rate, seed=4000 + 16 * rank + k) for k in range(min(16, max(nclips, 1)))]
+        clips = [distinct[k % len(distinct)] for k in range(nclips)]
+        batch = {"starts": np.arange(nclips, dtype=np.uint32) * pitch, "lens": np.full(nclips, clip_n, np.uint32),
+                 "clips": clips, "span": max(nclips, 1) * pitch, "count": nclips}
+        n_own = clip_n * nclips                          # samples per channel that are audio
         stride = batch["span"]
         d_pcm = torch.zeros((nch, stride), dtype=torch.int32, device="cuda")
         for k, c in enumerate(clips):
             d_pcm[:, k * pitch:k * pitch + clip_n] = torch.from_numpy(c).cuda()
         n_file, lo0, hi0, base = n_own, 0, n_own, 0
     else:
-        # one file of world x the configuration's length; this rank holds its scan piece plus one maximum block
-        n_file = n_cfg * world
+        # one file of world x the configuration's length (weak) or of the configuration's own length (strong); this
+        # rank holds its scan piece plus one maximum block
+        n_file = n_cfg * world if args.scaling == "weak" else n_cfg
         lo0, hi0 = sdist.scan_piece(n_file, world, rank)
-        top = min(n_file, hi0 + maxb) if world > 1 else n_file
+        top = sdist.upload_range(n_file, world, rank, maxb)[1] if world > 1 else n_file
         base = lo0
         span = top - lo0
         # the same plane stride on every rank (the residual planes are all-gathered as they are)
-        widest = max((min(n_file, sdist.scan_piece(n_file, world, r)[1] + maxb) if world > 1 else n_file) - sdist.scan_piece(n_file, world, r)[0]
+        widest = max(((sdist.upload_range(n_file, world, r, maxb)[1] if world > 1 else n_file) - sdist.scan_piece(n_file, world, r)[0])
                      for r in range(world))
         stride = (widest + 63) // 64 * 64
         d_pcm = torch.zeros((nch, stride), dtype=torch.int32, device="cuda")
@@ -346,18 +353,25 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
     kernel_ms /= max(args.steps, 1)
     span_ms /= max(args.steps, 1)
 
-    total_samples = float(n_file if batch is None else n_own) * nch * (1 if batch is None else world) * args.steps
+    if batch is not None and world > 1:
+        n_all = int(sdist.sum_over_ranks(float(n_own), dev_comm))      # samples per channel all ranks analysed per step
+    else:
+        n_all = n_file if batch is None else n_own
+    total_samples = float(n_all) * nch * args.steps
     value = total_samples / elapsed / 1e6
     own_lo, own_hi = state["own"]
     n_last = (own_hi - own_lo) if batch is None else n_own
 
     out = {
         "value": round(value, 3), "unit": "Msamples/s", "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
-        "config": {"workload": WORKLOAD_NAME[cfg] + (", batch of %d clips per GPU in one pass" % args.clips if batch else "")
-                               + (", ONE file of %d x that length sharded over %d ranks" % (world, world) if world > 1 and batch is None else ""),
-                   "name": cfg, "channels": nch, "bits": bits, "rate": rate, "seconds": seconds * (world if batch is None else 1),
+        "config": {"workload": WORKLOAD_NAME[cfg] + (", batch of %d clips on this GPU in one pass" % batch["count"] if batch else "")
+                               + (", ONE file of %d x that length sharded over %d ranks" % (world, world) if world > 1 and batch is None and args.scaling == "weak" else "")
+                               + (", that ONE file sharded over %d ranks" % world if world > 1 and batch is None and args.scaling == "strong" else ""),
+                   "name": cfg, "channels": nch, "bits": bits, "rate": rate,
+                   "seconds": seconds * (world if batch is None and args.scaling == "weak" else 1),
                    "parcor_order": order, "longterm_order": ltm, "lms_order": lms,
                    "max_block_samples": maxb, "samples_per_step_per_gpu": int((n_file // world if batch is None else n_own) * nch),
+                   "samples_per_step_all_gpus": int(n_all) * nch,
                    "parallelism": ("super-frames of one file sharded over %d GPUs: OR all-reduce + mask all-gather, then one RCCL all-gather "
                                    "of the residual planes%s" % (world, " overlapped with the next step" if overlap else ""))
                                   if world > 1 else "1 GPU"},
@@ -417,7 +431,7 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
         tr = enc.trace()
         nb = tr.num_blocks
         ok, checked = True, 0
-        for k in range(min(2, args.clips)):
+        for k in range(min(2, batch["count"])):
             ret, want, to = o.encode_trace(p, batch["clips"][k])
             start = int(batch["starts"][k])
             sel = [b for b in range(nb) if start <= tr.blk_start[b] < start + int(batch["lens"][k])]
@@ -428,11 +442,11 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
                     s0, s1, ln = int(tr.blk_start[b]), int(to.blk_start[j]), int(to.blk_nsmpl[j])
                     ex = tr.parcor_exact[b].astype(bool)      # exact chain kernel: bit patterns; certified route: the codes decide
                     ok &= bool(np.array_equal(tr.parcor[b].view(np.uint64)[ex], to.parcor[j].view(np.uint64)[ex])
-                               and np.all(np.abs(tr.parcor[b][~ex] - to.parcor[j][~ex]) <= 1e-9)
+                               and np.all(np.abs(tr.parcor[b][~ex] - to.parcor[j][~ex]) <= 2.0 ** -9)
                                and np.array_equal(tr.code[b], to.code[j]) and np.array_equal(tr.kint[b], to.kint[j]) and np.array_equal(tr.rice_init[b], to.rice_init[j])
                                and np.array_equal(tr.res_final[:, s0:s0 + ln], to.res_final[:, s1:s1 + ln]))
                 checked += 1
-        ver.update({"blocks_compared": checked, "fields": "block table, PARCOR (bit patterns where the exact kernel ran, 1e-9 where certified), codes, Rice parameters, final residual of the first 2 clips"})
+        ver.update({"blocks_compared": checked, "fields": "block table, PARCOR (bit patterns where the exact kernel ran, a quarter quantisation step where certified), codes, Rice parameters, final residual of the first 2 clips"})
     else:
         own_n = own_hi - own_lo
         frames = min(20 if maxb <= 4096 else 8, max(own_n // maxb - 1, 1))
@@ -464,7 +478,7 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
                        and np.array_equal(tr.code[:nblk], to.code[:nblk]) and np.array_equal(tr.kint[:nblk], to.kint[:nblk]) and np.array_equal(tr.rice_init[:nblk], to.rice_init[:nblk])
                        and np.array_equal(tr.blk_nsmpl[:nblk], to.blk_nsmpl[:nblk]))
         ver.update({"blocks_compared": int(nblk), "fields": "bytes of the first blocks (headers, Rice bodies, CRC16)"
-                    + (", PARCOR (bit patterns where the exact kernel ran, 1e-9 where certified), codes, Rice parameters" if to is not None else "")})
+                    + (", PARCOR (bit patterns where the exact kernel ran, a quarter quantisation step where certified), codes, Rice parameters" if to is not None else "")})
         # ... and the whole image decodes back to the PCM this rank analysed (size-independent property at full size)
         if lms in (4, 8, 16, 32) and maxb <= 16384:
             dec = sla_amd.Decoder(nch, maxb, order, ltm, lms)
@@ -585,6 +599,21 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
     return out
 
 
+def self_launch(ngpus):
+    """start the N ranks of this very command line as a child process: python -m torch.distributed.run ... bench.py ...
+    Returns the child's exit code; its stdout (rank 0's JSON line) and stderr pass through."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-worker":          # a child of cpu_baseline's all-cores leg: never touches the GPU
         print(json.dumps(_cpu_worker((sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5])))), flush=True)
@@ -601,14 +630,41 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="single-thread CPU work of the primary configuration's baseline (a third of it for every other leg)")
     ap.add_argument("--sync-gather", action="store_true", help="N > 1: wait for each step's all-gather before the next step starts")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
-    ap.add_argument("--clips", type=int, default=125, help="C4 only: clips per GPU and step (1000 clips over 8 GPUs)")
+    ap.add_argument("--clips", type=int, default=125, help="C4, weak scaling: clips per GPU and step (1000 clips over 8 GPUs)")
+    ap.add_argument("--total-clips", type=int, default=1000, help="C4, strong scaling: clips per step over all GPUs")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="N > 1: weak = one file N times the configuration's length (per-GPU work fixed); strong = the "
+                         "configuration's own length (C4: --total-clips) split over the N ranks")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only bring the ranks up (process group of --backend, no GPU work) and print the line's launch fields")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver may run it: this process has not touched the GPU (no torch import yet)
+        # and never will -- it starts the N ranks as a CHILD process, relays what rank 0 prints and exits with its code
+        raise SystemExit(self_launch(args.gpus))
 
     import slalibs as S
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(json.dumps({"error": "--gpus %d but WORLD_SIZE is %d: launch with --nproc-per-node %d (or without torchrun)"
+                                   % (args.gpus, world, args.gpus)}), file=sys.stderr, flush=True)
+        raise SystemExit(2)
+    if args.launch_check:
+        import torch.distributed as dist
+        seen = 1
+        if world > 1:
+            dist.init_process_group("gloo" if args.backend != "nccl" else args.backend)
+            seen = dist.get_world_size()
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": seen, "scaling": args.scaling}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     want_others = (world == 1 and not args.no_other_configs and args.seconds is None)
     # ---- CPU legs first, while this process has not touched the GPU (they start worker processes) ---------------
     cpu_results = None
@@ -633,12 +689,14 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    ranks_seen = dist.get_world_size() if world > 1 else 1
     res = run_config(torch, sla_amd, S, args.config, args, rank, world, True, cpu_results)
     if rank == 0:
         out = {"metric": "encode Msamples/s (LPC+residual path), verified bit-exact vs the oracle in this run",
                "value": res.pop("value"), "unit": res.pop("unit"), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f64+int32", "data": "synthetic"}
+               "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+               "dtype": "f64+int32", "data": "synthetic",
+               ("nccl_ranks_seen" if args.backend == "nccl" else "%s_ranks_seen" % args.backend): ranks_seen}
         out.update(res)
         out["device"] = sla_amd.device_name()
         if want_others:

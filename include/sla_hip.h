@@ -123,7 +123,11 @@ typedef struct sla_hip_pack_block {
 /* Tuning knobs of the launchers.  Nothing on the launch path reads the environment: an encoder handle owns one of
  * these (filled once in SLAEncoder_Create, changed through sla_hip_encoder_set_option) and names it to the
  * launchers of the calling host thread before it launches; a thread that never called sla_hip_use_tuning (or
- * passed NULL) gets the defaults = all zeros.  None of the knobs changes a result, only how the work is laid out. */
+ * passed NULL) gets the defaults = all zeros.  None of the knobs changes a result, only how the work is laid out --
+ * the three certification margins ("plan_margin", "cert_safety", "block_cert_safety") may only be WIDENED beyond their
+ * built-in values (1e-4, 64, 16; plan_margin / cert_safety also take 0 = built-in value / no certificate): smaller
+ * values would weaken the certificates byte-identity rests on, and sla_hip_encoder_set_option refuses them (a
+ * plan_margin below 1e-4 in a sla_hip_tuning handed to sla_hip_use_tuning is read as 0). */
 typedef struct sla_hip_tuning {
   uint32_t lpc_pack;            /* windows per workgroup of k_lpc / k_lpc_blocks, 0 = automatic                      */
   uint32_t lpc_threads;         /* 256 or 512 threads per k_lpc workgroup, 0 = automatic                             */
@@ -443,8 +447,11 @@ int sla_hip_analyze_batch_device(struct SLAEncoder* encoder, const int32_t* d_pc
  *                   (src/SLAEncoder.c:392-408, 846-869)                                -> all-gather of the 1-bit mask
  *   the header      counts blocks and keeps the largest block / bit rate (:920-926)   -> gathered with the bytes
  * Sequence on rank r of `world` (file of N samples per channel, pieces cut at multiples of 1024):
- *   1. upload any piece of the file that contains [N*r/world, N*(r+1)/world) plus max_num_block_samples behind it;
- *      sla_hip_shard_scan on exactly [N*r/world .. N*(r+1)/world)  ->  OR word, mask bits of the piece
+ *   1. scan pieces tile [0, N): piece r = [cut(r), cut(r+1)), cut(r) = ceil(N*r/world) floored to a multiple of 1024.
+ *      Upload [cut(r), min(N, cut(r+1) + 1023 + max_num_block_samples)): bounds[r+1] of step 3 is the first
+ *      super-frame start at or behind the UNFLOORED target ceil(N*(r+1)/world), i.e. less than one maximum block
+ *      behind it (sla_amd/dist.py: upload_range);
+ *      sla_hip_shard_scan on exactly the piece  ->  OR word, mask bits of the piece
  *   2. all-gather the OR words and OR them, all-gather the mask pieces (N/8 bytes in total)
  *   3. sla_hip_shard_bounds (pure host arithmetic, every rank computes the same table): rank r owns
  *      [bounds[r], bounds[r+1]), both super-frame starts of the whole file's hop
@@ -460,7 +467,7 @@ int sla_hip_shard_scan(struct SLAEncoder* encoder, const int32_t* d_pcm, uint64_
 /* Steps 1-3 without the mask when the file has no silence (the usual case): the scan only brings home the OR word and
  * the number of all-zero 64-sample mask words of the piece; a silence run moves a super-frame start only when it is at
  * least 2048 samples long, so if NO rank counts an all-zero word the hop is plain (nz_mask = NULL below) and the
- * ranks all-gather 8 bytes each instead of N/8 in total.  Otherwise fall back to sla_hip_shard_scan + the mask. */
+ * ranks all-gather 12 bytes each (OR word as two int32 halves + the count) instead of N/8 in total.  Otherwise fall back to sla_hip_shard_scan + the mask. */
 int sla_hip_shard_scan_counts(struct SLAEncoder* encoder, const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_samples,
                               uint32_t* or_word, uint32_t* zero_mask_words);
 int sla_hip_shard_bounds(uint32_t num_samples, uint32_t max_num_block_samples, const uint64_t* nz_mask /* NULL: no silence */,
@@ -496,6 +503,8 @@ int sla_hip_get_trace(struct SLAEncoder* encoder, sla_hip_trace* trace);
  * (log2 of the tile-sum energy limit, 1..53) [SLA_HIP_EXACT_BITS], "cert_safety" (safety factor of the certificate for
  * windows over that limit, default 64; 0: no certificate, such windows are rerun as serial chains) [SLA_HIP_CERT],
  * "device_plan" (0: partitions decided on the host) [SLA_HIP_PLAN=host],
+ * "block_cert" (0: every chosen block through the exact chain kernel; 1 = default: the certified route of
+ * sla_hip_launch_lpc_blocks_cert) [SLA_HIP_BLOCK_CERT], "block_cert_safety" (default 16),
  * "plan_margin" [SLA_HIP_PLAN_MARGIN], "lpc_blocks_chains" [SLA_HIP_LPC_BLOCKS=chains], "fuse_lattice"
  * [SLA_HIP_LATTICE=fused], "device_ltm" (0: long-term pitch + taps solved on the host threads from the downloaded
  * autocorrelations, one k_tail per pipeline chunk) [SLA_HIP_LTM=host], "single_tail" (0: one k_tail per pipeline chunk

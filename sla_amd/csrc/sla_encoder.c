@@ -885,7 +885,10 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
   RCCHK(dev_reserve(&e->d_nz, (size_t)(nwords + 2) * 8));
   RCCHK(pin_reserve(&e->h_nz, (size_t)(nwords + 2) * 8));
   HIPCHK(hipEventRecord(e->ev[0], e->stream));
-  if (e->skip_prepass && e->file_or_word != 0) {
+  /* (one exception keeps the prepass: a last super-frame of fewer than 127 samples can be all zero -- and then is a SILENT
+   * block, its minimum length being what is left of the file, src/SLAEncoder.c:401-407 -- without containing an aligned
+   * all-zero 64-sample word for the count to see; without silence the super-frames sit on multiples of the block size) */
+  if (e->skip_prepass && e->file_or_word != 0 && (n % maxb == 0 || n % maxb >= 127)) {
     /* sla_hip_shard_analyze_no_silence: the caller's scan of the whole file counted no all-zero mask word, and it knows
      * the file's OR word -- nothing the prepass could add: no super-frame of this range can be silent */
     HIPCHK(hipEventRecord(e->ev[1], e->stream));
@@ -2245,14 +2248,17 @@ static int pack_device_core(struct SLAEncoder* e, pack_seg_t* segs, uint32_t nse
   tp1 = now_ms();
   /* code lengths on the device */
   if (njobs > 0) {
-    RCCHK(dev_reserve(&e->d_kk, sizeof(uint16_t) * (size_t)C * e->stride));
-    RCCHK(dev_reserve(&e->d_pk_jobs, sizeof(sla_hip_rice_job) * njobs));
-    RCCHK(dev_reserve(&e->d_fold, sizeof(uint64_t) * njobs));
-    HIPCHK(hipMemcpyAsync(e->d_pk_jobs.ptr, jobs, sizeof(sla_hip_rice_job) * njobs, hipMemcpyHostToDevice, e->stream));
-    rc = sla_hip_launch_rice_len(RES2(e), e->stride, (const sla_hip_rice_job*)e->d_pk_jobs.ptr, njobs,
-                                 (uint16_t*)e->d_kk.ptr, (uint64_t*)e->d_fold.ptr, e->stream);
-    if (rc != 0) { free(job_of); return rc; }
-    HIPCHK(hipMemcpyAsync(e->h_fold.ptr, e->d_fold.ptr, sizeof(uint64_t) * njobs, hipMemcpyDeviceToHost, e->stream));
+    /* (every exit of this function releases job_of) */
+    if ((rc = dev_reserve(&e->d_kk, sizeof(uint16_t) * (size_t)C * e->stride)) != 0
+        || (rc = dev_reserve(&e->d_pk_jobs, sizeof(sla_hip_rice_job) * njobs)) != 0
+        || (rc = dev_reserve(&e->d_fold, sizeof(uint64_t) * njobs)) != 0
+        || (rc = hiprc(hipMemcpyAsync(e->d_pk_jobs.ptr, jobs, sizeof(sla_hip_rice_job) * njobs, hipMemcpyHostToDevice, e->stream))) != 0
+        || (rc = sla_hip_launch_rice_len(RES2(e), e->stride, (const sla_hip_rice_job*)e->d_pk_jobs.ptr, njobs,
+                                         (uint16_t*)e->d_kk.ptr, (uint64_t*)e->d_fold.ptr, e->stream)) != 0
+        || (rc = hiprc(hipMemcpyAsync(e->h_fold.ptr, e->d_fold.ptr, sizeof(uint64_t) * njobs, hipMemcpyDeviceToHost, e->stream))) != 0) {
+      free(job_of);
+      return rc;
+    }
   }
   {
     /* the header bytes, while the device walks the Rice parameters */
@@ -2261,7 +2267,7 @@ static int pack_device_core(struct SLAEncoder* e, pack_seg_t* segs, uint32_t nse
     parallel_for(e->pool, nb, pack_hdr_one, &hc);
     if (hc.bad) { free(job_of); (void)hipStreamSynchronize(e->stream); return SLA_APIRESULT_NG; }
   }
-  if (njobs > 0) { HIPCHK(hipStreamSynchronize(e->stream)); }
+  if (njobs > 0 && (rc = hiprc(hipStreamSynchronize(e->stream))) != 0) { free(job_of); return rc; }
 
   tp2 = now_ms();
   /* block sizes -> offsets; a file = 43 header bytes + its blocks */

@@ -45,6 +45,15 @@ def scan_piece(num_samples, world, rank):
     return cut(rank), cut(rank + 1)
 
 
+def upload_range(num_samples, world, rank, max_num_block_samples):
+    """[lo, top) of the file rank `rank` needs in device memory: its scan piece plus everything its own range can reach.
+    sla_hip_shard_bounds puts bounds[rank+1] at the first super-frame start at or behind the UNFLOORED target
+    ceil(N*(rank+1)/world), i.e. below target + max block; the scan piece ends at that target floored to PIECE_ALIGN,
+    so the range ends below piece end + PIECE_ALIGN - 1 + max block (include/sla_hip.h, step 1)."""
+    lo, hi = scan_piece(num_samples, world, rank)
+    return lo, min(num_samples, hi + PIECE_ALIGN - 1 + max_num_block_samples)
+
+
 def all_gather_planes(planes, out=None, async_op=False):
     """planes: int32 tensor [C, stride] holding this rank's residual planes.  Returns [world, C, stride]
     with every rank's planes (one collective; RCCL ring over xGMI when the backend is nccl).
@@ -62,6 +71,12 @@ def all_gather_planes(planes, out=None, async_op=False):
 def max_over_ranks(seconds, device):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device):
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
 
@@ -162,8 +177,8 @@ def encode_sharded_serial(backends, num_samples, max_num_block_samples):
 
 class HipShardBackend:
     """the product's backend: this rank's GPU through libsla_hip.so.  `pcm` = the file as planar left-justified int32
-    [C][N] in host memory (what SLAEncoder_EncodeWhole takes); only the rank's piece -- its scan range plus one
-    maximum block behind it, which always contains the range it ends up owning -- crosses PCIe, once."""
+    [C][N] in host memory (what SLAEncoder_EncodeWhole takes); only the rank's piece -- its scan range plus what
+    `upload_range` adds behind it, which always contains the range it ends up owning -- crosses PCIe, once."""
 
     def __init__(self, encoder, pcm, max_num_block_samples):
         self.enc, self.pcm, self.maxb = encoder, pcm, max_num_block_samples
@@ -173,8 +188,9 @@ class HipShardBackend:
         if self.dev is not None and self.base == lo:
             return
         n = self.pcm.shape[1]
-        top = min(n, hi + self.maxb)
+        top = min(n, hi + PIECE_ALIGN - 1 + self.maxb)      # = upload_range(): the scan piece ends at the floored target
         self.base = lo
+        self.top = top
         span = max(top - lo, 1)
         self.stride = (span + 63) // 64 * 64
         self.dev = torch.zeros((self.pcm.shape[0], self.stride), dtype=torch.int32, device="cuda")
@@ -194,6 +210,7 @@ class HipShardBackend:
         if hi <= lo:
             return b""                       # more ranks than super-frames: nothing to encode here
         off = lo - self.base
-        assert off >= 0 and hi - self.base <= self.stride
+        if off < 0 or hi > self.top:
+            raise ValueError("range [%d, %d) is not inside the uploaded piece [%d, %d)" % (lo, hi, self.base, self.top))
         self.enc.shard_analyze(self.dev.data_ptr() + 4 * off, self.stride, hi - lo, file_or, no_silence=no_silence)
         return self.enc.pack(8 * self.pcm.shape[0] * (hi - lo) + 65536, on_device=True)

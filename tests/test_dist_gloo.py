@@ -211,3 +211,47 @@ def test_shard_bounds_without_a_mask_when_nothing_is_silent():
         mask = np.packbits(bits.reshape(-1, 64), axis=1, bitorder="little").view(np.uint64).ravel()
         for world in (1, 2, 3, 8):
             assert sla_amd.shard_bounds(n, maxb, None, world) == sla_amd.shard_bounds(n, maxb, mask, world)
+
+
+def test_upload_range_contains_every_rank_range():
+    """the piece a rank uploads must contain the range sla_hip_shard_bounds later gives it, also when the
+    block size is not a multiple of 1024 (bounds[r+1] sits up to one block behind the UNFLOORED target) and when a
+    silence run has moved the super-frame starts off the block grid"""
+    import sla_amd
+    rng = np.random.default_rng(5)
+    cases = [(12002, 2, 3000), (250001, 5, 5000), (100000, 3, 2048), (1 << 20, 8, 4096), (77777, 7, 16384), (9000, 8, 4096)]
+    cases += [(int(rng.integers(2048, 400000)), int(rng.integers(1, 9)), int(rng.integers(2048, 16385))) for _ in range(200)]
+    for n, world, maxb in cases:
+        for with_silence in (False, True):
+            mask = None
+            if with_silence:
+                bits = np.ones(n + 64, bool)
+                a = int(rng.integers(0, max(n - 3000, 1)))
+                bits[a:a + int(rng.integers(2048, 3000))] = False      # one silence run of at least a minimum block
+                mask = np.packbits(bits[:(n + 63) // 64 * 64].reshape(-1, 64)[:, ::-1], axis=1).view(">u8").astype(np.uint64).ravel()
+            bounds = sla_amd.shard_bounds(n, maxb, mask, world)
+            assert bounds[0] == 0 and bounds[-1] == n
+            for r in range(world):
+                lo, top = sdist.upload_range(n, world, r, maxb)
+                assert lo <= bounds[r] and bounds[r + 1] <= top, (n, world, maxb, r, bounds, lo, top)
+                assert sdist.scan_piece(n, world, r)[0] == lo
+
+
+@pytest.mark.timeout(300)
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without WORLD_SIZE starts the two ranks itself (torch.distributed.run as a child
+    process) and relays rank 0's line; a rank whose WORLD_SIZE differs from --gpus exits non-zero"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--launch-check",
+                        "--scaling", "strong"], capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "strong"
+    env["WORLD_SIZE"], env["RANK"] = "1", "0"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

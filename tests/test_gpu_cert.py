@@ -88,7 +88,7 @@ CASES = [
     ("sine", 1, 16, 16, 4096, 0), ("nyquist", 1, 16, 16, 4096, 0), ("posconst", 2, 24, 12, 4096, 0),
     ("tones-20", 1, 24, 32, 4096, 0), ("tones-60", 2, 24, 48, 8192, 0), ("tones-100", 1, 24, 32, 4096, 0),
     ("tones-140", 1, 32, 48, 8192, 0), ("tones-60", 1, 32, 16, 2048, 0), ("silence", 2, 16, 16, 4096, 0),
-    ("bench", 1, 8, 4, 2048, 0), ("music", 1, 16, 52, 8192, 0),
+    ("bench", 1, 8, 4, 2048, 0), ("music", 1, 16, 51, 8192, 0),
 ]
 
 

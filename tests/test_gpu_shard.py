@@ -116,3 +116,30 @@ def test_scan_counts_decide_whether_the_mask_is_needed(oracle, hip):
             finally:
                 for e in encs:
                     e.close()
+
+
+@pytest.mark.parametrize("maxb,n,world", [(3000, 12002, 2), (5000, 250001, 5), (2048 + 64, 40000, 3), (4096, 30000, 3)])
+def test_block_sizes_off_the_1024_grid_and_dealigned_hops(oracle, hip, maxb, n, world):
+    """bounds[r+1] may sit up to one block behind the unfloored target -- 1022 samples past what the ranks
+    used to upload when the block size is not a multiple of 1024, or when a silence run moves the super-frame starts
+    off the grid; the third file ends in a short all-zero tail (a SILENT block the no-silence shortcut must not miss)"""
+    from sla_amd import dist as sdist
+    p = S.make_params(1, 16, 48000, 8, 1, 8, 0, 1, maxb, cap=(1, 16384, 16, 1, 8))
+    files = [S.synth_pcm(1, n, 16, 48000, seed=world)]
+    quiet = S.synth_pcm(1, n, 16, 48000, seed=world + 1)
+    quiet[:, 5000:5000 + 2500] = 0                       # a silence run of 2500 samples: every later super-frame start moves
+    files.append(quiet)
+    tail = S.synth_pcm(1, n - n % maxb + 60, 16, 48000, seed=world + 2)
+    tail[:, -60:] = 0                                   # last super-frame: 60 zero samples = a SILENT block without any all-zero mask word
+    files.append(tail)
+    for pcm in files:
+        ret, want = oracle.encode_whole(p, pcm)
+        assert ret == 0
+        encs = [_encoder(hip, p) for _ in range(world)]
+        try:
+            backs = [sdist.HipShardBackend(e, pcm, maxb) for e in encs]
+            got, bounds = sdist.encode_sharded_serial(backs, pcm.shape[1], maxb)
+            assert got == want, (maxb, n, world, bounds)
+        finally:
+            for e in encs:
+                e.close()
