@@ -59,6 +59,8 @@ WORKLOAD_NAME = {
     "C5": "96 kHz 24-bit 8-channel, 30 min, order-48 LPC, 8192-sample frames",
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VECTOR_PEAK_TFLOPS = 78.6 # MI355X FP64 vector (no dense contraction on this path: not the matrix figure); SURVEY 8(d), H8
+PCIE_PEAK_GBS = 63.0           # MI355X_MICROARCH.md: host link PCIe Gen5 x16 (spec)
 ALGO_BYTES_PER_SAMPLE = 8      # 4 B int32 PCM read + 4 B int32 final residual written
 LCG_A, LCG_C = 1664525, 1013904223
 
@@ -384,8 +386,12 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
     #      kernels run on) ----------------------------------------------------------------------------------
     nchunks = max(int(round(kernel_ms[9])), 1)
     exact_search = kernel_ms[11] > 0.5      # partition search ran on tile sums
-    ev = {"k_lpc_blocks": kernel_ms[2], "k_lattice": kernel_ms[3], "k_ltm_acf": kernel_ms[8], "k_tail": kernel_ms[4]}
-    dev = dict(zip(("k_lpc_blocks", "k_lattice", "k_ltm_acf", "k_tail"), span_ms))
+    cert_on, blocks_exact = enc.last_block_cert()
+    # the block stage: k_acf_blocks + k_blocks_finish (+ the exact chain kernels for what did not certify), or
+    # k_lpc_blocks + k_blocks_finish with option block_cert = 0
+    blk = "k_acf_blocks" if cert_on else "k_lpc_blocks"
+    ev = {blk: kernel_ms[2], "k_lattice": kernel_ms[3], "k_ltm_acf": kernel_ms[8], "k_tail": kernel_ms[4]}
+    dev = dict(zip((blk, "k_lattice", "k_ltm_acf", "k_tail"), span_ms))
     kernels = {"k_prepass": (kernel_ms[0], 1)}
     tail_launches = max(int(enc.last_counters()[4]), 1)         # one k_tail for the whole file unless the handle was told otherwise
     for name in ev:
@@ -397,8 +403,33 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
     launch_ms = t_step / launches
     algo_bytes = float(n_last) * nch * ALGO_BYTES_PER_SAMPLE / launches      # per launch: 8 B x the samples x channels it covers
     achieved = algo_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    # ---- secondary bounds: FP64 vector rate of what the kernels EXECUTE ----------------
+    # per sample x channel: tile-sum search 2 x lags flop (one FMA per lag; lags = order + 1 rounded up to a multiple of 4:
+    # 12/20/36/52); block stage the same on the windowed samples + 8 flop of staging (exact chain kernel: 1.5 x order + 2);
+    # long-term autocorrelation: two radix-2 transforms of npts = capacity complex points, 10 flop per butterfly,
+    # + 2 x 14 flop per point of recombination and power spectrum, per block of max_block samples; lattice, LMS tail,
+    # prepass and the Rice stages are integer kernels (no FP64)
+    lags = float(sla_amd.lib().sla_hip_search_exact_lags(order)) or float(order + 1)
+    npts_fft = 1
+    while npts_fft < cap[1]:
+        npts_fft <<= 1
+    lg = npts_fft.bit_length() - 1
+    flop_per_sc = {blk: (2.0 * lags + 8.0) if cert_on else (1.5 * order + 2.0),
+                   search_name: (2.0 * lags if exact_search else 1.5 * order * (4 if maxb <= 4096 else 14)),
+                   "k_ltm_acf": (2.0 * 10.0 * (npts_fft / 2) * lg + 28.0 * npts_fft) / float(maxb)}
+    sc_step = float(n_last) * nch
+    path_flop = sum(flop_per_sc.values()) * sc_step
     out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2),
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                       "path_frac": round(sc_step * ALGO_BYTES_PER_SAMPLE / (elapsed / max(args.steps, 1)) / 1e9 / HBM_PEAK_GBS, 5),
+                       "fp64_vector_frac": (round(flop_per_sc[dom] * sc_step / launches / (launch_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 5)
+                                            if dom in flop_per_sc and launch_ms > 0 else None),
+                       "path_fp64_vector_frac": round(path_flop / (elapsed / max(args.steps, 1)) / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 5),
+                       "fp64_flop_per_sample_channel": {k: round(v, 1) for k, v in flop_per_sc.items()},
+                       "fp64_peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                       "secondary_note": "path_frac = 8 B x samples x channels of one step / ms_per_step / 8 TB/s; fp64_vector_frac = executed FP64 "
+                                         "flop of the dominant kernel (model in fp64_flop_per_sample_channel; None for an integer kernel) / its "
+                                         "launch time / 78.6 TFLOP/s; path_fp64_vector_frac = the FP64 flop of all stages / ms_per_step / 78.6 TFLOP/s",
                        "traffic": None, "kernel_ms": round(float(launch_ms), 4), "launches_per_step": launches,
                        "algorithmic_bytes_per_launch": algo_bytes,
                        "kernel_ms_running": round(float(dev[dom] / launches), 4) if dom in dev and dev[dom] > 0 else None,
@@ -407,19 +438,30 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
                                "profiles/r2_kernel_stats_*.csv; both include the time a launch shares the SIMDs with, or waits "
                                "behind, the next chunk's kernels on the other streams); kernel_ms_running = first workgroup in to "
                                "last workgroup out on the device's 100 MHz clock, i.e. without that wait"}
-    try:       # HBM traffic per launch of that kernel from the committed rocprofv3 --pmc passes (same config only)
+    try:       # HBM traffic per launch of that kernel from the committed rocprofv3 --pmc passes of this configuration
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % cfg.lower())))
-        same_size = (str(pmc.get("seconds", "full")) == "full" and seconds == CONFIGS[cfg][3]) or str(pmc.get("seconds")) == str(int(seconds))
-        if same_size and world == 1 and dom in pmc["bytes_per_launch"]:
-            out["roofline"]["traffic"] = pmc["bytes_per_launch"][dom]["total"]
-            out["roofline"]["traffic_source"] = pmc["source"]
+        pk = dom.split("+")[0]
+        if world == 1 and pk in pmc["bytes_per_launch"]:
+            rec = pmc["bytes_per_launch"][pk]
+            if "bytes_per_sample_channel" in rec:
+                # the counters were collected on a shorter cut of the same workload: every kernel of the path moves a fixed
+                # number of bytes per sample and channel (blocks are independent), so the per-launch figure scales with the
+                # samples x channels a launch covers
+                out["roofline"]["traffic"] = int(round(rec["bytes_per_sample_channel"] * sc_step / launches))
+                out["roofline"]["traffic_source"] = pmc["source"] + "; scaled by samples x channels per launch"
+            else:
+                same_size = (str(pmc.get("seconds", "full")) == "full" and seconds == CONFIGS[cfg][3]) or str(pmc.get("seconds")) == str(int(seconds))
+                if same_size:
+                    out["roofline"]["traffic"] = rec["total"]
+                    out["roofline"]["traffic_source"] = pmc["source"]
     except (OSError, KeyError, ValueError):
         pass
+    out["block_certificate"] = {"on": bool(cert_on), "pairs_redone_by_exact_kernels": int(blocks_exact)}
     out["kernel_ms_on_device"] = {k: round(float(v), 4) for k, v in dev.items()}
     out["stage_ms"] = {"k_prepass": round(float(kernel_ms[0]), 4),
                        ("search_tile_sums" if exact_search else "k_lpc_search"): round(float(kernel_ms[1]), 4),
                        "search_groups_rerun_as_chains": round(float(kernel_ms[10]), 2),
-                       "k_lpc_blocks": round(float(kernel_ms[2]), 4), "k_lattice": round(float(kernel_ms[3]), 4),
+                       "block_stage(" + blk + "+k_blocks_finish)": round(float(kernel_ms[2]), 4), "k_lattice": round(float(kernel_ms[3]), 4),
                        "k_tail": round(float(kernel_ms[4]), 4), "k_ltm_acf": round(float(kernel_ms[8]), 4), "host_plan": round(float(kernel_ms[5]), 4),
                        "host_longterm": round(float(kernel_ms[6]), 4), "analyze_total": round(float(kernel_ms[7]), 4)}
 
@@ -479,6 +521,27 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
                        and np.array_equal(tr.blk_nsmpl[:nblk], to.blk_nsmpl[:nblk]))
         ver.update({"blocks_compared": int(nblk), "fields": "bytes of the first blocks (headers, Rice bodies, CRC16)"
                     + (", PARCOR (bit patterns where the exact kernel ran, a quarter quantisation step where certified), codes, Rice parameters" if to is not None else "")})
+        # two more windows, in the middle and at the end of the rank's range, against the oracle's encode of the same samples
+        # (a range that starts on a super-frame start reproduces the file's own blocks: include/sla_hip.h, one file, several GPUs)
+        if m < own_n and tr.num_blocks > 3:
+            lsh = tr.offset_lshift
+            starts = tr.blk_start[:tr.num_blocks].astype(np.int64)
+            byte_off = 43 + np.concatenate([[0], np.cumsum(tr.blk_bytes[:tr.num_blocks].astype(np.int64))])
+            sf = np.nonzero((starts - starts[0]) % maxb == 0)[0]                  # blocks that open a super-frame (no silence in this signal)
+            extra = 0
+            for b0 in (int(sf[len(sf) // 2]), int(sf[max(len(sf) - frames, 0)])):
+                s0 = int(starts[b0]) - int(starts[0])
+                mm = min(frames * maxb, own_n - s0)
+                subw = np.ascontiguousarray(d_pcm[:, own_lo - base + s0:own_lo - base + s0 + mm].cpu().numpy())
+                retw, wantw = o.encode_range(p, subw, lsh)
+                b1, pos = b0, 0
+                to_end = (s0 + mm == own_n)
+                while b1 < tr.num_blocks and (to_end or pos + int(tr.blk_nsmpl[b1]) <= mm - maxb):
+                    pos += int(tr.blk_nsmpl[b1]); b1 += 1
+                seg = image[int(byte_off[b0]):int(byte_off[b1])]
+                ok &= bool(retw == 0 and b1 > b0 and seg == wantw[43:43 + len(seg)] and (not to_end or len(wantw) == 43 + len(seg)))
+                extra += b1 - b0
+            ver["blocks_compared_mid_and_end"] = int(extra)
         # ... and the whole image decodes back to the PCM this rank analysed (size-independent property at full size)
         if lms in (4, 8, 16, 32) and maxb <= 16384:
             dec = sla_amd.Decoder(nch, maxb, order, ltm, lms)
@@ -499,20 +562,24 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
         raise SystemExit(3)
 
     # ---- end-to-end .sla encode from host PCM (PCIe + bit-pack included); never `value` -------------------------
-    if primary and not args.no_e2e and world == 1 and batch is not None:
+    if not args.no_e2e and world == 1 and batch is not None:
         enc2 = sla_amd.Encoder(*cap)
         enc2.set_wave_format(nch, bits, rate)
         enc2.set_encode_parameter(order, ltm, lms, ms, win, maxb)
         outs = [np.zeros(4 * nch * int(l) + 65536, np.uint8) for l in batch["lens"]]
         got = enc2.encode_batch(batch["clips"], outs=outs)
-        reps = 3
+        reps = 3 if primary else 2
         t1 = time.perf_counter()
         for _ in range(reps):
             got = enc2.encode_batch(batch["clips"], outs=outs)
         e2e = (time.perf_counter() - t1) / reps
+        sla_bytes = int(sum(len(d) for _, d in got))
+        h2d = n_own * nch * (2 if bits <= 16 else 4)          # pageable PCM of <= 16 significant bits is staged as int16
         out["end_to_end"] = {"msamples_s": round(n_own * nch / e2e / 1e6, 3), "samples": n_own * nch,
-                             "sla_bytes": int(sum(len(d) for _, d in got)), "files_ok": int(sum(1 for rc, _ in got if rc == 0)),
-                             "note": "sla_hip_encode_batch: pageable host PCM of every clip -> its own .sla bytes incl. PCIe both ways"}
+                             "sla_bytes": sla_bytes, "files_ok": int(sum(1 for rc, _ in got if rc == 0)),
+                             "pcie_bytes": h2d + sla_bytes, "pcie_frac": round((h2d + sla_bytes) / e2e / 1e9 / PCIE_PEAK_GBS, 4),
+                             "note": "sla_hip_encode_batch: pageable host PCM of every clip -> its own .sla bytes incl. PCIe both ways; "
+                                     "pcie_frac = bytes that cross the bus (PCM up, .sla down) / call time / 63 GB/s"}
         # the drop-in call, clip by clip (what the reference CLI does per file)
         one = batch["clips"][0]
         buf = np.zeros(4 * nch * one.shape[1] + 65536, np.uint8)
@@ -550,14 +617,17 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
         same = bool(len(plain) == size and np.array_equal(plain, data))
         del plain
         enc2.set_option("stream", 1)
+        h2d = n_file * nch * (2 if bits <= 16 else 4)         # pageable PCM of <= 16 significant bits is staged as int16
         out["end_to_end"] = {"msamples_s": round(n_file * nch / e2e / 1e6, 3), "samples": n_file * nch,
                              "plain_path_msamples_s": round(n_file * nch / e2e_plain / 1e6, 3), "streamed_equals_plain": same,
-                             "sla_bytes": size, "note": "SLAEncoder_EncodeWhole: pageable host PCM -> .sla bytes incl. PCIe both ways and the device bit-pack"}
+                             "sla_bytes": size, "pcie_bytes": h2d + size,
+                             "pcie_frac": round((h2d + size) / e2e / 1e9 / PCIE_PEAK_GBS, 4), "note": "SLAEncoder_EncodeWhole: pageable host PCM -> .sla bytes incl. PCIe both ways and the device bit-pack"}
         # the same call on page-locked caller memory (hipHostMalloc / hipHostRegister, here torch pinned tensors): DMA without the staging copy
         pin_in = torch.from_numpy(host_pcm).pin_memory()
         pin_out = torch.zeros(size + 65536, dtype=torch.uint8).pin_memory()
         data_p, e2p = timed(pin_in.numpy(), pin_out.numpy())
         out["end_to_end"]["pinned_msamples_s"] = round(n_file * nch / e2p / 1e6, 3)
+        out["end_to_end"]["pinned_pcie_frac"] = round((n_file * nch * 4 + size) / e2p / 1e9 / PCIE_PEAK_GBS, 4)      # page-locked planes cross as they are: 4 B per sample
         out["end_to_end"]["pinned_identical"] = bool(len(data_p) == size and np.array_equal(data_p, data))
         enc2.set_option("stream", 0)
         _, e2p_plain = timed(pin_in.numpy(), pin_out.numpy())

@@ -136,6 +136,8 @@ typedef struct sla_hip_tuning {
   uint32_t lpc_tile;            /* steps per tile of k_lpc_blocks' wide packs: 24, or 0 / 48 = 48 where it fits         */
   uint32_t tail_lanes;          /* lanes per tail job in units of the LMS order: 1 = one (k_tail2, two taps per lane), 2 = two (k_tail, one tap per lane), 0 = by the number of jobs */
   double   plan_margin;         /* certification margin of k_plan, 0 = 1e-4 (tests raise it to force the host plan)  */
+  uint32_t acf_classic;         /* 1: long-term autocorrelation through k_ltm_acf (one LDS pass per step) instead of k_ltm_acf2 */
+  uint32_t pad_;
 } sla_hip_tuning;
 void sla_hip_use_tuning(const sla_hip_tuning* tuning);
 

@@ -2229,6 +2229,43 @@ __device__ __forceinline__ void acf_pick(const double* v, const unsigned long lo
   }
 }
 
+// what a job leaves behind: the compact record {code, chosen lag, acf[0..4], acf[chosen-2..chosen+2]} (the Toeplitz
+// solve follows in k_ltm_solve), or the first `head` autocorrelation values
+template <int THREADS>
+__device__ __forceinline__ void acf_emit(const double2* z, uint32_t job, double* __restrict__ out, uint32_t head,
+                                         double* s_acf, unsigned long long (*s_mask)[ACF_PICK_LAGS / 64])
+{
+  if (head == SLA_HIP_ACF_RECORD) {
+    // compact record: {code, chosen lag, acf[0..4], acf[chosen-2..chosen+2]}; the Toeplitz solve (x87
+    // long double in the reference) is left to the host
+    __syncthreads();
+    if (threadIdx.x < ACF_PICK_LAGS) {
+      const uint32_t j = threadIdx.x;
+      const double vc = acf_at(z, j), vm = (j >= 1) ? acf_at(z, j - 1) : 0.0, vp = acf_at(z, j + 1);
+      s_acf[j] = vc;
+      const unsigned long long bu = __ballot(j >= 1 && j < 256 && vm < 0.0 && vc > 0.0);
+      const unsigned long long bd = __ballot(j >= 1 && j < 256 && vc > 0.0 && vp < 0.0);
+      const unsigned long long bl = __ballot(j >= 1 && j <= 257 && vc > vm && vc > vp && vc > 0.0);
+      if ((j & 63) == 0) { s_mask[0][j >> 6] = bu; s_mask[1][j >> 6] = bd; s_mask[2][j >> 6] = bl; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double* o = out + (uint64_t)job * SLA_HIP_ACF_RECORD;
+      uint32_t chosen = 0, ncand = 0;
+      double code = 0.0;                                   // 0: silent block
+      if (fabs(s_acf[0]) > (double)FLT_MIN) {
+        acf_pick(s_acf, s_mask[0], s_mask[1], s_mask[2], chosen, ncand);
+        code = (ncand == 0) ? 2.0 : 1.0;                   // 2: no pitch candidate
+      }
+      o[0] = code; o[1] = (double)chosen;
+      for (uint32_t k = 0; k < 5; k++) { o[2 + k] = s_acf[k]; }
+      for (uint32_t k = 0; k < 5; k++) { o[7 + k] = (chosen + k >= 2) ? s_acf[chosen + k - 2] : 0.0; }
+    }
+  } else {
+    for (uint32_t t = threadIdx.x; t < head; t += THREADS) { out[(uint64_t)job * head + t] = acf_at(z, t); }
+  }
+}
+
 template <bool IN_LDS>
 __global__ __launch_bounds__(ACF_THREADS)
 void k_ltm_acf(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_acf_job* __restrict__ jobs,
@@ -2288,35 +2325,191 @@ void k_ltm_acf(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_a
     }
     __syncthreads();
     acf_stages(z, log2npts, twr_i, twi_i);
-    if (head == SLA_HIP_ACF_RECORD) {
-      // compact record: {code, chosen lag, acf[0..4], acf[chosen-2..chosen+2]}; the Toeplitz solve (x87
-      // long double in the reference) is left to the host
-      __syncthreads();
-      if (threadIdx.x < ACF_PICK_LAGS) {
-        const uint32_t j = threadIdx.x;
-        const double vc = acf_at(z, j), vm = (j >= 1) ? acf_at(z, j - 1) : 0.0, vp = acf_at(z, j + 1);
-        s_acf[j] = vc;
-        const unsigned long long bu = __ballot(j >= 1 && j < 256 && vm < 0.0 && vc > 0.0);
-        const unsigned long long bd = __ballot(j >= 1 && j < 256 && vc > 0.0 && vp < 0.0);
-        const unsigned long long bl = __ballot(j >= 1 && j <= 257 && vc > vm && vc > vp && vc > 0.0);
-        if ((j & 63) == 0) { s_mask[0][j >> 6] = bu; s_mask[1][j >> 6] = bd; s_mask[2][j >> 6] = bl; }
+    acf_emit<ACF_THREADS>(z, job, out, head, s_acf, s_mask);
+    __syncthreads();
+  }
+  span_end(span);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_ltm_acf2: the same transform pair with fewer trips through the LDS (every butterfly is still the reference's
+// radix-2 one on the same operands: bit for bit the results of k_ltm_acf).  Per job and 2^L complex points:
+//   * the first three forward stages take their operands straight from the residual plane: the point at bit-reversed
+//     position 8b + m is sample pair t + rev3(m) * 2^(L-3) when b = rev(t), so consecutive lanes read consecutive
+//     samples, the zero padding costs no loads, and the scatter pass of k_ltm_acf is gone;
+//   * forward recombination, power spectrum, inverse recombination and the inverse transform's bit reversal are ONE
+//     pass: every step keeps the pair (i, N - i) to itself, so a thread carries its pairs through all of them in
+//     registers, a barrier separates all reads from all (bit-reversed) writes -- four passes of k_ltm_acf;
+//   * the record only needs autocorrelation lags 0 .. 259 (pitch <= 257, five taps): the last inverse passes only
+//     compute the groups, and store the points, those lags depend on (`need` complex slots).
+// LDS round trips per job at L = 13: 4 + 1 + ~3.9 instead of 15.
+// ---------------------------------------------------------------------------------------------
+typedef int32_t i32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+
+template <int R, int THREADS>
+__device__ __forceinline__ void acf2_first_pass(double2* z, const int32_t* __restrict__ src, uint32_t n, uint32_t L,
+                                                const double* __restrict__ twr, const double* __restrict__ twi)
+{
+  constexpr uint32_t P = 1u << R;
+  const uint32_t ngroups = 1u << (L - R);
+  const double scale = 4.656612873077392578125e-10;   // 2^-31
+  for (uint32_t t = threadIdx.x; t < ngroups; t += THREADS) {
+    const uint32_t b = __brev(t) >> (32 - (L - R));
+    double2 v[P];
+#pragma unroll
+    for (uint32_t m = 0; m < P; m++) {
+      const uint32_t c = t + (__brev(m) >> (32 - R)) * ngroups;          // complex sample index of position P*b + m
+      if (2 * c + 1 < n) {
+        const i32x2_u w = *(const i32x2_u*)(src + 2 * c);
+        v[m] = make_double2((double)w.x * scale, (double)w.y * scale);
+      } else {
+        v[m] = make_double2((2 * c < n) ? (double)src[2 * c] * scale : 0.0, 0.0);
       }
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        double* o = out + (uint64_t)job * SLA_HIP_ACF_RECORD;
-        uint32_t chosen = 0, ncand = 0;
-        double code = 0.0;                                   // 0: silent block
-        if (fabs(s_acf[0]) > (double)FLT_MIN) {
-          acf_pick(s_acf, s_mask[0], s_mask[1], s_mask[2], chosen, ncand);
-          code = (ncand == 0) ? 2.0 : 1.0;                   // 2: no pitch candidate
-        }
-        o[0] = code; o[1] = (double)chosen;
-        for (uint32_t k = 0; k < 5; k++) { o[2 + k] = s_acf[k]; }
-        for (uint32_t k = 0; k < 5; k++) { o[7 + k] = (chosen + k >= 2) ? s_acf[chosen + k - 2] : 0.0; }
-      }
-    } else {
-      for (uint32_t t = threadIdx.x; t < head; t += ACF_THREADS) { out[(uint64_t)job * head + t] = acf_at(z, t); }
     }
+#pragma unroll
+    for (int st = 0; st < R; st++) {
+      const uint32_t hs = 1u << st;
+#pragma unroll
+      for (uint32_t m = 0; m < P; m++) {
+        if ((m >> st) & 1u) { continue; }
+        const uint32_t k = m & ((1u << st) - 1u);
+        acf_bfly(v[m], v[m + (1u << st)], twr[hs - 1 + k], twi[hs - 1 + k]);
+      }
+    }
+#pragma unroll
+    for (uint32_t m = 0; m < P; m++) { z[acf_sw(P * b + m)] = v[m]; }
+  }
+  __syncthreads();
+}
+
+// acf_pass with pruning: after this pass the remaining stages only combine points whose positions agree modulo
+// H = h << R, so the slots [0, need) of the final result depend on the positions p with (p mod H) < need alone.
+template <int R, int THREADS>
+__device__ __forceinline__ void acf2_pass(double2* z, uint32_t npts, uint32_t log2h, const double* __restrict__ twr,
+                                          const double* __restrict__ twi, uint32_t need)
+{
+  constexpr uint32_t P = 1u << R;
+  const uint32_t h = 1u << log2h;
+  const bool prune = ((h << R) > need);
+  for (uint32_t b = threadIdx.x; b < (npts >> R); b += THREADS) {
+    const uint32_t low = b & (h - 1), ci = low + ((b >> log2h) << (log2h + R));
+    if (prune && low >= need) { continue; }
+    double2 v[P];
+#pragma unroll
+    for (uint32_t m = 0; m < P; m++) { v[m] = z[acf_sw(ci + m * h)]; }
+#pragma unroll
+    for (int st = 0; st < R; st++) {
+      const uint32_t hs = h << st;
+#pragma unroll
+      for (uint32_t m = 0; m < P; m++) {
+        if ((m >> st) & 1u) { continue; }
+        const uint32_t k = low + (m & ((1u << st) - 1u)) * h;
+        acf_bfly(v[m], v[m + (1u << st)], twr[hs - 1 + k], twi[hs - 1 + k]);
+      }
+    }
+#pragma unroll
+    for (uint32_t m = 0; m < P; m++) { if (!prune || low + m * h < need) { z[acf_sw(ci + m * h)] = v[m]; } }
+  }
+  __syncthreads();
+}
+
+template <int THREADS>
+__device__ __forceinline__ void acf2_stages(double2* z, uint32_t log2npts, uint32_t log2h, const double* __restrict__ twr,
+                                            const double* __restrict__ twi, uint32_t need)
+{
+  const uint32_t npts = 1u << log2npts;
+  while (log2h < log2npts) {
+    const uint32_t left = log2npts - log2h;
+    if (left >= 3 && left != 4) { acf2_pass<3, THREADS>(z, npts, log2h, twr, twi, need); log2h += 3; }
+    else if (left >= 2) { acf2_pass<2, THREADS>(z, npts, log2h, twr, twi, need); log2h += 2; }
+    else { acf2_pass<1, THREADS>(z, npts, log2h, twr, twi, need); log2h += 1; }
+  }
+}
+
+// the recombination of the reference's realft (src/SLAUtility.c:262-312) on the pair A = slot i-1, B = slot npts-(i-1):
+// the expressions of acf_real_pass, operation for operation
+__device__ __forceinline__ void acf2_recombine(double2& A, double2& B, double c2, double wr, double wi)
+{
+  const double c1 = 0.5;
+  const double h1r = c1 * (A.x + B.x);
+  const double h1i = c1 * (A.y - B.y);
+  const double h2r = -c2 * (A.y + B.y);
+  const double h2i = c2 * (A.x - B.x);
+  A = make_double2(h1r + wr * h2r - wi * h2i, h1i + wr * h2i + wi * h2r);
+  B = make_double2(h1r - wr * h2r + wi * h2i, -h1i + wr * h2i + wi * h2r);
+}
+
+template <int L, int THREADS>
+__device__ __forceinline__ void acf2_middle(double2* z, const double* __restrict__ rtr_f, const double* __restrict__ rti_f,
+                                            const double* __restrict__ rtr_i, const double* __restrict__ rti_i)
+{
+  constexpr uint32_t npts = 1u << L, pairs = (npts >> 1) - 1, K = (pairs + THREADS - 1) / THREADS;
+  double2 A[K], B[K];
+#pragma unroll
+  for (uint32_t k = 0; k < K; k++) {
+    const uint32_t i = 2 + threadIdx.x + k * THREADS;
+    if (i <= (npts >> 1)) {
+      A[k] = z[acf_sw(i - 1)]; B[k] = z[acf_sw(npts - (i - 1))];
+    }
+  }
+  double2 dc = make_double2(0.0, 0.0), mid = make_double2(0.0, 0.0);
+  if (threadIdx.x == 0) { dc = z[0]; mid = z[acf_sw(npts >> 1)]; }
+#pragma unroll
+  for (uint32_t k = 0; k < K; k++) {
+    const uint32_t i = 2 + threadIdx.x + k * THREADS;
+    if (i <= (npts >> 1)) {
+      acf2_recombine(A[k], B[k], -0.5, rtr_f[i - 2], rti_f[i - 2]);
+      A[k] = make_double2(A[k].x * A[k].x + A[k].y * A[k].y, 0.0);       // power spectrum  src/SLAPredictor.c:844-851
+      B[k] = make_double2(B[k].x * B[k].x + B[k].y * B[k].y, 0.0);
+      acf2_recombine(A[k], B[k], 0.5, rtr_i[i - 2], rti_i[i - 2]);
+    }
+  }
+  if (threadIdx.x == 0) {
+    const double s0 = dc.x + dc.y, s1 = dc.x - dc.y;
+    const double2 pw = make_double2(s0 * s0, s1 * s1);                   // DC and Nyquist power  :839-842
+    dc = make_double2(0.5 * (pw.x + pw.y), 0.5 * (pw.x - pw.y));
+    mid = make_double2(mid.x * mid.x + mid.y * mid.y, 0.0);              // the slot no pair touches
+  }
+  __syncthreads();                                                        // every read above is done: the slots may be overwritten
+#pragma unroll
+  for (uint32_t k = 0; k < K; k++) {
+    const uint32_t i = 2 + threadIdx.x + k * THREADS;
+    if (i <= (npts >> 1)) {
+      z[acf_sw(__brev(i - 1) >> (32 - L))] = A[k];
+      z[acf_sw(__brev(npts - (i - 1)) >> (32 - L))] = B[k];
+    }
+  }
+  if (threadIdx.x == 0) { z[0] = dc; z[acf_sw(1)] = mid; }                // rev(0) = 0, rev(npts/2) = 1
+  __syncthreads();
+}
+
+#define ACF2_THREADS 512
+#define ACF2_NEED 162u        // complex slots that hold lags 0 .. 323: what acf_emit reads for the compact record
+
+template <int L>
+__global__ __launch_bounds__(ACF2_THREADS, (L <= 12) ? 4 : 2)      // 64 KiB of LDS or less: two workgroups per CU
+void k_ltm_acf2(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_acf_job* __restrict__ jobs,
+                uint32_t njobs, const double* __restrict__ tw, double* __restrict__ out, uint32_t head, unsigned long long* span)
+{
+  extern __shared__ double2 lds2[];
+  span_begin(span);
+  __shared__ double s_acf[ACF_PICK_LAGS];
+  __shared__ unsigned long long s_mask[3][ACF_PICK_LAGS / 64];
+  constexpr uint32_t npts = 1u << L, F = npts << 1;
+  double2* z = lds2;
+  const double* twr_f = tw;            const double* twi_f = tw + (F >> 1);
+  const double* twr_i = tw + F;        const double* twi_i = tw + F + (F >> 1);
+  const double* rtr_f = tw + 2 * F;    const double* rti_f = rtr_f + (F >> 2);
+  const double* rtr_i = rti_f + (F >> 2); const double* rti_i = rtr_i + (F >> 2);
+  const uint32_t need = (head == SLA_HIP_ACF_RECORD) ? ACF2_NEED : npts;
+  for (uint32_t job = blockIdx.x; job < njobs; job += gridDim.x) {
+    const sla_hip_acf_job jb = jobs[job];
+    const int32_t* src = res + (uint64_t)jb.channel * stride + jb.blk_off;
+    acf2_first_pass<3, ACF2_THREADS>(z, src, jb.blk_len, L, twr_f, twi_f);
+    acf2_stages<ACF2_THREADS>(z, L, 3, twr_f, twi_f, npts);
+    acf2_middle<L, ACF2_THREADS>(z, rtr_f, rti_f, rtr_i, rti_i);
+    acf2_stages<ACF2_THREADS>(z, L, 0, twr_i, twi_i, need);
+    acf_emit<ACF2_THREADS>(z, job, out, head, s_acf, s_mask);
     __syncthreads();
   }
   span_end(span);
@@ -3075,7 +3268,15 @@ extern "C" int sla_hip_launch_ltm_acf(const int32_t* d_residual, uint64_t plane_
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = sizeof(double) * (size_t)fft_size;
   unsigned long long* span = take_span();
-  if (lds <= SLA_HIP_LDS_BUDGET) {
+  if (lds <= SLA_HIP_LDS_BUDGET && log2F >= 12 && log2F <= 14 && !tuning().acf_classic) {
+    // the capacities the encoder is created with (2048 .. 8192 samples per block): fewer LDS passes, same bits
+    const void* fn = (log2F == 12) ? (const void*)k_ltm_acf2<11> : (log2F == 13) ? (const void*)k_ltm_acf2<12> : (const void*)k_ltm_acf2<13>;
+    hipError_t e = ensure_dynamic_lds(fn, lds);
+    if (e != hipSuccess) { return hip_rc(e); }
+    if (log2F == 12) { hipLaunchKernelGGL(k_ltm_acf2<11>, dim3(num_jobs), dim3(ACF2_THREADS), lds, st, d_residual, plane_stride, d_jobs, num_jobs, d_twiddles, d_acf_head, head, span); }
+    else if (log2F == 13) { hipLaunchKernelGGL(k_ltm_acf2<12>, dim3(num_jobs), dim3(ACF2_THREADS), lds, st, d_residual, plane_stride, d_jobs, num_jobs, d_twiddles, d_acf_head, head, span); }
+    else { hipLaunchKernelGGL(k_ltm_acf2<13>, dim3(num_jobs), dim3(ACF2_THREADS), lds, st, d_residual, plane_stride, d_jobs, num_jobs, d_twiddles, d_acf_head, head, span); }
+  } else if (lds <= SLA_HIP_LDS_BUDGET) {
     hipError_t e = ensure_dynamic_lds((const void*)k_ltm_acf<true>, lds);
     if (e != hipSuccess) { return hip_rc(e); }
     hipLaunchKernelGGL(k_ltm_acf<true>, dim3(num_jobs), dim3(ACF_THREADS), lds, st, d_residual, plane_stride, d_jobs, num_jobs,

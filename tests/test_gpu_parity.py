@@ -1044,6 +1044,34 @@ def _full_length_check(oracle, hip, p, cap, nch, n, bits, rate, prefix_frames):
     assert ret == 0 and bytes(data[43:keep]) == want[43:keep]
     rch, h = hip.decode_header(data[:43])
     assert rch == 0 and h.num_samples == n
+    # two more windows pinned to the oracle, in the middle and at the end of the file: walk the block
+    # headers (sync 0xFFFF, 32-bit size of what follows, CRC16, 16-bit sample count: src/SLAEncoder.c:685-693) to find the
+    # bytes of the blocks that start at a super-frame start; the oracle encodes the same samples as a range of this file
+    offs, starts, pos, off = [], [], 0, 43
+    raw = data if isinstance(data, np.ndarray) else np.frombuffer(data, np.uint8)
+    while off < len(raw):
+        assert raw[off] == 0xFF and raw[off + 1] == 0xFF
+        size = (int(raw[off + 2]) << 24) | (int(raw[off + 3]) << 16) | (int(raw[off + 4]) << 8) | int(raw[off + 5])
+        offs.append(off); starts.append(pos)
+        pos += (int(raw[off + 8]) << 8) | int(raw[off + 9])
+        off += 6 + size
+    assert pos == n and len(offs) == h.num_blocks
+    offs.append(off)
+    starts = np.array(starts, np.int64)
+    maxb = p.max_block_samples
+    lshift = int(to.offset_lshift)
+    for s0 in ((n // 2) // maxb * maxb, (n // maxb - prefix_frames) * maxb):
+        b0 = int(np.searchsorted(starts, s0))
+        assert starts[b0] == s0                                          # no silence in this signal: super-frames sit on the block grid
+        mm = min(prefix_frames * maxb, n - s0) if s0 + prefix_frames * maxb < n - maxb else n - s0
+        retw, wantw = oracle.encode_range(p, np.ascontiguousarray(pcm[:, s0:s0 + mm]), lshift)
+        to_end = (s0 + mm == n)
+        b1 = b0
+        ends = np.append(starts[1:], n)
+        while b1 < len(starts) and (to_end or ends[b1] <= s0 + mm - maxb):      # (the window's last super-frame ends the oracle's "file")
+            b1 += 1
+        seg = bytes(raw[offs[b0]:offs[b1]])
+        assert retw == 0 and b1 > b0 and seg == wantw[43:43 + len(seg)] and (not to_end or len(wantw) == 43 + len(seg)), (s0, b0, b1)
     print("full length: %d ch x %d samples, synth %.1f s, encode %.2f s (%.0f Msamples/s end to end), decode %.2f s, %d bytes, %d blocks"
           % (nch, n, t1 - t0, t2 - t1, nch * n / (t2 - t1) / 1e6, t3 - t2, len(data), h.num_blocks))
 
