@@ -278,10 +278,11 @@ int sla_hip_launch_lattice_groups(const int32_t* d_pcm, uint64_t plane_stride, u
  * (zero-padded to fft_size, forward, |.|^2, inverse).  head == SLA_HIP_ACF_RECORD: per job a 12-double
  * record {code (0 silent, 1 ok, 2 no candidate), chosen pitch lag, acf[0..4], acf[chosen-2..chosen+2]}
  * after the reference's peak scan (src/SLAPredictor.c:866-924); any other head: the first `head` lags.  d_twiddles holds the
- * 3*fft_size doubles produced by the host with the reference's recurrence (layout: sla_kernels.hip).
+ * SLA_HIP_TWIDDLE_DOUBLES(fft_size) doubles produced by the host with the reference's recurrence (layout: sla_kernels.hip).
  * fft_size*8 bytes must fit SLA_HIP_LDS_BUDGET, otherwise d_scratch (scratch_slots x fft_size doubles
  * of device memory) is used as the work area. */
 #define SLA_HIP_ACF_RECORD 12u
+#define SLA_HIP_TWIDDLE_DOUBLES(fft_size) (6u * (size_t)(fft_size))
 int sla_hip_launch_ltm_acf(const int32_t* d_residual, uint64_t plane_stride,
                            const sla_hip_acf_job* d_jobs, uint32_t num_jobs, uint32_t fft_size,
                            const double* d_twiddles, double* d_scratch, uint32_t scratch_slots,

@@ -1060,11 +1060,11 @@ static int pipeline_reserve(struct SLAEncoder* e, const actx_t* a)
     e->win_dirty = 0;
   }
   if (!e->twiddle_ready) {
-    double* tw = (double*)malloc(sizeof(double) * 3 * (size_t)fft_size);
+    double* tw = (double*)malloc(sizeof(double) * SLA_HIP_TWIDDLE_DOUBLES(fft_size));
     if (tw == NULL) { return SLA_APIRESULT_NG; }
     slai_fft_plan_export(e->fft, tw);
-    RCCHK(dev_reserve(&e->d_twiddle, sizeof(double) * 3 * (size_t)fft_size));
-    HIPCHK(hipMemcpy(e->d_twiddle.ptr, tw, sizeof(double) * 3 * (size_t)fft_size, hipMemcpyHostToDevice));
+    RCCHK(dev_reserve(&e->d_twiddle, sizeof(double) * SLA_HIP_TWIDDLE_DOUBLES(fft_size)));
+    HIPCHK(hipMemcpy(e->d_twiddle.ptr, tw, sizeof(double) * SLA_HIP_TWIDDLE_DOUBLES(fft_size), hipMemcpyHostToDevice));
     free(tw);
     e->twiddle_ready = 1;
   }

@@ -97,12 +97,15 @@ void slai_fft_plan_destroy(slai_fft_plan* p)
 
 uint32_t slai_fft_plan_size(const slai_fft_plan* p) { return p->fft_size; }
 
-/* flat copy for the device kernel (layout documented at k_ltm_acf in sla_kernels.hip):
- * 3 * fft_size doubles */
+/* flat copy for the device kernels (layout documented at k_ltm_acf in sla_kernels.hip): SLA_HIP_TWIDDLE_DOUBLES(fft_size)
+ * = 6 * fft_size doubles -- the split re / im tables of k_ltm_acf, then the same values as (re, im) pairs for k_ltm_acf2,
+ * which fetches a twiddle with one 16-byte load */
 void slai_fft_plan_export(const slai_fft_plan* p, double* out)
 {
   const uint32_t F = p->fft_size, half = F / 2, quarter = F / 4;
-  memset(out, 0, sizeof(double) * 3 * (size_t)F);
+  double* pair = out + 3 * (size_t)F;
+  uint32_t i, d;
+  memset(out, 0, sizeof(double) * 6 * (size_t)F);
   memcpy(out,                       p->tw_re[0], sizeof(double) * (half - 1));
   memcpy(out + half,                p->tw_im[0], sizeof(double) * (half - 1));
   memcpy(out + F,                   p->tw_re[1], sizeof(double) * (half - 1));
@@ -111,6 +114,11 @@ void slai_fft_plan_export(const slai_fft_plan* p, double* out)
   memcpy(out + 2 * F + quarter,     p->rt_im[0], sizeof(double) * (quarter - 1));
   memcpy(out + 2 * F + 2 * quarter, p->rt_re[1], sizeof(double) * (quarter - 1));
   memcpy(out + 2 * F + 3 * quarter, p->rt_im[1], sizeof(double) * (quarter - 1));
+  /* pairs: [0, F/2) forward stages | [F/2, F) inverse stages | [F, F + F/4) forward recombination | [F + F/4, F + F/2) inverse */
+  for (d = 0; d < 2; d++) {
+    for (i = 0; i + 1 < half; i++) { pair[2 * ((size_t)d * half + i)] = p->tw_re[d][i]; pair[2 * ((size_t)d * half + i) + 1] = p->tw_im[d][i]; }
+    for (i = 0; i + 1 < quarter; i++) { pair[2 * ((size_t)F + (size_t)d * quarter + i)] = p->rt_re[d][i]; pair[2 * ((size_t)F + (size_t)d * quarter + i) + 1] = p->rt_im[d][i]; }
+  }
 }
 
 /* ---- tiny dense solve (reference src/SLAUtility.c:487-674) ---------------- */

@@ -232,10 +232,10 @@ struct SLALongTermCalculator* SLALongTermCalculator_Create(
   if (c == NULL) { return NULL; }
   c->fft_size = fft_size; c->max_taps = max_num_taps;
   plan = slai_fft_plan_create(fft_size);
-  tw = (double*)malloc(sizeof(double) * 3 * (size_t)fft_size);
+  tw = (double*)malloc(sizeof(double) * SLA_HIP_TWIDDLE_DOUBLES(fft_size));
   if (plan == NULL || tw == NULL) { slai_fft_plan_destroy(plan); free(tw); free(c); return NULL; }
   slai_fft_plan_export(plan, tw);
-  if (up(&c->d_tw, tw, sizeof(double) * 3 * (size_t)fft_size) != 0) { dfree(&c->d_tw); free(c); c = NULL; }
+  if (up(&c->d_tw, tw, sizeof(double) * SLA_HIP_TWIDDLE_DOUBLES(fft_size)) != 0) { dfree(&c->d_tw); free(c); c = NULL; }
   slai_fft_plan_destroy(plan); free(tw);
   return c;
 }

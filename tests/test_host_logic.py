@@ -216,7 +216,7 @@ def test_fft_twiddle_tables(L, oracle):
     L.slai_fft_plan_export.argtypes = [C.c_void_p, f64p]
     F = 1024
     plan = L.slai_fft_plan_create(F)
-    tw = np.zeros(3 * F)
+    tw = np.zeros(6 * F)
     L.slai_fft_plan_export(plan, ptr(tw, f64p))
     L.slai_fft_plan_destroy(plan)
     rng = np.random.default_rng(0)
