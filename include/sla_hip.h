@@ -134,7 +134,8 @@ typedef struct sla_hip_tuning {
   uint32_t lpc_blocks_chains;   /* 1: chosen blocks through k_lpc's serial chains instead of k_lpc_blocks            */
   uint32_t tail_waves;          /* waves per k_tail workgroup (1..4), 0 = automatic (1)                              */
   uint32_t lpc_tile;            /* steps per tile of k_lpc_blocks' wide packs: 24, or 0 / 48 = 48 where it fits         */
-  uint32_t tail_lanes;          /* lanes per tail job in units of the LMS order: 1 = one (k_tail2, two taps per lane), 2 = two (k_tail, one tap per lane), 0 = by the number of jobs */
+  uint32_t tail_lanes;          /* lanes per tail job in units of the LMS order: 1 = one (k_tail2, two taps per lane), 2 = two (k_tail, one tap per lane),
+                                   3 = ONE lane per job (k_tail1, LMS order <= 16), 0 = by the number of jobs */
   double   plan_margin;         /* certification margin of k_plan, 0 = 1e-4 (tests raise it to force the host plan)  */
   uint32_t acf_classic;         /* 1: long-term autocorrelation through k_ltm_acf (one LDS pass per step) instead of k_ltm_acf2 */
   uint32_t pad_;
@@ -221,7 +222,8 @@ int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_stride, uin
                                 const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
                                 uint32_t max_cands_per_group,
                                 const sla_hip_lpc_cand* d_cands, double* d_tile_sums, double* d_out,
-                                double exact_limit, double cert_safety, sla_hip_stream_t stream);
+                                double exact_limit, double cert_safety, uint32_t* d_any_exact /* one scratch word, may be NULL */,
+                                sla_hip_stream_t stream);
 
 /* The scalar tail of the partition search on the device: estimated code length per candidate, adjacency
  * matrix, shortest path (reference src/SLAPredictor.c:416-468, 1521-1581, 1615-1692).  d_groups: the groups of
@@ -500,7 +502,7 @@ int sla_hip_get_trace(struct SLAEncoder* encoder, sla_hip_trace* trace);
 /* Options of one encoder handle, by name (the environment variable of the same meaning, read once in
  * SLAEncoder_Create, is given in brackets).  Layout knobs: "lpc_pack" [SLA_HIP_LPC_PACK], "lpc_threads"
  * [SLA_HIP_LPC_THREADS], "lpc_tile" (24 / 48 / 0 = automatic), "tail_waves" [SLA_HIP_TAIL_WAVES], "tail_lanes" (1: two
- * taps per lane, 2: one tap per lane, 0: by the number of jobs), "chunks" [SLA_HIP_CHUNKS],
+ * taps per lane, 2: one tap per lane, 3: one lane per job, 0: by the number of jobs) [SLA_HIP_TAIL_LANES], "chunks" [SLA_HIP_CHUNKS],
  * "threads" (host pool) [SLA_HIP_THREADS].  Route switches -- every route gives the same bytes; tests force the
  * slower exact ones through these: "search_exact" (0: no tile-sum search) [SLA_HIP_SEARCH=chain], "exact_bits"
  * (log2 of the tile-sum energy limit, 1..53) [SLA_HIP_EXACT_BITS], "cert_safety" (safety factor of the certificate for

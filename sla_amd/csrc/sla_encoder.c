@@ -390,6 +390,8 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   g_trace_on = e->trace;
   env = getenv("SLA_HIP_LPC_PACK");
   if (env != NULL && atoi(env) >= 1) { e->tune.lpc_pack = (uint32_t)atoi(env); }
+  env = getenv("SLA_HIP_TAIL_LANES");
+  if (env != NULL && atoi(env) >= 0 && atoi(env) <= 3) { e->tune.tail_lanes = (uint32_t)atoi(env); }
   env = getenv("SLA_HIP_ACF");
   if (env != NULL && strcmp(env, "classic") == 0) { e->tune.acf_classic = 1; }
   env = getenv("SLA_HIP_LPC_THREADS");
@@ -1096,7 +1098,7 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
       const double cert = e->device_plan ? e->cert_safety : 0.0;
       RCCHK(sla_hip_launch_search_exact(e->pcm_dev, e->stride, ms, order, dx, nx, a->max_window, a->max_xcands, (const sla_hip_lpc_cand*)e->d_cands.ptr,
                                         (double*)e->d_tile_sums.ptr + (size_t)k->xg_lo * SLA_HIP_XTILES * 2 * sla_hip_search_exact_lags(order),
-                                        (double*)e->d_lpc_out.ptr, limit, cert, e->stream));
+                                        (double*)e->d_lpc_out.ptr, limit, cert, (uint32_t*)e->d_or.ptr + 8 + c, e->stream));
       if (!(cert > 0.0))
       RCCHK(sla_hip_launch_lpc_rerun(e->pcm_dev, e->stride, ms, order, (const sla_hip_lpc_group*)e->d_groups.ptr + k->grp_lo, ng,
                                      a->max_window, a->max_cpg, (const sla_hip_lpc_cand*)e->d_cands.ptr, (double*)e->d_lpc_out.ptr,
@@ -1771,7 +1773,7 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   else if (strcmp(name, "tail_waves") == 0)        { OPT_RANGE(0, 4); e->tune.tail_waves = (uint32_t)iv; }
   else if (strcmp(name, "lpc_tile") == 0)          { if (iv != 0 && iv != 24 && iv != 48) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.lpc_tile = (uint32_t)iv; }
   else if (strcmp(name, "acf_classic") == 0)       { OPT_RANGE(0, 1); e->tune.acf_classic = (uint32_t)iv; }
-  else if (strcmp(name, "tail_lanes") == 0)        { OPT_RANGE(0, 2); e->tune.tail_lanes = (uint32_t)iv; }
+  else if (strcmp(name, "tail_lanes") == 0)        { OPT_RANGE(0, 3); e->tune.tail_lanes = (uint32_t)iv; }
   else if (strcmp(name, "lpc_blocks_chains") == 0) { OPT_RANGE(0, 1); e->tune.lpc_blocks_chains = (uint32_t)iv; if (iv) { e->fuse_lattice = 0; } }
   /* the certification margins may only be widened: below the built-in values byte-identity is no longer guaranteed */
   else if (strcmp(name, "plan_margin") == 0)       { if (value != 0.0 && !(value >= 1e-4)) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.plan_margin = value; }

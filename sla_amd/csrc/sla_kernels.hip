@@ -1505,8 +1505,13 @@ template <int P, int mode>           // P >= order: 16, 32, 48, 64
 __global__ __launch_bounds__(64)
 void k_search_finish(uint32_t order, uint32_t lags, uint32_t gpw, uint32_t per,
                      const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, const sla_hip_lpc_cand* __restrict__ cands,
-                     const double* __restrict__ tile_sums, double* __restrict__ out, double exact_limit, double cert)
+                     const double* __restrict__ tile_sums, double* __restrict__ out, double exact_limit, double cert,
+                     uint32_t* __restrict__ any_exact)
 {
+  // any_exact (may be NULL): mode 1 sets the word when it meets a group below the limit, mode 2 returns at once while it is
+  // still 0 -- loud material wider than 16 bits has no such group, and the mode-2 launch (70 KiB of LDS per workgroup) cost
+  // 0.15 ms per C5-120 s launch just to find that out group by group
+  if (mode == 2 && any_exact != nullptr && *any_exact == 0u) { return; }
   // mode 0: every group is known to be under the exactness limit (16-bit material): Levinson-Durbin in registers, LDS only
   // holds r; 1: only the groups over the limit (certificate; LDS only holds r: three times the waves per CU at order 48);
   // 2: only the groups below it, Levinson-Durbin with its vectors in LDS.  Material that may have both kinds is launched
@@ -1530,6 +1535,7 @@ void k_search_finish(uint32_t order, uint32_t lags, uint32_t gpw, uint32_t per,
     double energy = 0.0;
     for (uint32_t t = 0; t < ntiles; t++) { energy += ts[(uint64_t)t * 2 * lags]; }
     const bool skip = (mode == 1 && energy < exact_limit) || (mode == 2 && !(energy < exact_limit));
+    if (mode == 1 && skip && any_exact != nullptr) { atomicOr(any_exact, 1u); }
     s_g[lane] = g; s_energy[lane] = energy; s_skip[lane] = skip ? 1u : 0u;
     if (!skip) { atomicMax(&s_cmax, g.cand_count); }
   }
@@ -2089,6 +2095,118 @@ void k_tail2(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, 
     fsum += ((uint64_t)hi << 32) | lo;
   }
   if (have && t == 0) { fold_sum[j] = fsum; }
+  span_end(span);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tail1: the same stage with ONE LANE per job -- for files with tens of thousands of (block, channel) jobs.  k_tail
+// and k_tail2 spread a job's taps over 8 - 16 lanes to shorten the serial chain per sample, which is what a short file
+// needs (its duration is one block's chain); a long file has more jobs than the chip has lanes, and then what counts is
+// instructions per job and sample: ~25 per 4 - 8 jobs there, ~70 per 64 jobs here (2*ORDER products and as many
+// sign-step updates, all in registers: ORDER samples are unrolled so that the histories' ring positions are static
+// register indices).  A lane walks its own block: it fetches ORDER consecutive samples (and the long-term window
+// behind them) per step, one step ahead of the arithmetic.
+// ---------------------------------------------------------------------------------------------
+template <int ORDER, bool FIRST>
+__device__ __forceinline__ void tail1_block(const int32_t (&vs)[ORDER], int32_t (&es)[ORDER], int32_t (&cf)[ORDER], int32_t (&ci)[ORDER],
+                                            int32_t (&hf)[ORDER], int32_t (&hi)[ORDER], int32_t (&sf)[ORDER], int32_t (&si)[ORDER])
+{
+#pragma unroll
+  for (int u = 0; u < ORDER; u++) {
+    const int32_t v = vs[u];
+    int32_t e, ph;
+    if (FIRST) {
+      e = v; ph = v;                                   // the first ORDER samples only prime both histories  src/SLAPredictor.c:1233-1255
+    } else {
+      // the element of age i sits in slot (i - u) mod ORDER at step u of the unrolled block
+      uint32_t sum = 1u << 9;
+#pragma unroll
+      for (int i = 0; i < ORDER; i++) {
+        const int slot = (i - u + ORDER) % ORDER;
+        sum += (uint32_t)cf[i] * (uint32_t)hf[slot];
+        sum += (uint32_t)ci[i] * (uint32_t)hi[slot];
+      }
+      const int32_t p = (int32_t)sum >> 10;
+      e = (int32_t)((uint32_t)v - (uint32_t)p);
+      const int32_t ne = (int32_t)((uint32_t)p - (uint32_t)v);
+      const uint32_t mag = (uint32_t)max(e, ne);
+      const int32_t lg = 32 - (int32_t)__clz((int)mag);                    // ceil(log2(|e|+1)); __clz(0) = 32
+      const int32_t step = __mul24(sgn(e), lg >> 1);                       // step table src/SLAPredictor.c:123-144 times sign(e)
+#pragma unroll
+      for (int i = 0; i < ORDER; i++) {
+        const int slot = (i - u + ORDER) % ORDER;
+        cf[i] = mad24(step, sf[slot], cf[i]);
+        ci[i] = mad24(step, si[slot], ci[i]);
+      }
+      ph = p;
+    }
+    const int put = (ORDER - 1 - u + ORDER) % ORDER;   // the oldest element's slot takes the new one
+    hf[put] = v; sf[put] = sgn(v);
+    hi[put] = ph; si[put] = sgn(ph);
+    es[u] = e;
+  }
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(64)
+void k_tail1(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, uint64_t stride,
+             const sla_hip_tail_job* __restrict__ jobs, uint32_t num_jobs, uint32_t ntaps,
+             uint64_t* __restrict__ fold_sum, unsigned long long* span, uint32_t stage_flags)
+{
+  span_begin(span);
+  const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+  const bool have = (j < num_jobs);
+  const sla_hip_tail_job job = jobs[have ? j : 0];
+  const uint32_t n = have ? job.blk_len : 0;
+  const int32_t* in = res_in + (uint64_t)job.channel * stride + job.blk_off;
+  int32_t* out = res_out + (uint64_t)job.channel * stride + job.blk_off;
+  const uint32_t delay = job.pitch + (ntaps >> 1);
+  const bool use_ltm = (job.pitch >= 3);
+  const bool pass = (n < (uint32_t)ORDER) || (stage_flags & 1u);      // fewer samples than taps, or no LMS stage wanted: everything passes through
+  const uint32_t nmax = umax_wave(n);
+
+  // ORDER consecutive samples behind the long-term stage   src/SLAPredictor.c:1063-1099
+  auto fetch = [&](uint32_t s0, int32_t (&v)[ORDER]) {
+#pragma unroll
+    for (int u = 0; u < ORDER; u++) {
+      const uint32_t s = s0 + (uint32_t)u;
+      int32_t x = 0;
+      if (s < n) {
+        x = in[s];
+        if (use_ltm && s >= delay) {
+          int64_t acc = (int64_t)1 << 30;
+          for (uint32_t k = 0; k < ntaps; k++) { acc += (int64_t)job.ltm_coef[k] * (int64_t)in[s - delay + k]; }
+          x = (int32_t)((uint32_t)x - (uint32_t)(int32_t)(acc >> 31));
+        }
+      }
+      v[u] = x;
+    }
+  };
+
+  int32_t cf[ORDER], ci[ORDER], hf[ORDER], hi[ORDER], sf[ORDER], si[ORDER];
+#pragma unroll
+  for (int i = 0; i < ORDER; i++) { cf[i] = 0; ci[i] = 0; hf[i] = 0; hi[i] = 0; sf[i] = 0; si[i] = 0; }
+  uint64_t fsum = 0;
+  int32_t nxt[ORDER];
+  fetch(0, nxt);
+  for (uint32_t s0 = 0; s0 < nmax; s0 += ORDER) {
+    int32_t cur[ORDER], es[ORDER];
+#pragma unroll
+    for (int u = 0; u < ORDER; u++) { cur[u] = nxt[u]; }
+    fetch(s0 + ORDER, nxt);                          // the next step's samples travel while this one computes
+    if (s0 == 0) { tail1_block<ORDER, true>(cur, es, cf, ci, hf, hi, sf, si); }
+    else { tail1_block<ORDER, false>(cur, es, cf, ci, hf, hi, sf, si); }
+#pragma unroll
+    for (int u = 0; u < ORDER; u++) {
+      const uint32_t s = s0 + (uint32_t)u;
+      const int32_t e = pass ? cur[u] : es[u];
+      if (s < n) {
+        out[s] = e;
+        fsum += (e < 0) ? ~((uint32_t)e << 1) : ((uint32_t)e << 1);   // zig-zag fold, src/SLAUtility.h:37
+      }
+    }
+  }
+  if (have) { fold_sum[j] = fsum; }
   span_end(span);
 }
 
@@ -3161,7 +3279,7 @@ extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_
                                            const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
                                            uint32_t max_cands_per_group,
                                            const sla_hip_lpc_cand* d_cands, double* d_tile_sums, double* d_out,
-                                           double exact_limit, double cert_safety, sla_hip_stream_t stream)
+                                           double exact_limit, double cert_safety, uint32_t* d_any_exact, sla_hip_stream_t stream)
 {
   if (d_pcm == nullptr || d_groups == nullptr || d_cands == nullptr || d_tile_sums == nullptr || d_out == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   const uint32_t lags = sla_hip_search_exact_lags(order);
@@ -3169,6 +3287,10 @@ extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_
   if (max_window == 0 || max_cands_per_group == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (num_groups == 0) { return 0; }
   hipStream_t st = (hipStream_t)stream;
+  if (d_any_exact != nullptr) {
+    const hipError_t ez = hipMemsetAsync(d_any_exact, 0, sizeof(uint32_t), st);
+    if (ez != hipSuccess) { return hip_rc(ez); }
+  }
   const uint32_t tiles = (max_window + SLA_HIP_XTILE - 1) / SLA_HIP_XTILE;       // waves per group
   const uint32_t waves = num_groups * tiles;
   const dim3 grid((waves + 3) / 4), block(256);
@@ -3196,16 +3318,16 @@ extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_
       e = ensure_dynamic_lds((const void*)k_search_finish<PP, 0>, lds_r); \
       if (e != hipSuccess) { return hip_rc(e); } \
       hipLaunchKernelGGL((k_search_finish<PP, 0>), dim3((num_groups + gpw - 1) / gpw), dim3(64), lds_r, st, order, lags, gpw, per, \
-                         d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety); \
+                         d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety, d_any_exact); \
     } else { \
       e = ensure_dynamic_lds((const void*)k_search_finish<PP, 1>, lds_r); \
       if (e != hipSuccess) { return hip_rc(e); } \
       e = ensure_dynamic_lds((const void*)k_search_finish<PP, 2>, lds); \
       if (e != hipSuccess) { return hip_rc(e); } \
       hipLaunchKernelGGL((k_search_finish<PP, 1>), dim3((num_groups + gpw - 1) / gpw), dim3(64), lds_r, st, order, lags, gpw, per, \
-                         d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety); \
+                         d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety, d_any_exact); \
       hipLaunchKernelGGL((k_search_finish<PP, 2>), dim3((num_groups + gpw - 1) / gpw), dim3(64), lds, st, order, lags, gpw, per, \
-                         d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety); \
+                         d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety, d_any_exact); \
     } } while (0)
   switch (pclass) {
     case 16: SLA_FINISH(16); break;
@@ -3341,6 +3463,17 @@ static int launch_tail_impl(const int32_t* d_res_in, int32_t* d_res_out, uint64_
    * 3.4 waves per SIMD, 1.01 -> 0.79 ms).  Automatic: k_tail2 above three one-tap waves per SIMD of an MI355X. */
   const uint32_t one_tap_waves = (num_jobs + (64 / (2 * lms_order)) - 1) / (64 / (2 * lms_order));
   const uint32_t lanes_knob = tuning().tail_lanes;
+  /* One lane per job (k_tail1) once there are more jobs than half the chip's lanes -- then instructions per job and sample
+   * decide, not the length of one job's chain; LMS orders 4 - 16 (the histories live in registers). */
+  if (lms_order <= 16 && (lanes_knob == 3 || (lanes_knob == 0 && num_jobs >= 32768u))) {
+    dim3 grid1((num_jobs + 63) / 64), block1(64);
+    switch (lms_order) {
+      case 4:  hipLaunchKernelGGL(k_tail1<4>,  grid1, block1, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
+      case 8:  hipLaunchKernelGGL(k_tail1<8>,  grid1, block1, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
+      default: hipLaunchKernelGGL(k_tail1<16>, grid1, block1, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
+    }
+    return hip_rc(hipGetLastError());
+  }
   if (lanes_knob == 1 || (lanes_knob == 0 && one_tap_waves > 3u * 1024u)) {      /* two taps per lane: `order` lanes per job */
     const uint32_t jpb = tail_waves * (64 / lms_order);
     dim3 grid2((num_jobs + jpb - 1) / jpb), block2(64 * tail_waves);

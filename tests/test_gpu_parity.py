@@ -45,7 +45,7 @@ def hip_encode(hip, p, pcm, want_residuals=True):
             enc.set_option("stream", 1)
             enc.set_option("stream_piece", 1024)
             enc.set_option("stream_lanes", 1 + (n // 7) % 4)
-            enc.set_option("tail_lanes", 1 + (n // 5) % 2)               # both layouts of the tail kernel take turns
+            enc.set_option("tail_lanes", 1 + (n // 5) % 3)               # the three layouts of the tail kernel take turns
             again = enc.encode_whole(pcm)
             assert again == data, "streamed EncodeWhole differs from the plain path"
         return data, tr
@@ -159,6 +159,8 @@ def test_tail_orders(oracle, hip, lms, ltm):
     got, _ = _encode_with_options(hip, p, pcm, tail_lanes=1)      # two taps per lane (k_tail2)
     assert got == want
     got, _ = _encode_with_options(hip, p, pcm, tail_lanes=1, tail_waves=2, chunks=1)
+    assert got == want
+    got, _ = _encode_with_options(hip, p, pcm, tail_lanes=3)      # one lane per job (k_tail1: the choice for tens of thousands of jobs; order 32 falls back)
     assert got == want
 
 
@@ -572,7 +574,7 @@ def test_search_exact_launcher_equals_serial_chains(oracle, hip, order, nch, bit
     def run(lim):
         rc = L.sla_hip_launch_search_exact(C.c_void_p(d_pcm.data_ptr()), C.c_uint64(stride), ms, order,
                                            C.c_void_p(d_g.data_ptr()), nch, W_, len(cand), C.c_void_p(d_c.data_ptr()),
-                                           C.c_void_p(d_ts.data_ptr()), C.c_void_p(d_out.data_ptr()), C.c_double(lim), C.c_double(0.0), None)
+                                           C.c_void_p(d_ts.data_ptr()), C.c_void_p(d_out.data_ptr()), C.c_double(lim), C.c_double(0.0), None, None)
         assert rc == 0
         torch.cuda.synchronize()
         return d_out.cpu().numpy().reshape(nch, len(cand), order + 2)
@@ -653,7 +655,7 @@ def test_search_certificate_brackets_the_reference(oracle, hip, order, nch, bits
     torch.cuda.synchronize()
     rc = L.sla_hip_launch_search_exact(C.c_void_p(d_pcm.data_ptr()), C.c_uint64(stride), ms, order,
                                        C.c_void_p(d_g.data_ptr()), nch, W_, len(cand), C.c_void_p(d_c.data_ptr()),
-                                       C.c_void_p(d_ts.data_ptr()), C.c_void_p(d_out.data_ptr()), C.c_double(0.0), C.c_double(64.0), None)
+                                       C.c_void_p(d_ts.data_ptr()), C.c_void_p(d_out.data_ptr()), C.c_double(0.0), C.c_double(64.0), None, None)
     assert rc == 0
     torch.cuda.synchronize()
     out = d_out.cpu().numpy().reshape(nch, len(cand), order + 2)
