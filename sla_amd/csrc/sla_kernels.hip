@@ -2147,63 +2147,83 @@ __device__ __forceinline__ void tail1_block(const int32_t (&vs)[ORDER], int32_t 
   }
 }
 
+// A lane that walked its own block through global memory touched 64 different cache lines per load or store instruction
+// (measured: twice as slow as k_tail2).  So the wave moves the samples as tiles: T1_TILE samples of each of its 64 jobs
+// per step, fetched row by row with all lanes on consecutive samples of one job (two jobs per instruction; the
+// long-term stage is applied on the way in, src/SLAPredictor.c:1063-1099), transposed through LDS -- row stride
+// T1_TILE + 1 words, so that both the row-wise fill and the lane-per-row walk are conflict-free -- and written back the
+// same way.
+#define T1_TILE 32
+#define T1_ROW (T1_TILE + 1)
+
 template <int ORDER>
 __global__ __launch_bounds__(64)
 void k_tail1(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, uint64_t stride,
              const sla_hip_tail_job* __restrict__ jobs, uint32_t num_jobs, uint32_t ntaps,
              uint64_t* __restrict__ fold_sum, unsigned long long* span, uint32_t stage_flags)
 {
+  __shared__ int32_t t_in[64 * T1_ROW], t_out[64 * T1_ROW];
+  __shared__ sla_hip_tail_job s_job[64];
   span_begin(span);
-  const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t j = blockIdx.x * 64 + lane;
   const bool have = (j < num_jobs);
-  const sla_hip_tail_job job = jobs[have ? j : 0];
-  const uint32_t n = have ? job.blk_len : 0;
-  const int32_t* in = res_in + (uint64_t)job.channel * stride + job.blk_off;
-  int32_t* out = res_out + (uint64_t)job.channel * stride + job.blk_off;
-  const uint32_t delay = job.pitch + (ntaps >> 1);
-  const bool use_ltm = (job.pitch >= 3);
+  s_job[lane] = jobs[have ? j : 0];
+  if (!have) { s_job[lane].blk_len = 0; }
+  const uint32_t n = s_job[lane].blk_len;
   const bool pass = (n < (uint32_t)ORDER) || (stage_flags & 1u);      // fewer samples than taps, or no LMS stage wanted: everything passes through
   const uint32_t nmax = umax_wave(n);
-
-  // ORDER consecutive samples behind the long-term stage   src/SLAPredictor.c:1063-1099
-  auto fetch = [&](uint32_t s0, int32_t (&v)[ORDER]) {
-#pragma unroll
-    for (int u = 0; u < ORDER; u++) {
-      const uint32_t s = s0 + (uint32_t)u;
-      int32_t x = 0;
-      if (s < n) {
-        x = in[s];
-        if (use_ltm && s >= delay) {
-          int64_t acc = (int64_t)1 << 30;
-          for (uint32_t k = 0; k < ntaps; k++) { acc += (int64_t)job.ltm_coef[k] * (int64_t)in[s - delay + k]; }
-          x = (int32_t)((uint32_t)x - (uint32_t)(int32_t)(acc >> 31));
-        }
-      }
-      v[u] = x;
-    }
-  };
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   int32_t cf[ORDER], ci[ORDER], hf[ORDER], hi[ORDER], sf[ORDER], si[ORDER];
 #pragma unroll
   for (int i = 0; i < ORDER; i++) { cf[i] = 0; ci[i] = 0; hf[i] = 0; hi[i] = 0; sf[i] = 0; si[i] = 0; }
   uint64_t fsum = 0;
-  int32_t nxt[ORDER];
-  fetch(0, nxt);
-  for (uint32_t s0 = 0; s0 < nmax; s0 += ORDER) {
-    int32_t cur[ORDER], es[ORDER];
-#pragma unroll
-    for (int u = 0; u < ORDER; u++) { cur[u] = nxt[u]; }
-    fetch(s0 + ORDER, nxt);                          // the next step's samples travel while this one computes
-    if (s0 == 0) { tail1_block<ORDER, true>(cur, es, cf, ci, hf, hi, sf, si); }
-    else { tail1_block<ORDER, false>(cur, es, cf, ci, hf, hi, sf, si); }
-#pragma unroll
-    for (int u = 0; u < ORDER; u++) {
-      const uint32_t s = s0 + (uint32_t)u;
-      const int32_t e = pass ? cur[u] : es[u];
-      if (s < n) {
-        out[s] = e;
-        fsum += (e < 0) ? ~((uint32_t)e << 1) : ((uint32_t)e << 1);   // zig-zag fold, src/SLAUtility.h:37
+  const uint32_t half = lane >> 5, t = lane & 31u;
+  for (uint32_t s0 = 0; s0 < nmax; s0 += T1_TILE) {
+    // ---- tile in: row q = samples [s0, s0 + T1_TILE) of job q, behind the long-term stage ----
+#pragma unroll 4
+    for (uint32_t r = 0; r < 32; r++) {
+      const uint32_t q = 2 * r + half;
+      const sla_hip_tail_job* jq = &s_job[q];        // (fields straight from LDS: a private copy with its tap array would live in scratch)
+      const uint32_t s = s0 + t;
+      int32_t x = 0;
+      if (s < jq->blk_len) {
+        const int32_t* in = res_in + (uint64_t)jq->channel * stride + jq->blk_off;
+        const uint32_t pitch = jq->pitch, delay = pitch + (ntaps >> 1);
+        x = in[s];
+        if (pitch >= 3 && s >= delay) {
+          int64_t acc = (int64_t)1 << 30;
+          for (uint32_t k = 0; k < ntaps; k++) { acc += (int64_t)jq->ltm_coef[k] * (int64_t)in[s - delay + k]; }
+          x = (int32_t)((uint32_t)x - (uint32_t)(int32_t)(acc >> 31));
+        }
       }
+      t_in[q * T1_ROW + t] = x;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- the serial cascade: lane = job, ORDER samples per unrolled block ----
+#pragma unroll 1
+    for (uint32_t b0 = 0; b0 < T1_TILE; b0 += ORDER) {
+      int32_t cur[ORDER], es[ORDER];
+#pragma unroll
+      for (int u = 0; u < ORDER; u++) { cur[u] = t_in[lane * T1_ROW + b0 + u]; }
+      if (s0 + b0 == 0) { tail1_block<ORDER, true>(cur, es, cf, ci, hf, hi, sf, si); }
+      else { tail1_block<ORDER, false>(cur, es, cf, ci, hf, hi, sf, si); }
+#pragma unroll
+      for (int u = 0; u < ORDER; u++) {
+        const int32_t e = pass ? cur[u] : es[u];
+        t_out[lane * T1_ROW + b0 + u] = e;
+        if (s0 + b0 + (uint32_t)u < n) { fsum += (e < 0) ? ~((uint32_t)e << 1) : ((uint32_t)e << 1); }   // zig-zag fold, src/SLAUtility.h:37
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- tile out ----
+#pragma unroll 4
+    for (uint32_t r = 0; r < 32; r++) {
+      const uint32_t q = 2 * r + half;
+      const sla_hip_tail_job* jq = &s_job[q];
+      const uint32_t s = s0 + t;
+      if (s < jq->blk_len) { res_out[(uint64_t)jq->channel * stride + jq->blk_off + s] = t_out[q * T1_ROW + t]; }
     }
   }
   if (have) { fold_sum[j] = fsum; }
@@ -3463,9 +3483,11 @@ static int launch_tail_impl(const int32_t* d_res_in, int32_t* d_res_out, uint64_
    * 3.4 waves per SIMD, 1.01 -> 0.79 ms).  Automatic: k_tail2 above three one-tap waves per SIMD of an MI355X. */
   const uint32_t one_tap_waves = (num_jobs + (64 / (2 * lms_order)) - 1) / (64 / (2 * lms_order));
   const uint32_t lanes_knob = tuning().tail_lanes;
-  /* One lane per job (k_tail1) once there are more jobs than half the chip's lanes -- then instructions per job and sample
-   * decide, not the length of one job's chain; LMS orders 4 - 16 (the histories live in registers). */
-  if (lms_order <= 16 && (lanes_knob == 3 || (lanes_knob == 0 && num_jobs >= 32768u))) {
+  /* One lane per job (k_tail1; LMS orders 4 - 16, the histories live in registers): only on request.  Measured against
+   * k_tail2 on the full-length files -- C3 (90 k jobs) 4.05 against 3.61 ms, C5-600 s (56 k jobs of 8192 samples) 7.6
+   * against 5.2 ms, the C4 batch 3.1 against 1.34 ms: 16 quarter-rate 32-bit products per sample in ONE lane's chain and
+   * the tile transposes cost more than the 64 jobs per wave save. */
+  if (lms_order <= 16 && lanes_knob == 3) {
     dim3 grid1((num_jobs + 63) / 64), block1(64);
     switch (lms_order) {
       case 4:  hipLaunchKernelGGL(k_tail1<4>,  grid1, block1, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
