@@ -441,6 +441,8 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
     try:       # HBM traffic per launch of that kernel from the committed rocprofv3 --pmc passes of this configuration
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % cfg.lower())))
         pk = dom.split("+")[0]
+        if pk not in pmc["bytes_per_launch"] and pk + "2" in pmc["bytes_per_launch"]:
+            pk = pk + "2"                     # the stage "k_ltm_acf" runs k_ltm_acf2
         if world == 1 and pk in pmc["bytes_per_launch"]:
             rec = pmc["bytes_per_launch"][pk]
             if "bytes_per_sample_channel" in rec:

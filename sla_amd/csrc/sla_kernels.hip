@@ -1573,7 +1573,7 @@ void k_search_finish(uint32_t order, uint32_t lags, uint32_t gpw, uint32_t per,
       const double* rc = r + (size_t)lane * O1;
       if (energy < exact_limit) {
         if (mode == 0) { levinson_regs<P>(rc, o, order, cd.len); }
-        else if (mode == 2) { levinson_out(rc, av + (size_t)lane * O2, vv + (size_t)lane * O2, o, order, cd.len); }
+        else if (mode == 2) { levinson_regs<P>(rc, o, order, cd.len); }      // (registers, as mode 0: no work space in LDS)
       } else if (mode != 1 || !(cert > 0.0)) {
         o[0] = __longlong_as_double(0x7FF8000000000000ll);          // flagged: rerun as serial chains
       } else {
@@ -3049,7 +3049,7 @@ static hipError_t ensure_dynamic_lds(const void* fn, size_t bytes)
 
 static inline int hip_rc(hipError_t e) { return (e == hipSuccess) ? 0 : -(int)e; }
 
-#define LIST_LPC_GRID 512u        // list mode of k_lpc_blocks: workgroups that walk the list of uncertified blocks
+#define LIST_LPC_GRID 256u        // list mode of k_lpc_blocks: workgroups that walk the list of uncertified blocks
 #define LIST_FINISH_GRID 64u      // list mode of k_blocks_finish
 
 static int launch_prepass_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_channels,
@@ -3197,6 +3197,7 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
     if (pmax > LPC_MAX_PACK) { pmax = LPC_MAX_PACK; }
     if (pmax > 2) { pmax = 2; }
     if (tune.lpc_pack >= 1 && tune.lpc_pack <= LPC_MAX_PACK && tune.lpc_pack * order <= 64) { pmax = tune.lpc_pack; }
+    if (list != nullptr) { pmax = 1; }      // list mode (usually an empty list): the smallest LDS footprint, so that the launch does not wait for whole CUs
     for (uint32_t p = pmax; p >= 1; p--) {
       uint32_t nch = 16;
       while (nch < p * order) { nch <<= 1; }
@@ -3204,7 +3205,7 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
       const uint32_t spl = (nch <= 32) ? 12 : 6;                    // producer lanes per chain: nch * spl <= LB_PRODUCERS
       // steps per tile: 48 for the wide packs (64 chains, 6 producer lanes each: C5-120 s 10.7 -> 10.3 ms per step, a
       // ten-minute order-16 file loses with them: 2.31 -> 2.46 ms) when the longer tiles still fit, else 24
-      uint32_t lbk = (spl == 6 && 2u * 48u * p <= LB_PRODUCERS && tune.lpc_tile != 24u) ? 48u : 24u;
+      uint32_t lbk = (spl == 6 && 2u * 48u * p <= LB_PRODUCERS && tune.lpc_tile != 24u && list == nullptr) ? 48u : 24u;
       size_t bytes = sizeof(double) * ((size_t)p * xr + (size_t)2 * (lbk + 2) * nch + (size_t)2 * 2 * lbk * p + (size_t)p * (order + 1));
       if (bytes > SLA_HIP_LDS_BUDGET && lbk == 48u) {
         lbk = 24u;
@@ -3328,7 +3329,9 @@ extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_
   if (gpw > XF_GROUPS) { gpw = XF_GROUPS; }
   if (gpw < 1) { gpw = 1; }
   const size_t lds_r = sizeof(double) * (size_t)gpw * per * (order + 1);
-  const size_t lds = lds_r + sizeof(double) * (size_t)gpw * per * 2 * (size_t)(order + 2);
+  // (the exact windows of mixed material run the recursion in registers as well: a launch that needs 70 KiB of LDS per
+  // workgroup waits for CUs that the other streams' kernels have left that much of, even when -- loud material wider than
+  // 16 bits -- it has nothing to do)
   // |x| < 2 in the search's unit (mid/side: side = l - r), so a window's energy stays below 4 x its length: when even
   // that is under the limit (16-bit material) every group takes the exact path and one launch does
   const bool all_exact = (exact_limit >= 4.0 * (double)max_window);
@@ -3342,11 +3345,11 @@ extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_
     } else { \
       e = ensure_dynamic_lds((const void*)k_search_finish<PP, 1>, lds_r); \
       if (e != hipSuccess) { return hip_rc(e); } \
-      e = ensure_dynamic_lds((const void*)k_search_finish<PP, 2>, lds); \
+      e = ensure_dynamic_lds((const void*)k_search_finish<PP, 2>, lds_r); \
       if (e != hipSuccess) { return hip_rc(e); } \
       hipLaunchKernelGGL((k_search_finish<PP, 1>), dim3((num_groups + gpw - 1) / gpw), dim3(64), lds_r, st, order, lags, gpw, per, \
                          d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety, d_any_exact); \
-      hipLaunchKernelGGL((k_search_finish<PP, 2>), dim3((num_groups + gpw - 1) / gpw), dim3(64), lds, st, order, lags, gpw, per, \
+      hipLaunchKernelGGL((k_search_finish<PP, 2>), dim3((num_groups + gpw - 1) / gpw), dim3(64), lds_r, st, order, lags, gpw, per, \
                          d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety, d_any_exact); \
     } } while (0)
   switch (pclass) {
