@@ -321,6 +321,8 @@ int sla_hip_launch_rice_write(const int32_t* d_residual, const int32_t* d_pcm, u
 /* int16 -> left-justified int32 (<< 16); d_in must be 8-byte aligned.  Used by the host-PCM path of
  * SLAEncoder_EncodeWhole to halve the PCIe bytes of <= 16-bit input. */
 int sla_hip_launch_unpack16(const int16_t* d_in, int32_t* d_out, uint64_t count, sla_hip_stream_t stream);
+/* the same for <= 24 significant bits carried as three bytes per sample (little-endian, the int32's upper three bytes) */
+int sla_hip_launch_unpack24(const uint8_t* d_in, int32_t* d_out, uint64_t count, sla_hip_stream_t stream);
 
 /* ---- decode side (kernels in sla_decode.hip, driver: SLADecoder.h) -----------------
  * The stream image is the .sla file's bytes in device memory (hipMalloc alignment, viewed as 32-bit words).
@@ -516,7 +518,8 @@ int sla_hip_get_trace(struct SLAEncoder* encoder, sla_hip_trace* trace);
  * instead of one for the file) [SLA_HIP_SINGLE_TAIL], "first_chunk" (1/1000 of the super-frames in pipeline chunk 0;
  * 0: built-in shares), "alt_streams" (block stages of odd and even pipeline chunks on two streams: 0 never, 1 always,
  * 2 = default: for big files, samples x channels x order >= 1e9).  SLAEncoder_EncodeWhole of long files: "stream" (0: never streamed) [SLA_HIP_STREAM],
- * "stream_piece" (samples per piece, all channels together; default 32 Mi; a file of fewer than two pieces is not
+ * "upload24" (1: pageable input of <= 24 significant bits crosses the bus as three bytes per sample; default 0, see DESIGN
+ * section 7 for the A/B) [SLA_HIP_UPLOAD24], "stream_piece" (samples per piece, all channels together; default 32 Mi; a file of fewer than two pieces is not
  * streamed), "stream_lanes" (worker lanes, 1..4, default 4).  After a streamed call the handle holds no analysis tables:
  * sla_hip_get_trace / sla_hip_pack / sla_hip_final_residual answer SLA_APIRESULT_PARAMETER_NOT_SET (NULL).
  * Returns SLA_APIRESULT_INVALID_ARGUMENT for an unknown name or a value out of range. */

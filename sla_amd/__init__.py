@@ -176,7 +176,7 @@ EXPORTED_SYMBOLS = [
     "SLAEncoder_EncodeHeader", "SLAEncoder_EncodeBlock", "SLAEncoder_EncodeWhole",
     # include/sla_hip.h
     "sla_hip_launch_prepass", "sla_hip_launch_lpc", "sla_hip_launch_lattice", "sla_hip_launch_tail",
-    "sla_hip_launch_ltm_acf", "sla_hip_launch_rice_len", "sla_hip_launch_rice_write", "sla_hip_pack_device", "sla_hip_launch_unpack16",
+    "sla_hip_launch_ltm_acf", "sla_hip_launch_rice_len", "sla_hip_launch_rice_write", "sla_hip_pack_device", "sla_hip_launch_unpack16", "sla_hip_launch_unpack24",
     "sla_hip_analyze_device", "sla_hip_pack", "sla_hip_final_residual", "sla_hip_lattice_residual",
     "sla_hip_get_trace", "sla_hip_device_name", "sla_hip_last_timing", "sla_hip_launch_search_exact",
     "sla_hip_search_exact_lags", "sla_hip_launch_plan", "sla_hip_last_counters", "sla_hip_launch_lpc_rerun", "sla_hip_last_kernel_ms", "sla_hip_launch_lpc_blocks", "sla_hip_launch_lpc_blocks_cert", "sla_hip_last_block_cert",

@@ -73,6 +73,7 @@ struct SLAEncoder {
   int      alt_now;                 /* this run's decision */
   int      device_ltm;              /* 1: pitch + taps solved on the device, the block stage runs lattice -> tail without the host (default) */
   int      trace;                   /* host-side timeline on stderr (SLA_HIP_TRACE) */
+  int      upload24;                /* 1: pageable input of <= 24 significant bits crosses the bus as three bytes per sample (k_unpack24); 0 = default, see DESIGN 7 */
   int      block_cert;              /* 1 (default): chosen blocks through the any-order autocorrelation where their codes and the RAW decision certify,
                                      * the exact chain kernel for the rest; 0: every block through the exact kernel */
   double   block_cert_safety;       /* safety factor on the first-order bound of that certificate (16) */
@@ -390,6 +391,8 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   g_trace_on = e->trace;
   env = getenv("SLA_HIP_LPC_PACK");
   if (env != NULL && atoi(env) >= 1) { e->tune.lpc_pack = (uint32_t)atoi(env); }
+  env = getenv("SLA_HIP_UPLOAD24");
+  if (env != NULL) { e->upload24 = (atoi(env) != 0); }
   env = getenv("SLA_HIP_TAIL_LANES");
   if (env != NULL && atoi(env) >= 0 && atoi(env) <= 3) { e->tune.tail_lanes = (uint32_t)atoi(env); }
   env = getenv("SLA_HIP_ACF");
@@ -1781,6 +1784,7 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   else if (strcmp(name, "search_exact") == 0)      { OPT_RANGE(0, 1); e->search_exact = (int)iv; }
   else if (strcmp(name, "exact_bits") == 0)        { OPT_RANGE(1, 53); e->exact_bits = (int)iv; }
   else if (strcmp(name, "cert_safety") == 0)       { if ((value != 0.0 && value < 64.0) || value > 1e30) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->cert_safety = value; }
+  else if (strcmp(name, "upload24") == 0)          { OPT_RANGE(0, 1); e->upload24 = (int)iv; }
   else if (strcmp(name, "block_cert") == 0)        { OPT_RANGE(0, 1); e->block_cert = (int)iv; }
   else if (strcmp(name, "block_cert_safety") == 0) { if (!(value >= 16.0) || value > 1e30) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->block_cert_safety = value; }
   else if (strcmp(name, "device_plan") == 0)       { OPT_RANGE(0, 1); e->device_plan = (int)iv; }
@@ -2411,7 +2415,7 @@ int sla_hip_pack_device(struct SLAEncoder* e, uint8_t* data, uint32_t data_size,
 #define XFER_SLOT_BYTES (8u << 20)
 #define XFER_GRAIN      (64u << 10)          /* samples / bytes per host-thread work item */
 
-typedef struct { const int32_t* src; int16_t* dst16; int32_t* dst32; size_t count; uint32_t lowbits; } stage_in_t;
+typedef struct { const int32_t* src; int16_t* dst16; uint8_t* dst24; int32_t* dst32; size_t count; uint32_t lowbits; } stage_in_t;
 static void stage_in_one(void* vctx, uint32_t i)
 {
   stage_in_t* c = (stage_in_t*)vctx;
@@ -2421,16 +2425,37 @@ static void stage_in_one(void* vctx, uint32_t i)
     uint32_t low = 0;
     for (k = lo; k < hi; k++) { const int32_t v = c->src[k]; low |= (uint32_t)v & 0xFFFFu; c->dst16[k] = (int16_t)(v >> 16); }
     if (low) { __atomic_fetch_or(&c->lowbits, low, __ATOMIC_RELAXED); }
+  } else if (c->dst24 != NULL) {
+    /* option "upload24": the three significant bytes of every sample, four samples = three 32-bit words (XFER_GRAIN is a
+     * multiple of 4: every work item starts on a word) */
+    uint32_t low = 0;
+    uint32_t* w = (uint32_t*)(c->dst24 + 3 * lo);
+    for (k = lo; k + 4 <= hi; k += 4, w += 3) {
+      const uint32_t a = (uint32_t)c->src[k], b = (uint32_t)c->src[k + 1], d = (uint32_t)c->src[k + 2], f = (uint32_t)c->src[k + 3];
+      low |= (a | b | d | f) & 0xFFu;
+      w[0] = (a >> 8) | ((b >> 8) << 24);
+      w[1] = (b >> 16) | ((d >> 8) << 16);
+      w[2] = (d >> 24) | ((f >> 8) << 8);
+    }
+    for (; k < hi; k++) {
+      const uint32_t a = (uint32_t)c->src[k];
+      low |= a & 0xFFu;
+      c->dst24[3 * k] = (uint8_t)(a >> 8); c->dst24[3 * k + 1] = (uint8_t)(a >> 16); c->dst24[3 * k + 2] = (uint8_t)(a >> 24);
+    }
+    if (low) { __atomic_fetch_or(&c->lowbits, low, __ATOMIC_RELAXED); }
   } else {
     memcpy(c->dst32 + lo, c->src + lo, sizeof(int32_t) * (hi - lo));
   }
 }
 
+/* mode16: 0 = int32 as it is, 1 = int16 (the upper half), 24 = three bytes per sample (option "upload24") */
 static int upload_pass(struct SLAEncoder* e, const int32_t* const* input, uint32_t n, uint64_t stride, int mode16, uint32_t* lowbits)
 {
   extern int sla_hip_launch_unpack16(const int16_t*, int32_t*, uint64_t, sla_hip_stream_t);
+  extern int sla_hip_launch_unpack24(const uint8_t*, int32_t*, uint64_t, sla_hip_stream_t);
   const uint32_t C = e->wave_format.num_channels;
-  const size_t slot_samples = mode16 ? (XFER_SLOT_BYTES / 2) : (XFER_SLOT_BYTES / 4);
+  const int mode24 = (mode16 == 24);
+  const size_t slot_samples = mode24 ? ((XFER_SLOT_BYTES / 3) & ~(size_t)(XFER_GRAIN - 1)) : mode16 ? (XFER_SLOT_BYTES / 2) : (XFER_SLOT_BYTES / 4);
   uint32_t ch, k = 0;
   size_t o;
   stage_in_t ctx;
@@ -2442,10 +2467,14 @@ static int upload_pass(struct SLAEncoder* e, const int32_t* const* input, uint32
       int32_t* dst = (int32_t*)e->d_pcm.ptr + (size_t)ch * stride + o;
       if (k >= 2) { HIPCHK(hipEventSynchronize(e->ev_stage[slot])); }
       ctx.src = input[ch] + o; ctx.count = count;
-      ctx.dst16 = mode16 ? (int16_t*)e->h_stage[slot].ptr : NULL;
+      ctx.dst16 = (mode16 && !mode24) ? (int16_t*)e->h_stage[slot].ptr : NULL;
+      ctx.dst24 = mode24 ? (uint8_t*)e->h_stage[slot].ptr : NULL;
       ctx.dst32 = mode16 ? NULL : (int32_t*)e->h_stage[slot].ptr;
       parallel_for(e->upload_pool != NULL ? e->upload_pool : e->pool, (uint32_t)((count + XFER_GRAIN - 1) / XFER_GRAIN), stage_in_one, &ctx);
-      if (mode16) {
+      if (mode24) {
+        HIPCHK(hipMemcpyAsync(e->d_stage[slot].ptr, e->h_stage[slot].ptr, count * 3, hipMemcpyHostToDevice, e->stream));
+        RCCHK(sla_hip_launch_unpack24((const uint8_t*)e->d_stage[slot].ptr, dst, count, e->stream));
+      } else if (mode16) {
         HIPCHK(hipMemcpyAsync(e->d_stage[slot].ptr, e->h_stage[slot].ptr, count * 2, hipMemcpyHostToDevice, e->stream));
         RCCHK(sla_hip_launch_unpack16((const int16_t*)e->d_stage[slot].ptr, dst, count, e->stream));
       } else {
@@ -2478,7 +2507,7 @@ static int upload_pcm(struct SLAEncoder* e, const int32_t* const* input, uint32_
   const uint32_t C = e->wave_format.num_channels;
   const uint64_t stride = ((uint64_t)n + 63) & ~(uint64_t)63;
   uint32_t ch, lowbits = 0;
-  int mode16 = (e->wave_format.bit_per_sample <= 16), pinned = (n > 0);
+  int mode16 = (e->wave_format.bit_per_sample <= 16) ? 1 : (e->upload24 && e->wave_format.bit_per_sample <= 24) ? 24 : 0, pinned = (n > 0);
   for (ch = 0; ch < C; ch++) { if (input[ch] == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; } }
   RCCHK(dev_reserve(&e->d_pcm, sizeof(int32_t) * (size_t)C * (stride + 64)));
   for (ch = 0; ch < C && pinned; ch++) { pinned = is_pinned_host(input[ch], sizeof(int32_t) * (size_t)n); }

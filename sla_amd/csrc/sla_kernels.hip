@@ -1431,7 +1431,7 @@ void k_acf_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ord
 // Only used where nothing has to match the reference's Levinson recursion bit for bit (the certificate): fused
 // multiply-adds, and NaN as soon as the recursion leaves the positive-definite range.
 template <int P>
-__device__ __forceinline__ double schur_error(const double* __restrict__ rc, double r0, uint32_t order)
+__device__ __forceinline__ double schur_error(const double* __restrict__ rc, double r0, uint32_t order, double& growth)
 {
   const double nan = __longlong_as_double(0x7FF8000000000000ll);
   double u[P + 1], v[P + 2];
@@ -1448,6 +1448,7 @@ __device__ __forceinline__ double schur_error(const double* __restrict__ rc, dou
       bad = bad || !(u[0] > 0.0);
       const double k = -v[1] / u[0];
       bad = bad || !(fabs(k) < 1.0);
+      growth *= 1.0 + fabs(k);                            // prod (1 + |k_j|) >= ||a||_1 of every predictor on the way
 #pragma unroll
       for (int i = 0; i <= P - m; i++) {
         const double t = v[i + 1], ui = u[i];
@@ -1585,15 +1586,22 @@ void k_search_finish(uint32_t order, uint32_t lags, uint32_t gpw, uint32_t per,
           const double delta = ((double)cd.len * u) * r0 + (48.0 * u) * energy;
           const double d = cert * (double)(2 * order + 1) * delta;
           // one copy of the unrolled recursion, run three times (three inlined copies do not fit the instruction cache)
-          double e3[3];
+          double e3[3], g3[3] = {1.0, 1.0, 1.0};
 #pragma unroll 1
           for (int bk = 0; bk < 3; bk++) {
             const double rb = (bk == 0) ? r0 : (bk == 1) ? (r0 + d) : (r0 - d);
             e3[bk] = (bk == 2 && !(r0 - d > (double)FLT_EPSILON)) ? __longlong_as_double(0x7FF8000000000000ll)
-                                                                  : schur_error<P>(rc, rb, order);
+                                                                  : schur_error<P>(rc, rb, order, g3[bk]);
           }
           const double e_mid = e3[0], e_hi = e3[1], e_lo = e3[2];
-          if (e_mid > 0.0 && e_lo > 0.0 && e_hi >= e_mid && e_mid >= e_lo && e_hi < inf) {
+          // The factor cert - 1 on top of the summation bounds is what is left for the rounding of the Levinson-Durbin
+          // recursion itself (the reference's run): to first order it enters stage m through the sum num_m = sum a_i r_(m-i)
+          // with at most (m + 2) 2^-53 ||a^(m-1)||_1 r0, i.e. like an autocorrelation error of that size -- covered by
+          // d = cert (2 order + 1) delta as long as (order + 2) ||a||_1 2^-53 r0 <= (cert - 1) (2 order + 1) delta.
+          // ||a||_1 <= prod (1 + |k_j|) of the most pessimistic bracket end; a candidate beyond that is not certified.
+          const double gmax = fmax(g3[0], fmax(g3[1], g3[2]));
+          const bool rounding_covered = ((double)(order + 2) * gmax * u * r0 <= (cert - 1.0) * (double)(2 * order + 1) * delta);
+          if (rounding_covered && e_mid > 0.0 && e_lo > 0.0 && e_hi >= e_mid && e_mid >= e_lo && e_hi < inf) {
             const double up = log2(e_hi / e_mid), dn = log2(e_mid / e_lo);
             w = ((up > dn) ? up : dn) * 1.000001 + 1e-11;         // (device log2: a few ulp)
             lg = log2(e_mid / r0);
@@ -3881,6 +3889,35 @@ void k_unpack16(const int16_t* __restrict__ in, int32_t* __restrict__ out, uint6
   } else {
     for (uint64_t k = i; k < count; k++) { out[k] = (int32_t)in[k] << 16; }
   }
+}
+
+// k_unpack24: the same for input of <= 24 significant bits that crossed the bus as three bytes per sample (option
+// "upload24"): four samples = three 32-bit words.
+__global__ __launch_bounds__(256)
+void k_unpack24(const uint32_t* __restrict__ in, int32_t* __restrict__ out, uint64_t count)
+{
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // group of four samples
+  const uint64_t i = q * 4;
+  if (i + 4 <= count) {
+    const uint32_t w0 = in[3 * q], w1 = in[3 * q + 1], w2 = in[3 * q + 2];
+    int32_t* o = out + i;
+    o[0] = (int32_t)(w0 << 8);
+    o[1] = (int32_t)(((w0 >> 24) | (w1 << 8)) << 8);
+    o[2] = (int32_t)(((w1 >> 16) | (w2 << 16)) << 8);
+    o[3] = (int32_t)((w2 >> 8) << 8);
+  } else if (i < count) {
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(in);
+    for (uint64_t k = i; k < count; k++) { out[k] = (int32_t)(((uint32_t)b[3 * k] << 8) | ((uint32_t)b[3 * k + 1] << 16) | ((uint32_t)b[3 * k + 2] << 24)); }
+  }
+}
+
+extern "C" int sla_hip_launch_unpack24(const uint8_t* d_in, int32_t* d_out, uint64_t count, sla_hip_stream_t stream)
+{
+  if (d_in == nullptr || d_out == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (count == 0) { return 0; }
+  const uint64_t threads = (count + 3) / 4;
+  hipLaunchKernelGGL(k_unpack24, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)d_in, d_out, count);
+  return hip_rc(hipGetLastError());
 }
 
 extern "C" int sla_hip_launch_unpack16(const int16_t* d_in, int32_t* d_out, uint64_t count, sla_hip_stream_t stream)

@@ -160,3 +160,59 @@ def test_certified_doubles_sit_inside_the_bound(hip, oracle, order, maxb, bits):
             worst = max(worst, float(np.max(dk / eps[1:])))
             certified += 1
     assert certified >= 40 and worst <= 0.25, (certified, flagged, worst)
+
+
+# ------------------------------------------------------------------ the partition search's certificate
+
+@pytest.mark.parametrize("order,bits", [(16, 24), (32, 24), (48, 24), (32, 32)])
+def test_search_certificate_conditioning_sweep(hip, oracle, order, bits):
+    """>= 10^4 windows in all -- pure tones over noise floors from -20 to -140 dB, 24- and 32-bit
+    material, orders 16 / 32 / 48, every window forced over the exactness limit.  For every candidate that carries a
+    finite bracket the reference's value (autocorrelation in ITS order, ITS Levinson-Durbin recursion) must sit within 25 %
+    of the bracket's half width."""
+    import ctypes as C
+    import torch
+    L = hip.lib()
+    L.sla_hip_search_exact_lags.restype = C.c_uint32
+    lags = L.sla_hip_search_exact_lags(order)
+    W_ = 4096
+    cand = sorted({(i * 1024, (j - i) * 1024) for i in range(5) for j in range(i + 2, 5)})
+    nwin = 420
+
+    class Group(C.Structure):
+        _fields_ = [("pcm_off", C.c_uint64)] + [(k, C.c_uint32) for k in (
+            "num_samples", "channel", "win_off", "int_shift", "cand_first", "cand_count", "slot_first", "pad_")]
+
+    worst, bracketed, total = 0.0, 0, 0
+    for fi, floor in enumerate((-20, -40, -60, -90, -120, -140)):
+        n = W_ * nwin
+        pcm = tones(n, bits, float(floor), 1000 * order + fi)
+        groups = (Group * nwin)(*[Group(g * W_, W_, 0, 0xFFFFFFFF, 32 - bits, 0, len(cand), g * len(cand), 0) for g in range(nwin)])
+        d_pcm = torch.from_numpy(pcm).cuda()
+        d_g = torch.frombuffer(bytearray(bytes(groups)), dtype=torch.uint8).cuda()
+        d_c = torch.from_numpy(np.array(cand, np.uint32)).cuda()
+        d_ts = torch.zeros(nwin * 16 * 2 * lags, dtype=torch.float64, device="cuda")
+        d_out = torch.zeros(nwin * len(cand) * (order + 2), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        rc = L.sla_hip_launch_search_exact(C.c_void_p(d_pcm.data_ptr()), C.c_uint64(n), 0, order, C.c_void_p(d_g.data_ptr()), nwin, W_,
+                                           len(cand), C.c_void_p(d_c.data_ptr()), C.c_void_p(d_ts.data_ptr()), C.c_void_p(d_out.data_ptr()),
+                                           C.c_double(0.0), C.c_double(64.0), None, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        out = d_out.cpu().numpy().reshape(nwin, len(cand), order + 2)
+        xd = pcm[0].astype(np.float64) * 2.0 ** -31
+        for g in range(nwin):
+            for i, (s, ln) in enumerate(cand):
+                o = out[g, i]
+                total += 1
+                if not np.isfinite(o[1]):
+                    continue                                       # no bracket: the window is rerun as serial chains
+                xs = np.ascontiguousarray(xd[g * W_ + s:g * W_ + s + ln])
+                r0 = oracle.autocorr(xs, 1)[0]
+                _, par = oracle.parcor(xs, order)
+                ref = np.log2(r0) + np.sum(np.log2(1.0 - par[1:] ** 2))
+                mid = np.log2(o[0]) + o[2]
+                assert abs(ref - mid) <= 0.25 * o[1], (order, bits, floor, g, s, ln, ref - mid, o[1])
+                worst = max(worst, abs(ref - mid) / o[1])
+                bracketed += 1
+    assert total == 6 * nwin * len(cand) and bracketed >= total // 3, (total, bracketed, worst)

@@ -1088,3 +1088,17 @@ def test_c3_full_sixty_minutes(oracle, hip):
 def test_c5_full_thirty_minutes(oracle, hip):
     p = S.make_params(8, 24, 96000, 48, 3, 8, 0, 1, 8192, cap=(8, 8192, 48, 3, 8))
     _full_length_check(oracle, hip, p, (8, 8192, 48, 3, 8), 8, 96000 * 1800, 24, 96000, 6)
+
+
+@pytest.mark.parametrize("nch,bits,n", [(2, 24, 300001), (1, 20, 70000), (3, 24, 4099)])
+def test_upload24_gives_the_same_bytes(oracle, hip, nch, bits, n):
+    """option "upload24": pageable input of <= 24 significant bits crosses the bus as three bytes per sample and is
+    re-expanded by k_unpack24 -- same planes on the device, same file"""
+    pcm = W.music_like(nch, n, bits, seed=n % 97)
+    p = S.make_params(nch, bits, 48000, 16, 1, 8, 0, 1, 4096)
+    ret, want = oracle.encode_whole(p, pcm)
+    assert ret == 0
+    got, _ = _encode_with_options(hip, p, pcm, upload24=1)
+    assert got == want
+    got, _ = _encode_with_options(hip, p, pcm, upload24=1, stream=1, stream_piece=65536)
+    assert got == want
