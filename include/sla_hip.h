@@ -518,8 +518,8 @@ int sla_hip_get_trace(struct SLAEncoder* encoder, sla_hip_trace* trace);
  * instead of one for the file) [SLA_HIP_SINGLE_TAIL], "first_chunk" (1/1000 of the super-frames in pipeline chunk 0;
  * 0: built-in shares), "alt_streams" (block stages of odd and even pipeline chunks on two streams: 0 never, 1 always,
  * 2 = default: for big files, samples x channels x order >= 1e9).  SLAEncoder_EncodeWhole of long files: "stream" (0: never streamed) [SLA_HIP_STREAM],
- * "upload24" (1: pageable input of <= 24 significant bits crosses the bus as three bytes per sample; default 0, see DESIGN
- * section 7 for the A/B) [SLA_HIP_UPLOAD24], "stream_piece" (samples per piece, all channels together; default 32 Mi; a file of fewer than two pieces is not
+ * "upload24" (1 = default: pageable input of 17..24 significant bits crosses the bus as three bytes per sample; DESIGN
+ * section 7 has the A/B) [SLA_HIP_UPLOAD24], "stream_piece" (samples per piece, all channels together; default 32 Mi; a file of fewer than two pieces is not
  * streamed), "stream_lanes" (worker lanes, 1..4, default 4).  After a streamed call the handle holds no analysis tables:
  * sla_hip_get_trace / sla_hip_pack / sla_hip_final_residual answer SLA_APIRESULT_PARAMETER_NOT_SET (NULL).
  * Returns SLA_APIRESULT_INVALID_ARGUMENT for an unknown name or a value out of range. */

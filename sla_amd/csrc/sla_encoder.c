@@ -73,7 +73,7 @@ struct SLAEncoder {
   int      alt_now;                 /* this run's decision */
   int      device_ltm;              /* 1: pitch + taps solved on the device, the block stage runs lattice -> tail without the host (default) */
   int      trace;                   /* host-side timeline on stderr (SLA_HIP_TRACE) */
-  int      upload24;                /* 1: pageable input of <= 24 significant bits crosses the bus as three bytes per sample (k_unpack24); 0 = default, see DESIGN 7 */
+  int      upload24;                /* 1 (default): pageable input of 17..24 significant bits crosses the bus as three bytes per sample (k_unpack24), see DESIGN 7 */
   int      block_cert;              /* 1 (default): chosen blocks through the any-order autocorrelation where their codes and the RAW decision certify,
                                      * the exact chain kernel for the rest; 0: every block through the exact kernel */
   double   block_cert_safety;       /* safety factor on the first-order bound of that certificate (16) */
@@ -365,6 +365,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   }
   e->search_exact = 1; e->exact_bits = 53; e->device_plan = 1; e->cert_safety = 64.0;
   e->block_cert = 1; e->block_cert_safety = 16.0;
+  e->upload24 = 1;      /* profiles/r3_pack24_ab_*.json: plain path +13 % (C3) / +15 % (C5) from pageable memory, streamed path +1..3 % */
   env = getenv("SLA_HIP_BLOCK_CERT");
   if (env != NULL && atof(env) >= 0.0) { e->block_cert = (atof(env) != 0.0); if (atof(env) >= 16.0) { e->block_cert_safety = atof(env); } }
   e->stream_mode = 1; e->stream_piece = 32u << 20; e->stream_lanes = 4;
