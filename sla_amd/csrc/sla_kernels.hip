@@ -1198,6 +1198,42 @@ __device__ __forceinline__ void load4_raw(const int32_t* __restrict__ plane, uin
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The sliding dot products of a 256-sample tile, partners from LDS: lane t owns x[4t .. 4t+3] and pairs every one of them
+// with the `lag` samples BEHIND it -- r[lag] = sum x[m] x[m - lag] -- so a tile only needs the samples in front of it, which
+// the tile before has already staged, and the loads of the next tile can travel while this one is multiplied.  For the lag
+// block 4k .. 4k+3 a lane needs x[4(t-k) - 3 .. 4(t-k) + 3].  The samples lie in LDS as 16-byte pairs, even pairs
+// (x[4i], x[4i+1]) in E and odd pairs (x[4i+2], x[4i+3]) in O, slot HL + i for the tile's own pair i and slots [0, HL) for
+// the HL = NB + 1 pairs in front of the tile: consecutive lanes read consecutive 16-byte slots (no bank conflicts), two
+// ds_read_b128 per 16 FMAs.  (The first form of these kernels moved the partners from lane to lane by DPP: 16 moves per
+// 16 FMAs, the last NB lanes of a pass only supplied partners, and nothing was in flight while a pass computed.)
+// ---------------------------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ void acf_tile_fma(const double (&own)[4], const double2* __restrict__ E, const double2* __restrict__ O,
+                                             uint32_t lane, double (&acc)[NB * 4])
+{
+  constexpr uint32_t HL = NB + 1;
+  const double2* e = E + HL + lane;
+  const double2* o = O + HL + lane;
+  // block k works on P[i] = x[4(t-k) - 3 + i], i = 0 .. 6: (E[-k-1].y, O[-k-1].x, O[-k-1].y, E[-k].x, E[-k].y, O[-k].x, O[-k].y)
+  double2 e0 = make_double2(own[0], own[1]), o0 = make_double2(own[2], own[3]);
+  double2 e1 = e[-1], o1 = o[-1];
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+    double2 e2 = e1, o2 = o1;
+    if (k + 1 < NB) { e2 = e[-k - 2]; o2 = o[-k - 2]; }                    // the next block's new pairs travel under this block's FMAs
+    const double P[7] = {e1.y, o1.x, o1.y, e0.x, e0.y, o0.x, o0.y};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) { acc[4 * k + j] = __builtin_fma(own[q], P[q - j + 3], acc[4 * k + j]); }
+    }
+    e0 = e1; o0 = o1; e1 = e2; o1 = o2;
+  }
+}
+
+#define ACF_TILE 256u
+
 template <int NB>
 __global__ __launch_bounds__(256)
 void k_acf_tiles(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
@@ -1291,14 +1327,13 @@ void k_acf_tiles(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
 
 // ---------------------------------------------------------------------------------------------
 // k_acf_blocks: autocorrelation of the CHOSEN blocks' analysis windows in any summation order (the certified route of
-// the block stage, see k_blocks_finish<.., true>).  One wave per (block, channel) walks the whole window in passes of
-// (64 - NB) * 4 samples with k_acf_tiles' scheme: a lane owns 4 consecutive samples, the partners x[m + lag] of lag block
-// 4k..4k+3 arrive from lanes t+k, t+k+1 by one-lane DPP shifts, 16 FMAs per 8 shifted dwords; the accumulators live
-// in registers across the passes and are reduced over the lanes ONCE per block.  The samples are staged as the
-// reference stages them -- x[s] = w[s]*in[s] - 0.96875 * w[s-1]*in[s-1] (src/SLAEncoder.c:505-515, 540-543,
-// src/SLAPredictor.c:1803-1809): the previous windowed sample comes from the lane below (from the last owning lane of
-// the pass before for lane 0).  Out: slot = { -, r[0..order] } and the quantiser's shift, exactly what k_lpc_blocks hands
-// to k_blocks_finish -- but r[] is the correctly ordered sum only up to the rounding errors of ~48 additions.
+// the block stage, see k_blocks_finish<.., true>).  One wave per (block, channel) walks the whole window in tiles of 256
+// samples (acf_tile_fma); the accumulators live in registers across the tiles and are reduced over the lanes ONCE per
+// block.  The samples are staged as the reference stages them -- x[s] = w[s]*in[s] - 0.96875 * w[s-1]*in[s-1]
+// (src/SLAEncoder.c:505-515, 540-543, src/SLAPredictor.c:1803-1809): the previous windowed sample comes from the lane
+// below (from the last lane of the tile before for lane 0).  Out: slot = { -, r[0..order] } and the quantiser's shift,
+// exactly what k_lpc_blocks hands to k_blocks_finish -- but r[] is the correctly ordered sum only up to the rounding
+// errors of ~48 additions.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double shr1_f64(double v, double first)       // lane t <- lane t-1, lane 0 <- first
 {
@@ -1308,14 +1343,14 @@ __device__ __forceinline__ double shr1_f64(double v, double first)       // lane
 }
 
 template <int NB, bool MS>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, (NB >= 13) ? 3 : 1)      // 52 lags: 104 accumulator registers -- keep three waves per SIMD
 void k_acf_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t order,
                   const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups,
                   const double* __restrict__ window_pool, double* __restrict__ out, uint32_t* __restrict__ out_rshift,
                   unsigned long long* exec_span)
 {
-  constexpr uint32_t OL = 64 - NB;             // lanes of a pass that own samples
-  constexpr uint32_t STEP = OL * 4, LAGS = NB * 4;
+  constexpr uint32_t LAGS = NB * 4, HL = NB + 1;             // HL pairs in front of a tile: all that lags < 4 NB reach
+  __shared__ double2 s_e[4][2][64 + HL], s_o[4][2][64 + HL];
   span_begin(exec_span);
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t gi = blockIdx.x * 4 + wv;
@@ -1327,34 +1362,42 @@ void k_acf_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ord
   const int32_t* p1 = pcm + stride;
   const double* win = window_pool + g.win_off;
 
+  struct raw4 { int32_t a[4]; int32_t b[4]; double w[4]; };
+  auto fetch = [&](uint32_t idx, raw4& r) {      // four consecutive raw samples (both channels for mid/side) and their window values; zero past the block
+    load4_raw(p0, g.pcm_off, idx, N, r.a);
+    if (MS) { load4_raw(p1, g.pcm_off, idx, N, r.b); }
+#pragma unroll
+    for (int q = 0; q < 4; q++) { r.w[q] = (idx + q < N) ? win[idx + q] : 0.0; }
+  };
+
   double acc[LAGS];
 #pragma unroll
   for (int i = 0; i < (int)LAGS; i++) { acc[i] = 0.0; }
   uint32_t maxabs = 0;
-  double carry = 0.0;                          // windowed sample right before the pass (0 before the block: src/SLAPredictor.c:1729-1738)
-  for (uint32_t s0 = 0; s0 < N; s0 += STEP) {
+  double carry = 0.0;                          // windowed sample right before the tile (0 before the block: src/SLAPredictor.c:1729-1738)
+  if (lane < HL) { s_e[wv][0][lane] = make_double2(0.0, 0.0); s_o[wv][0][lane] = make_double2(0.0, 0.0); }      // nothing in front of the block
+  raw4 nxt;
+  fetch(4 * lane, nxt);
+  uint32_t buf = 0;
+  for (uint32_t s0 = 0; s0 < N; s0 += ACF_TILE, buf ^= 1u) {
     const uint32_t idx = s0 + 4 * lane;
-    int32_t ra[4], rb[4];
-    double w[4];
-    load4_raw(p0, g.pcm_off, idx, N, ra);
-    if (MS) { load4_raw(p1, g.pcm_off, idx, N, rb); }
-#pragma unroll
-    for (int q = 0; q < 4; q++) { w[q] = (idx + q < N) ? win[idx + q] : 0.0; }
-    double y[4], cur[4], own[4];
+    const raw4 cur = nxt;
+    if (s0 + ACF_TILE < N) { fetch(idx + ACF_TILE, nxt); }      // the next tile's samples travel while this one is multiplied
+    double y[4], own[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       double v;
       int32_t iv;
       if (MS) {
-        const double l = (double)ra[q] * scale, r = (double)rb[q] * scale;
+        const double l = (double)cur.a[q] * scale, r = (double)cur.b[q] * scale;
         v = (g.channel == 0) ? ((l + r) / 2) : (l - r);
-        const int32_t li = ra[q] >> g.int_shift, ri = rb[q] >> g.int_shift;
+        const int32_t li = cur.a[q] >> g.int_shift, ri = cur.b[q] >> g.int_shift;
         iv = (g.channel == 0) ? ((int32_t)((uint32_t)li + (uint32_t)ri) >> 1) : (int32_t)((uint32_t)li - (uint32_t)ri);
       } else {
-        v = (double)ra[q] * scale;
-        iv = ra[q] >> g.int_shift;
+        v = (double)cur.a[q] * scale;
+        iv = cur.a[q] >> g.int_shift;
       }
-      y[q] = v * w[q];
+      y[q] = v * cur.w[q];
       const uint32_t a = (iv > 0) ? (uint32_t)iv : (0u - (uint32_t)iv);
       maxabs = (a > maxabs) ? a : maxabs;        // (samples past the block are zero)
     }
@@ -1363,26 +1406,20 @@ void k_acf_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ord
     for (int q = 0; q < 4; q++) {
       const double pv = (q == 0) ? below : y[q - 1];
       const double x = y[q] - pv * 0.96875;
-      cur[q] = (idx + q < N) ? x : 0.0;
-      own[q] = (lane < OL) ? cur[q] : 0.0;
+      own[q] = (idx + q < N) ? x : 0.0;
     }
-    carry = readlane_f64(y[3], (int)OL - 1);
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-      double nxt[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) { nxt[q] = shl1_f64(cur[q]); }
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const double partner = (q + j < 4) ? cur[q + j] : nxt[q + j - 4];
-          acc[4 * k + j] = __builtin_fma(own[q], partner, acc[4 * k + j]);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; q++) { cur[q] = nxt[q]; }
+    carry = readlane_f64(y[3], 63);
+    double2* E = s_e[wv][buf];
+    double2* O = s_o[wv][buf];
+    E[HL + lane] = make_double2(own[0], own[1]);
+    O[HL + lane] = make_double2(own[2], own[3]);
+    if (lane >= 64 - HL) {                     // this tile's last HL pairs are what the next tile finds in front of it
+      s_e[wv][buf ^ 1u][lane - (64 - HL)] = make_double2(own[0], own[1]);
+      s_o[wv][buf ^ 1u][lane - (64 - HL)] = make_double2(own[2], own[3]);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    acf_tile_fma<NB>(own, E, O, lane, acc);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   double* o = out + (uint64_t)g.slot_first * (order + 2);
   {
