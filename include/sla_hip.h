@@ -516,8 +516,8 @@ int sla_hip_get_trace(struct SLAEncoder* encoder, sla_hip_trace* trace);
  * [SLA_HIP_LATTICE=fused], "device_ltm" (0: long-term pitch + taps solved on the host threads from the downloaded
  * autocorrelations, one k_tail per pipeline chunk) [SLA_HIP_LTM=host], "single_tail" (0: one k_tail per pipeline chunk
  * instead of one for the file) [SLA_HIP_SINGLE_TAIL], "first_chunk" (1/1000 of the super-frames in pipeline chunk 0;
- * 0: built-in shares), "alt_streams" (block stages of odd and even pipeline chunks on two streams: 0 never, 1 always,
- * 2 = default: for big files, samples x channels x order >= 1e9).  SLAEncoder_EncodeWhole of long files: "stream" (0: never streamed) [SLA_HIP_STREAM],
+ * 0: built-in shares), "alt_streams" (block stages of odd and even pipeline chunks on two streams: 0 never, 1 / 2 = default:
+ * whenever the file is cut into chunks).  SLAEncoder_EncodeWhole of long files: "stream" (0: never streamed) [SLA_HIP_STREAM],
  * "upload24" (1 = default: pageable input of 17..24 significant bits crosses the bus as three bytes per sample; DESIGN
  * section 7 has the A/B) [SLA_HIP_UPLOAD24], "stream_piece" (samples per piece, all channels together; default 32 Mi; a file of fewer than two pieces is not
  * streamed), "stream_lanes" (worker lanes, 1..4, default 4).  After a streamed call the handle holds no analysis tables:

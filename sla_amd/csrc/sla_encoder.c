@@ -69,7 +69,7 @@ struct SLAEncoder {
   int      chunks_forced;           /* the caller chose the chunk count: no short-file rule */
   uint32_t first_chunk;             /* 1/1000 of the super-frames in chunk 0 (0: built-in shares) */
   int      single_tail;             /* 1: one k_tail launch for all chunks (default) */
-  int      alt_streams;             /* option: 0 never, 1 always, 2 (default) for big files -- the block stages of odd and even chunks on two streams */
+  int      alt_streams;             /* option: 0 never, 1 / 2 (default) whenever chunked -- the block stages of odd and even chunks on two streams */
   int      alt_now;                 /* this run's decision */
   int      device_ltm;              /* 1: pitch + taps solved on the device, the block stage runs lattice -> tail without the host (default) */
   int      trace;                   /* host-side timeline on stderr (SLA_HIP_TRACE) */
@@ -1589,11 +1589,11 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   if (want_chunks > MAX_CHUNKS) { want_chunks = MAX_CHUNKS; }
   if (want_chunks < 1) { want_chunks = 1; }
   a.nchunks = want_chunks;
-  /* big files (throughput-bound kernels): the block stages of the two chunks on two streams, so that one chunk's lattice /
-   * FFT kernels fill the gaps of the other's k_lpc_blocks -- C3-600 s 5.29 -> 5.13 ms, C5-120 s 11.12 -> 10.74 with a
-   * 40 % first chunk; a ten-minute mono file loses (2.32 -> 2.43 ms: its kernels are too short to share the device) */
-  e->alt_now = (e->alt_streams == 1)
-            || (e->alt_streams == 2 && (uint64_t)e->num_samples * C * e->encode_param.parcor_order >= 1000000000ull);
+  /* the block stages of the two chunks on two streams, so that one chunk's lattice / FFT kernels fill the gaps of the
+   * other's block stage.  Round 2 kept this to big files (k_lpc_blocks of a ten-minute mono file was too short to share
+   * the device: 2.32 -> 2.43 ms); with the certified block stage of round 3 the ten-minute mono file gains the most
+   * (1.61 -> 1.52 ms), C3-600 s 3.03 -> 2.96, C5-120 s 5.26 -> 5.33 (within the run-to-run spread): on whenever chunked */
+  e->alt_now = (e->alt_streams != 0);
   if (!(e->device_ltm && e->single_tail) || a.nchunks < 2) { e->alt_now = 0; }
   /* chunk boundaries in 1/1000 of the super-frames: equal parts unless SLA_HIP_CHUNK_SPLIT gave the shares */
   if (e->first_chunk != 0 && a.nchunks >= 2) {

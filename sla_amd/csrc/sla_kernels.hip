@@ -1622,26 +1622,29 @@ void k_search_finish(uint32_t order, uint32_t lags, uint32_t gpw, uint32_t per,
         if (cd.len >= order && r0 > 2.0 * (double)FLT_EPSILON) {     // (the reference zeroes the coefficients below FLT_EPSILON, src/SLAPredictor.c:274)
           const double delta = ((double)cd.len * u) * r0 + (48.0 * u) * energy;
           const double d = cert * (double)(2 * order + 1) * delta;
-          // one copy of the unrolled recursion, run three times (three inlined copies do not fit the instruction cache)
-          double e3[3], g3[3] = {1.0, 1.0, 1.0};
+          // one copy of the unrolled recursion, run for both ends of the bracket (inlined copies do not fit the instruction
+          // cache).  The value handed to k_plan is the middle of the bracket in the logarithm, which is where the width applies:
+          // log2(e_p) of the reference lies in [log2 e_lo, log2 e_hi] = mid +- w.  (A third recursion on the unshifted sums,
+          // used as the middle until round 3, bought nothing but a third of this kernel's time.)
+          double e2[2], g2[2] = {1.0, 1.0};
 #pragma unroll 1
-          for (int bk = 0; bk < 3; bk++) {
-            const double rb = (bk == 0) ? r0 : (bk == 1) ? (r0 + d) : (r0 - d);
-            e3[bk] = (bk == 2 && !(r0 - d > (double)FLT_EPSILON)) ? __longlong_as_double(0x7FF8000000000000ll)
-                                                                  : schur_error<P>(rc, rb, order, g3[bk]);
+          for (int bk = 0; bk < 2; bk++) {
+            const double rb = (bk == 0) ? (r0 + d) : (r0 - d);
+            e2[bk] = (bk == 1 && !(r0 - d > (double)FLT_EPSILON)) ? __longlong_as_double(0x7FF8000000000000ll)
+                                                                  : schur_error<P>(rc, rb, order, g2[bk]);
           }
-          const double e_mid = e3[0], e_hi = e3[1], e_lo = e3[2];
+          const double e_hi = e2[0], e_lo = e2[1];
           // The factor cert - 1 on top of the summation bounds is what is left for the rounding of the Levinson-Durbin
           // recursion itself (the reference's run): to first order it enters stage m through the sum num_m = sum a_i r_(m-i)
           // with at most (m + 2) 2^-53 ||a^(m-1)||_1 r0, i.e. like an autocorrelation error of that size -- covered by
           // d = cert (2 order + 1) delta as long as (order + 2) ||a||_1 2^-53 r0 <= (cert - 1) (2 order + 1) delta.
-          // ||a||_1 <= prod (1 + |k_j|) of the most pessimistic bracket end; a candidate beyond that is not certified.
-          const double gmax = fmax(g3[0], fmax(g3[1], g3[2]));
+          // ||a||_1 <= prod (1 + |k_j|) of the more pessimistic bracket end; a candidate beyond that is not certified.
+          const double gmax = fmax(g2[0], g2[1]);
           const bool rounding_covered = ((double)(order + 2) * gmax * u * r0 <= (cert - 1.0) * (double)(2 * order + 1) * delta);
-          if (rounding_covered && e_mid > 0.0 && e_lo > 0.0 && e_hi >= e_mid && e_mid >= e_lo && e_hi < inf) {
-            const double up = log2(e_hi / e_mid), dn = log2(e_mid / e_lo);
-            w = ((up > dn) ? up : dn) * 1.000001 + 1e-11;         // (device log2: a few ulp)
-            lg = log2(e_mid / r0);
+          if (rounding_covered && e_lo > 0.0 && e_hi >= e_lo && e_hi < inf) {
+            const double lh = log2(e_hi / r0), ll = log2(e_lo / r0);
+            w = 0.5 * (lh - ll) * 1.000001 + 1e-11;               // (device log2: a few ulp)
+            lg = 0.5 * (lh + ll);
           }
         }
         o[0] = r0;
