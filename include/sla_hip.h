@@ -241,6 +241,34 @@ int sla_hip_launch_plan(const sla_hip_lpc_group* d_groups, uint32_t num_superfra
                         double* d_lpc_out, uint32_t* d_parts, uint32_t* d_num_parts, uint32_t* d_status,
                         sla_hip_stream_t stream);
 
+/* Block table of one run of super-frames from sla_hip_launch_plan's partitions, written on the device, so that the
+ * block-stage kernels can follow the partition search without the host building and uploading their descriptors
+ * (the host part of src/SLAEncoder.c:846-869: the walk over the super-frames that numbers the blocks).
+ * d_superframes: the run, in file order.  A live super-frame names its row of d_parts / d_num_parts / d_status; one
+ * that is a single SILENT block (live == SLA_HIP_NOT_LIVE) takes one block index and produces no group.  No block of
+ * a live super-frame is treated as silent: the caller uses this only for input whose non-zero mask has no all-zero
+ * word (sla_hip_launch_prepass: d_or_mask[1] == 0), where a block of SLA's minimum length cannot be.
+ * Per (block, channel), numbered on from d_run[0] blocks / d_run[1] groups: d_groups[g] (windowed form: win_off looked
+ * up by block length in the d_win_len / d_win_off list, cand_first = g, slot_first = block * num_channels + channel),
+ * d_cands[g] = {0, length}, d_acf_jobs[g].  counts (which may be page-locked host memory: the caller can poll
+ * counts[3]): [0] blocks and [1] groups of this run, [2] 1 = tables valid, 0 = some super-frame was not certified
+ * (d_status != 0), a length has no window, the tables are full or an earlier run failed (d_run[2] != 0) -- nothing
+ * may be launched from them, and every later run on the same d_run fails too; [3] = sequence, written last. */
+#define SLA_HIP_NOT_LIVE 0xFFFFFFFFu
+typedef struct sla_hip_superframe {
+  uint32_t start;          /* first sample */
+  uint32_t window;         /* samples (a SILENT one: the length of the zero run) */
+  uint32_t live;           /* row of the plan's arrays, or SLA_HIP_NOT_LIVE */
+  uint32_t pad_;
+} sla_hip_superframe;
+int sla_hip_launch_expand(const sla_hip_superframe* d_superframes, uint32_t num_superframes,
+                          const uint32_t* d_parts, const uint32_t* d_num_parts, const uint32_t* d_status,
+                          uint32_t num_channels, uint32_t int_shift,
+                          const uint32_t* d_win_len, const uint32_t* d_win_off, uint32_t num_windows,
+                          uint32_t* d_run, sla_hip_lpc_group* d_groups, sla_hip_lpc_cand* d_cands,
+                          sla_hip_acf_job* d_acf_jobs, uint32_t group_capacity,
+                          uint32_t* counts, uint32_t sequence, sla_hip_stream_t stream);
+
 /* Building blocks of the per-call predictor API (include/SLAPredictor.h), also usable on their own:
  *   sla_hip_launch_lpc_f64      sla_hip_launch_lpc in its search form on samples that already are doubles
  *                               (group.pcm_off indexes d_samples; no conversion, window or pre-emphasis)
@@ -539,6 +567,10 @@ int sla_hip_last_counters(const struct SLAEncoder* encoder, uint32_t* counters);
 /* 2 counters of the last analysis: 1 if the block stage took the certified route (sla_hip_launch_lpc_blocks_cert);
  * (block, channel) pairs its certificate handed to the exact chain kernels. */
 int sla_hip_last_block_cert(const struct SLAEncoder* encoder, uint32_t* counters);
+
+/* 2 counters of the last analysis: pipeline chunks whose block stage was launched from device-written tables
+ * (sla_hip_launch_expand; option "device_expand"), pipeline chunks in all. */
+int sla_hip_last_expand(const struct SLAEncoder* encoder, uint32_t* counters);
 
 /* 4 floats [ms]: execution time of k_lpc_blocks, k_lattice, k_ltm_acf, k_tail in the last analysis, summed over
  * its launches and measured ON the device (first wave in to last wave out, constant 100 MHz clock) -- what

@@ -79,6 +79,10 @@ struct SLAEncoder {
   double   block_cert_safety;       /* safety factor on the first-order bound of that certificate (16) */
   volatile int cert_broken;         /* a block flagged by the certificate was not redone (internal error) */
   int      cert_now;                /* this run's block stage takes the certified route */
+  int      device_expand;           /* 1 (default): the block table of certified partitions is written on the device (k_expand) and the block
+                                     * stage launched from two counts, the host's own tables following under the kernels; 0: host tables first */
+  uint32_t expand_seq;              /* sequence number of the last k_expand launch (what the host polls for) */
+  uint32_t expanded_chunks;         /* last analysis: pipeline chunks whose block stage was launched from device tables */
   uint32_t blocks_exact;            /* last analysis: (block, channel) pairs the certificate handed to the exact kernel */
   sla_hip_tuning tune;              /* launcher knobs, named to the launchers at every API entry */
   uint32_t host_planned;            /* last analysis: super-frames whose partition the host had to decide */
@@ -91,11 +95,13 @@ struct SLAEncoder {
   /* device workspace */
   devbuf_t d_pcm, d_res1, d_res2, d_or, d_nz, d_groups, d_cands, d_lpc_out, d_code, d_kint, d_rshift,
            d_winpool, d_chunks, d_jobs, d_fold, d_acf_jobs, d_acf, d_acf_scratch, d_twiddle, d_bgroups, d_bcands, d_blk_out, d_kk, d_pk_jobs, d_pk_blocks, d_pk_hdr, d_image,
-           d_xgroups, d_tile_sums, d_fgroups, d_parts, d_nparts, d_pstatus, d_spans, d_cert_flag, d_fb_list, d_fb_count;
+           d_xgroups, d_tile_sums, d_fgroups, d_parts, d_nparts, d_pstatus, d_spans, d_cert_flag, d_fb_list, d_fb_count,
+           d_sframes, d_winmap, d_run;
   int twiddle_ready;
   /* pinned host staging */
   pinbuf_t h_nz, h_groups, h_cands, h_lpc_out, h_code, h_kint, h_rshift, h_chunks, h_jobs, h_fold, h_res, h_pcm, h_acf_jobs, h_acf,
-           h_bgroups, h_bcands, h_blk_out, h_pk_jobs, h_pk_blocks, h_pk_hdr, h_xgroups, h_fgroups, h_parts, h_nparts, h_pstatus, h_cert_flag;
+           h_bgroups, h_bcands, h_blk_out, h_pk_jobs, h_pk_blocks, h_pk_hdr, h_xgroups, h_fgroups, h_parts, h_nparts, h_pstatus, h_cert_flag,
+           h_sframes, h_winmap, h_counts;
   uint32_t* h_or;
   size_t nz_ones_cap; uint64_t nz_ones_words;    /* h_nz words [0, nz_ones_words) are known to be all ones (h_nz.cap == nz_ones_cap) */
   pinbuf_t h_stage[2]; devbuf_t d_stage[2]; hipEvent_t ev_stage[2];
@@ -365,6 +371,9 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   }
   e->search_exact = 1; e->exact_bits = 53; e->device_plan = 1; e->cert_safety = 64.0;
   e->block_cert = 1; e->block_cert_safety = 16.0;
+  e->device_expand = 1;
+  env = getenv("SLA_HIP_EXPAND");
+  if (env != NULL) { e->device_expand = (atoi(env) != 0); }
   e->upload24 = 1;      /* profiles/r3_pack24_ab_*.json: plain path +13 % (C3) / +15 % (C5) from pageable memory, streamed path +1..3 % */
   env = getenv("SLA_HIP_BLOCK_CERT");
   if (env != NULL && atof(env) >= 0.0) { e->block_cert = (atof(env) != 0.0); if (atof(env) >= 16.0) { e->block_cert_safety = atof(env); } }
@@ -437,8 +446,8 @@ fail:
 
 void SLAEncoder_Destroy(struct SLAEncoder* e)
 {
-  devbuf_t* d[37];
-  pinbuf_t* h[26];
+  devbuf_t* d[40];
+  pinbuf_t* h[29];
   int i;
   if (e == NULL) { return; }
   for (i = 0; i < 4; i++) { SLAEncoder_Destroy(e->lane[i]); e->lane[i] = NULL; }
@@ -457,13 +466,15 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   d[27] = &e->d_xgroups; d[28] = &e->d_tile_sums; d[29] = &e->d_fgroups;
   d[30] = &e->d_parts; d[31] = &e->d_nparts; d[32] = &e->d_pstatus; d[33] = &e->d_spans;
   d[34] = &e->d_cert_flag; d[35] = &e->d_fb_list; d[36] = &e->d_fb_count;
-  for (i = 0; i < 37; i++) { if (d[i]->ptr != NULL) { (void)hipFree(d[i]->ptr); } }
+  d[37] = &e->d_sframes; d[38] = &e->d_winmap; d[39] = &e->d_run;
+  for (i = 0; i < 40; i++) { if (d[i]->ptr != NULL) { (void)hipFree(d[i]->ptr); } }
   h[0] = &e->h_nz; h[1] = &e->h_groups; h[2] = &e->h_cands; h[3] = &e->h_lpc_out; h[4] = &e->h_code; h[5] = &e->h_kint;
   h[6] = &e->h_rshift; h[7] = &e->h_chunks; h[8] = &e->h_jobs; h[9] = &e->h_fold; h[10] = &e->h_res; h[11] = &e->h_pcm;
   h[12] = &e->h_acf_jobs; h[13] = &e->h_acf; h[14] = &e->h_bgroups; h[15] = &e->h_bcands; h[16] = &e->h_blk_out;
   h[17] = &e->h_pk_jobs; h[18] = &e->h_pk_blocks; h[19] = &e->h_pk_hdr; h[20] = &e->h_xgroups; h[21] = &e->h_fgroups;
   h[22] = &e->h_parts; h[23] = &e->h_nparts; h[24] = &e->h_pstatus; h[25] = &e->h_cert_flag;
-  for (i = 0; i < 26; i++) { if (h[i]->ptr != NULL) { (void)hipHostFree(h[i]->ptr); } }
+  h[26] = &e->h_sframes; h[27] = &e->h_winmap; h[28] = &e->h_counts;
+  for (i = 0; i < 29; i++) { if (h[i]->ptr != NULL) { (void)hipHostFree(h[i]->ptr); } }
   if (e->h_or != NULL) { (void)hipHostFree(e->h_or); }
   if (e->d_tile_or.ptr != NULL) { (void)hipFree(e->d_tile_or.ptr); }
   if (e->h_tile_or.ptr != NULL) { (void)hipHostFree(e->h_tile_or.ptr); }
@@ -572,7 +583,7 @@ static int blocks_push(struct SLAEncoder* e, uint32_t start, uint32_t nsmpl, uin
 
 #define MAX_CHUNKS 8
 enum { EV_SEARCH_S, EV_SEARCH_E, EV_SEARCH_DONE, EV_LPCB_S, EV_LPCB_E, EV_LAT_E, EV_ACF_S, EV_ACF_E, EV_BLOCK_DONE,
-       EV_TAIL_S, EV_TAIL_E, EV_TAIL_DONE, EV_UPLOADED, EV_PLANNED, EV_UPLOADED2, EV_LPC_DOWN, EV_SOLVED, EV_PER_CHUNK };
+       EV_TAIL_S, EV_TAIL_E, EV_TAIL_DONE, EV_UPLOADED, EV_PLANNED, EV_UPLOADED2, EV_LPC_DOWN, EV_SOLVED, EV_EXPANDED, EV_PER_CHUNK };
 typedef char ev_array_holds_every_chunk[(2 + MAX_CHUNKS * EV_PER_CHUNK <= 2 + 8 * 20) ? 1 : -1];
 
 typedef struct { uint32_t start, window, min_blk, shape, slot_base, grp_lo, grp_hi, xg; } sframe_t;
@@ -600,6 +611,11 @@ typedef struct {
   uint32_t *parts, *nparts; int* status;          /* per super-frame plan results        */
   chunk_t ck[MAX_CHUNKS]; uint32_t nchunks;
   hipEvent_t* ev;                                 /* [nchunks][EV_PER_CHUNK]             */
+  /* device-written block tables (k_expand) */
+  int expand;                                     /* this run asks for them                       */
+  uint32_t dev_blk, dev_bg;                       /* blocks / groups numbered by the device so far */
+  uint8_t launched[MAX_CHUNKS];                   /* the chunk's block stage runs from them        */
+  uint32_t dev_lo[MAX_CHUNKS][4];                 /* blk_lo, blk_hi, bg_lo, bg_hi it was launched with */
 } actx_t;
 
 typedef struct {
@@ -864,6 +880,26 @@ static int upload_search_tables(struct SLAEncoder* e, const actx_t* a)
   if (a->nsgroups > 0) {
     HIPCHK(hipMemcpyAsync(e->d_groups.ptr, e->h_groups.ptr, sizeof(sla_hip_lpc_group) * a->nsgroups, hipMemcpyHostToDevice, e->stream));
   }
+  if (e->device_expand && e->device_plan && e->nsegs == 0 && a->nsf > 0 && e->win_entries > 0) {
+    /* what k_expand reads: the super-frames in file order and the window offset of every block length */
+    const uint32_t C = e->wave_format.num_channels;
+    sla_hip_superframe* hs; uint32_t* hw; uint32_t i;
+    RCCHK(pin_reserve(&e->h_sframes, sizeof(sla_hip_superframe) * a->nsf));
+    RCCHK(dev_reserve(&e->d_sframes, sizeof(sla_hip_superframe) * a->nsf));
+    RCCHK(pin_reserve(&e->h_winmap, sizeof(uint32_t) * 2 * e->win_entries));
+    RCCHK(dev_reserve(&e->d_winmap, sizeof(uint32_t) * 2 * e->win_entries));
+    RCCHK(dev_reserve(&e->d_run, 16));
+    RCCHK(pin_reserve(&e->h_counts, sizeof(uint32_t) * 4 * MAX_CHUNKS));
+    hs = (sla_hip_superframe*)e->h_sframes.ptr; hw = (uint32_t*)e->h_winmap.ptr;
+    for (i = 0; i < a->nsf; i++) {
+      hs[i].start = a->sf[i].start; hs[i].window = a->sf[i].window; hs[i].pad_ = 0;
+      hs[i].live = (a->sf[i].shape == 0xFFFFFFFFu) ? SLA_HIP_NOT_LIVE : a->sf[i].xg / C;
+    }
+    for (i = 0; i < e->win_entries; i++) { hw[i] = e->win_len[i]; hw[e->win_entries + i] = e->win_off[i]; }
+    HIPCHK(hipMemcpyAsync(e->d_sframes.ptr, hs, sizeof(sla_hip_superframe) * a->nsf, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_winmap.ptr, hw, sizeof(uint32_t) * 2 * e->win_entries, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(e->d_run.ptr, 0, 16, e->stream));
+  }
   return 0;
 }
 
@@ -980,6 +1016,12 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
   }
   a->exact = (e->search_exact && SLAI_SEARCH_DELTA == SLA_HIP_XTILE && maxb <= SLA_HIP_XTILE * SLA_HIP_XTILES
               && sla_hip_search_exact_lags(order) != 0 && e->h_or[0] != 0);
+  /* Block tables on the device (k_expand) where no block inside a searched super-frame can be SILENT: the mask has no
+   * all-zero word (or the caller vouched for that), so no run of zeros reaches SLA's minimum block length; whole SILENT
+   * super-frames (only the file's last one can be, then) are in the table the kernel reads. */
+  a->expand = (e->device_expand && e->device_plan && e->nsegs == 0 && !rebuild && e->h_or[1] == 0 && a->nsf > 0
+               && e->win_entries > 0 && e->win_entries <= 256 && a->max_window <= MAX_ANALYSIS_WINDOW
+               && e->d_sframes.ptr != NULL && e->h_counts.ptr != NULL);
   return 0;
 }
 
@@ -1121,6 +1163,20 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
                                 (double*)e->d_lpc_out.ptr, (uint32_t*)e->d_parts.ptr + (size_t)live_lo * SLA_HIP_PLAN_NODES,
                                 (uint32_t*)e->d_nparts.ptr + live_lo, (uint32_t*)e->d_pstatus.ptr + live_lo, e->stream));
       HIPCHK(hipEventRecord(ev[EV_PLANNED], e->stream));
+      if (a->expand) {
+        /* the chunk's block table, written on the device right behind the plan; two counts (polled in page-locked memory)
+         * are all the host needs to launch the block stage -- its own copy of the tables follows under those kernels */
+        volatile uint32_t* hc = (volatile uint32_t*)e->h_counts.ptr + 4 * (size_t)c;
+        const uint32_t bps = e->wave_format.bit_per_sample;
+        hc[0] = hc[1] = hc[2] = hc[3] = 0;
+        RCCHK(sla_hip_launch_expand((const sla_hip_superframe*)e->d_sframes.ptr + k->sf_lo, k->sf_hi - k->sf_lo,
+                                    (const uint32_t*)e->d_parts.ptr, (const uint32_t*)e->d_nparts.ptr, (const uint32_t*)e->d_pstatus.ptr,
+                                    C, 32 - bps + e->lshift, (const uint32_t*)e->d_winmap.ptr, (const uint32_t*)e->d_winmap.ptr + e->win_entries,
+                                    e->win_entries, (uint32_t*)e->d_run.ptr, (sla_hip_lpc_group*)e->d_bgroups.ptr, (sla_hip_lpc_cand*)e->d_bcands.ptr,
+                                    (sla_hip_acf_job*)e->d_acf_jobs.ptr, a->blocks_bound * C, (uint32_t*)e->h_counts.ptr + 4 * (size_t)c,
+                                    e->expand_seq, e->stream));
+        HIPCHK(hipEventRecord(ev[EV_EXPANDED], e->stream));
+      }
       {
         /* The three small result copies stay on the search stream, in order behind k_plan.  On the download stream
          * they would sit there waiting for every chunk's search in turn, in front of whatever shares that stream's
@@ -1242,8 +1298,11 @@ static int tail_enqueue(struct SLAEncoder* e, actx_t* a, uint32_t c, uint32_t lo
   return 0;
 }
 
-/* stage 2 of chunk c: windowed LPC + quantiser, lattice, long-term FFT for blocks [blk_lo, blk_hi) */
-static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
+/* stage 2 of chunk c: windowed LPC + quantiser, lattice, long-term FFT for blocks [blk_lo, blk_hi).
+ * mode 0: host tables, their upload, the launches.  With device-written tables (k_expand) the two halves come apart:
+ * mode 1 launches from the counts in a->dev_lo[c] alone, mode 2 -- later, under those kernels -- builds the host's
+ * own tables from the partitions that have come home meanwhile and checks that both sides numbered alike. */
+static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c, int mode)
 {
   chunk_t* k = &a->ck[c];
   const uint32_t C = e->wave_format.num_channels, bps = e->wave_format.bit_per_sample;
@@ -1266,10 +1325,17 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
    * works in the shared global scratch) */
   hipStream_t bs = (e->alt_now && e->device_ltm && e->single_tail && (c & 1u)
                     && sizeof(double) * (size_t)fft_size <= SLA_HIP_LDS_BUDGET) ? e->stream3 : e->stream2;
-  const size_t slot_lo = (size_t)k->blk_lo * C, nsl = (size_t)(k->blk_hi - k->blk_lo) * C;
+  size_t slot_lo, nsl;
 
+  if (mode == 1) {
+    k->blk_lo = a->dev_lo[c][0]; k->blk_hi = a->dev_lo[c][1]; k->bg_lo = a->dev_lo[c][2]; k->bg_hi = a->dev_lo[c][3];
+    k->lc_lo = k->lc_hi = a->nlc;
+    max_window = a->max_window;
+    if (e->device_ltm) { k->job_lo = k->bg_lo; k->job_hi = k->bg_hi; }
+  }
   /* pass 1: what k_lpc_blocks needs (one group per block and channel).  The descriptors of the lattice and FFT
    * launches are built in pass 2, while k_lpc_blocks is already running. */
+  if (mode != 1) {
   k->bg_lo = a->nbg; k->lc_lo = a->nlc;
   for (b = k->blk_lo; b < k->blk_hi; b++) {
     const blk_t* blk = &e->blk[b];
@@ -1290,8 +1356,15 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     if (blk->nsmpl > max_window) { max_window = blk->nsmpl; }
   }
   k->bg_hi = a->nbg;
-  ng = k->bg_hi - k->bg_lo;
   if (e->device_ltm) { k->job_lo = k->bg_lo; k->job_hi = k->bg_hi; a->njobs = a->nbg; }
+  }
+  if (mode == 2) {
+    k->lc_hi = a->nlc;
+    return (k->blk_lo == a->dev_lo[c][0] && k->blk_hi == a->dev_lo[c][1] && k->bg_lo == a->dev_lo[c][2] && k->bg_hi == a->dev_lo[c][3])
+           ? 0 : SLA_APIRESULT_NG;
+  }
+  ng = k->bg_hi - k->bg_lo;
+  slot_lo = (size_t)k->blk_lo * C; nsl = (size_t)(k->blk_hi - k->blk_lo) * C;
 
   if (ng == 0) { k->lc_hi = a->nlc; HIPCHK(hipEventRecord(ev[EV_LPCB_S], bs)); }
   if (ng > 0) {
@@ -1299,12 +1372,16 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     sla_hip_lattice_chunk* dl = (sla_hip_lattice_chunk*)e->d_chunks.ptr + k->lc_lo;
     sla_hip_acf_job* da = (sla_hip_acf_job*)e->d_acf_jobs.ptr + k->bg_lo;
     uint32_t slots = 0;
+    if (mode == 0) {
     HIPCHK(hipMemcpyAsync(dg, groups + k->bg_lo, sizeof(sla_hip_lpc_group) * ng, hipMemcpyHostToDevice, e->stream_up));
     HIPCHK(hipMemcpyAsync((sla_hip_lpc_cand*)e->d_bcands.ptr + k->bg_lo, cands + k->bg_lo, sizeof(sla_hip_lpc_cand) * ng, hipMemcpyHostToDevice, e->stream_up));
     /* (k_lpc_blocks writes every output slot of its groups; slots of silent blocks are never read) */
     /* uploads and result downloads travel on their own streams: the kernel stream runs kernel after kernel */
     HIPCHK(hipEventRecord(ev[EV_UPLOADED], e->stream_up));
     HIPCHK(hipStreamWaitEvent(bs, ev[EV_UPLOADED], 0));
+    } else {
+      HIPCHK(hipStreamWaitEvent(bs, ev[EV_EXPANDED], 0));      /* the tables were written on the search stream */
+    }
     HIPCHK(hipEventRecord(ev[EV_LPCB_S], bs));
     slai_next_launch_span(SPAN_SLOT(e, c, 0));
     if (fused) {
@@ -1339,7 +1416,7 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     }
     HIPCHK(hipEventRecord(ev[EV_LPC_DOWN], e->stream_down));
     /* pass 2 (k_lpc_blocks is running): lattice chunks and FFT jobs */
-    {
+    if (mode == 0) {
       uint32_t g = k->bg_lo;
       for (b = k->blk_lo; b < k->blk_hi; b++) {
         const blk_t* blk = &e->blk[b];
@@ -1525,6 +1602,23 @@ static void finish_rice(struct SLAEncoder* e, const actx_t* a)
   }
 }
 
+/* wait for k_expand's counts of one chunk: the kernel writes them into page-locked memory, the sequence word last, so the
+ * host sees them a few microseconds after the kernel's last store instead of an event's completion latency later.  The
+ * event is the safety net (a platform whose host memory the device writes through a cache the CPU does not snoop). */
+static int wait_counts(volatile const uint32_t* hc, uint32_t seq, hipEvent_t done)
+{
+  uint32_t spins = 0;
+  for (;;) {
+    if (hc[3] == seq) { __sync_synchronize(); return 0; }
+    if ((++spins & 1023u) == 0) {
+      const hipError_t q = hipEventQuery(done);
+      if (q == hipSuccess) { __sync_synchronize(); return (hc[3] == seq) ? 0 : SLA_APIRESULT_NG; }
+      if (q != hipErrorNotReady) { return SLA_APIRESULT_NG; }
+    }
+    __asm__ volatile("" ::: "memory");
+  }
+}
+
 static float ev_ms(hipEvent_t s, hipEvent_t t) { float ms = 0.f; return (hipEventElapsedTime(&ms, s, t) == hipSuccess) ? ms : 0.f; }
 
 /* run the pipeline.  preset_blocks != 0: the block table is already in e->blk (EncodeBlock), no search. */
@@ -1539,11 +1633,13 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   actx_t a;
   uint32_t c, i, want_chunks;
   double t_host = 0.0, t0;
-  int rc = 0;
+  int rc = 0, tail_queued = 0;
   memset(&a, 0, sizeof(a));
   a.ev = e->ev + 2;
 
   e->fallback_groups = 0; e->host_planned = 0; e->blocks_exact = 0; e->cert_broken = 0;
+  e->expanded_chunks = 0;
+  e->expand_seq += 1; if (e->expand_seq == 0) { e->expand_seq = 1; }
   e->cert_now = (e->block_cert && !(e->fuse_lattice && e->encode_param.parcor_order <= 64) && !e->tune.lpc_blocks_chains
                  && sla_hip_search_exact_lags(e->encode_param.parcor_order) != 0);
   if (!preset_blocks) {
@@ -1585,6 +1681,10 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   /* chunks pay off once the kernels are throughput-bound; a short file (a 10-second clip: 118 super-frames) is one
    * block's serial LMS / Rice chain per stage however it is cut, and every extra chunk adds one more of those */
   if (preset_blocks || (a.nsf < 1024 && !e->chunks_forced)) { want_chunks = 1; }
+  /* Chunks exist to plan one part of the file on the host while the device works on another.  With device-written block
+   * tables nothing waits for the host, and one chunk saves the second set of launches and of half-filled kernels
+   * (tests/tools/chunk_sweep.py: C2 1.57 -> 1.39 ms, C3-600 s 2.89 -> 2.82, C5-120 s 5.15 -> 5.05) */
+  if (a.expand && !e->chunks_forced) { want_chunks = 1; }
   if (want_chunks > a.nsf / 32 + 1) { want_chunks = a.nsf / 32 + 1; }
   if (want_chunks > MAX_CHUNKS) { want_chunks = MAX_CHUNKS; }
   if (want_chunks < 1) { want_chunks = 1; }
@@ -1639,6 +1739,29 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   } else {
     a.ck[0].blk_lo = 0; a.ck[0].blk_hi = e->num_blocks;
   }
+  /* device-written block tables: every chunk's block stage goes out as soon as its two counts are in, then the one tail
+   * -- the device has its whole queue before the host starts on its own copy of the tables.  A chunk the device could
+   * not finish (a partition that needs the host's logarithms) ends this: it and the chunks behind it take the host route. */
+  if (!preset_blocks && a.expand && rc == 0) {
+    for (c = 0; c < a.nchunks && rc == 0; c++) {
+      volatile const uint32_t* hc = (volatile const uint32_t*)e->h_counts.ptr + 4 * (size_t)c;
+      if (a.ck[c].grp_hi == a.ck[c].grp_lo) { break; }      /* nothing searched in this chunk: no k_expand ran */
+      if ((rc = wait_counts(hc, e->expand_seq, a.ev[(size_t)c * EV_PER_CHUNK + EV_EXPANDED])) != 0) { break; }
+      if (hc[2] != 1u) { break; }
+      a.dev_lo[c][0] = a.dev_blk; a.dev_lo[c][1] = a.dev_blk + hc[0]; a.dev_lo[c][2] = a.dev_bg; a.dev_lo[c][3] = a.dev_bg + hc[1];
+      a.dev_blk += hc[0]; a.dev_bg += hc[1];
+      if (a.dev_blk > a.blocks_bound || (size_t)a.dev_bg > (size_t)a.blocks_bound * C) { rc = SLA_APIRESULT_NG; break; }
+      TRACE("counts in", c);
+      if ((rc = blocks_launch(e, &a, c, 1)) != 0) { break; }
+      a.launched[c] = 1; e->expanded_chunks++;
+      TRACE("blocks launched (device tables)", c);
+    }
+    if (rc == 0 && e->expanded_chunks == a.nchunks && e->device_ltm && e->single_tail) {
+      rc = tail_enqueue(e, &a, a.nchunks - 1, 0, a.dev_bg);
+      tail_queued = 1;
+      TRACE("tail queued", a.nchunks - 1);
+    }
+  }
   /* software pipeline over chunks: plan(c) | blocks(c) ; solve+tail(c-1) */
   for (c = 0; c < a.nchunks && rc == 0; c++) {
     hipEvent_t* ev = a.ev + (size_t)c * EV_PER_CHUNK;
@@ -1651,8 +1774,8 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
       if (rc != 0) { break; }
       TRACE("planned", c);
     }
-    if ((rc = blocks_launch(e, &a, c)) != 0) { break; }
-    TRACE("blocks launched", c);
+    if ((rc = blocks_launch(e, &a, c, a.launched[c] ? 2 : 0)) != 0) { break; }
+    TRACE(a.launched[c] ? "host tables" : "blocks launched", c);
     if (c >= 1) {
       hipEvent_t* pv = a.ev + (size_t)(c - 1) * EV_PER_CHUNK;
       if (hipEventSynchronize(pv[EV_LPC_DOWN]) != hipSuccess) { rc = SLA_APIRESULT_NG; break; }
@@ -1676,7 +1799,8 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
     /* everything is queued: one k_tail over all groups (unless every chunk queued its own), then the RAW decision of
      * the last chunk on the host threads while the device works */
     hipEvent_t* pv = a.ev + (size_t)(a.nchunks - 1) * EV_PER_CHUNK;
-    if (e->single_tail) { rc = tail_enqueue(e, &a, a.nchunks - 1, 0, a.nbg); TRACE("tail queued", a.nchunks - 1); }
+    if (e->single_tail && !tail_queued) { rc = tail_enqueue(e, &a, a.nchunks - 1, 0, a.nbg); TRACE("tail queued", a.nchunks - 1); }
+    if (tail_queued && a.nbg != a.dev_bg) { rc = SLA_APIRESULT_NG; }
     if (rc == 0 && hipEventSynchronize(pv[EV_LPC_DOWN]) != hipSuccess) { rc = SLA_APIRESULT_NG; }
     if (rc == 0) { rc = raw_phase(e, &a, a.nchunks - 1); }
     TRACE("RAW decided", a.nchunks - 1);
@@ -1795,6 +1919,7 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   else if (strcmp(name, "stream_lanes") == 0)      { OPT_RANGE(1, 4); e->stream_lanes = (uint32_t)iv; }
   else if (strcmp(name, "first_chunk") == 0)       { OPT_RANGE(0, 999); e->first_chunk = (uint32_t)iv; }
   else if (strcmp(name, "alt_streams") == 0)       { OPT_RANGE(0, 2); e->alt_streams = (int)iv; }
+  else if (strcmp(name, "device_expand") == 0)     { OPT_RANGE(0, 1); e->device_expand = (int)iv; }
   else if (strcmp(name, "device_ltm") == 0)        { OPT_RANGE(0, 1); e->device_ltm = (int)iv; }
   else if (strcmp(name, "fuse_lattice") == 0)      { OPT_RANGE(0, 1); e->fuse_lattice = (int)iv && !e->tune.lpc_blocks_chains; }
   else if (strcmp(name, "threads") == 0) {
@@ -1993,6 +2118,13 @@ int sla_hip_last_counters(const struct SLAEncoder* e, uint32_t* counters)
   counters[0] = e->fallback_groups; counters[1] = e->host_planned;
   counters[2] = (uint32_t)e->timing[11]; counters[3] = (uint32_t)e->device_plan;
   counters[4] = e->tail_launches; counters[5] = (uint32_t)e->device_ltm;
+  return 0;
+}
+
+int sla_hip_last_expand(const struct SLAEncoder* e, uint32_t* counters)
+{
+  if (e == NULL || counters == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  counters[0] = e->expanded_chunks; counters[1] = (uint32_t)e->timing[9];
   return 0;
 }
 
@@ -2773,6 +2905,7 @@ static struct SLAEncoder* stream_lane(struct SLAEncoder* e, uint32_t t)
   l->chunks = e->chunks; l->chunks_forced = e->chunks_forced; l->first_chunk = e->first_chunk; l->split_count = 0;
   l->fuse_lattice = e->fuse_lattice; l->device_plan = e->device_plan; l->search_exact = e->search_exact; l->exact_bits = e->exact_bits;
   l->cert_safety = e->cert_safety; l->single_tail = e->single_tail; l->device_ltm = e->device_ltm; l->tune = e->tune;
+  l->block_cert = e->block_cert; l->block_cert_safety = e->block_cert_safety; l->alt_streams = e->alt_streams; l->device_expand = e->device_expand;
   l->trace = 0;
   return l;
 }

@@ -1,0 +1,144 @@
+"""Block tables written on the device (k_expand, option "device_expand"): the block stage is launched from two counts,
+the host's own tables follow under the kernels.  Same bytes as the host-table route and as the oracle; the route falls
+back to host tables chunk-wise when the device cannot certify a partition, and is not taken at all for input with
+all-zero mask words (where a block inside a super-frame could be SILENT).
+
+Reference: the walk over the super-frames that numbers the blocks, src/SLAEncoder.c:846-869."""
+import numpy as np
+import pytest
+
+import slalibs as S
+import waveforms as W
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    torch.cuda.init()
+    import sla_amd
+    sla_amd.lib()
+    return sla_amd
+
+
+def _encode(hip, p, pcm, **options):
+    enc = hip.Encoder(p.cap_channels, p.cap_block_samples, p.cap_parcor_order, p.cap_longterm_order, p.cap_lms_order)
+    try:
+        for k, v in options.items():
+            enc.set_option(k, v)
+        enc.set_wave_format(p.num_channels, p.bits_per_sample, p.sampling_rate)
+        enc.set_encode_parameter(p.parcor_order, p.longterm_order, p.lms_order, p.ch_process_method,
+                                 p.window_type, p.max_block_samples)
+        data = enc.encode_whole(pcm)
+        return data, enc.last_expand(), enc.last_counters()
+    finally:
+        enc.close()
+
+
+CASES = [
+    # nch, bits, rate, order, ms, maxb, samples, kind
+    (1, 16, 48000, 16, 0, 4096, 48000 * 60, "bench"),          # the C2 shape: two chunks
+    (2, 24, 48000, 32, 1, 4096, 48000 * 40 + 1234, "bench"),   # ragged last super-frame
+    (2, 16, 48000, 16, 1, 4096, 480000, "music"),              # a clip: one chunk
+    (3, 24, 96000, 48, 0, 8192, 96000 * 12 + 77, "music"),     # a last super-frame of 77 samples
+    (1, 24, 44100, 8, 0, 2048, 44100 * 30, "noise"),
+    (2, 20, 48000, 24, 1, 16384, 48000 * 30 + 5000, "music"),
+]
+
+
+def _signal(kind, nch, n, bits, seed):
+    if kind == "bench":
+        return S.synth_pcm(nch, n, bits, 48000, seed=seed)
+    if kind == "music":
+        return W.music_like(nch, n, bits, seed=seed)
+    rng = np.random.default_rng(seed)
+    x = rng.integers(-(1 << (bits - 3)), 1 << (bits - 3), size=(nch, n), dtype=np.int64)
+    return (x << (32 - bits)).astype(np.int32)
+
+
+@pytest.mark.parametrize("nch,bits,rate,order,ms,maxb,n,kind", CASES)
+def test_device_tables_give_the_host_tables_bytes(oracle, hip, nch, bits, rate, order, ms, maxb, n, kind):
+    pcm = _signal(kind, nch, n, bits, seed=order + nch)
+    p = S.make_params(nch, bits, rate, order, 1, 8, ms, 1, maxb)
+    host, eh, _ = _encode(hip, p, pcm, device_expand=0, stream=0)
+    dev, ed, cnt = _encode(hip, p, pcm, device_expand=1, stream=0)
+    assert eh[0] == 0
+    assert dev == host
+    # every chunk of a file without silence whose partitions all certify runs from device tables
+    if cnt[1] == 0:
+        assert ed[0] == ed[1] and ed[1] >= 1, ed
+    if n <= 48000 * 40 + 1234:
+        ret, want = oracle.encode_whole(p, pcm)
+        assert ret == 0 and dev == want
+
+
+@pytest.mark.parametrize("chunks", [1, 2, 3, 5])
+def test_chunk_counts(hip, chunks):
+    pcm = S.synth_pcm(2, 48000 * 90, 16, 48000, seed=7)
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096)
+    host, _, _ = _encode(hip, p, pcm, device_expand=0, stream=0, chunks=chunks)
+    dev, ed, _ = _encode(hip, p, pcm, device_expand=1, stream=0, chunks=chunks)
+    assert dev == host
+    assert ed == (chunks, chunks)
+
+
+def test_uncertified_partitions_take_the_host_tables(oracle, hip):
+    """plan_margin = 1e30: k_plan certifies nothing, k_expand reports the chunk as not valid, the host route runs"""
+    pcm = W.music_like(2, 300000, 16, seed=3)
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096)
+    ret, want = oracle.encode_whole(p, pcm)
+    assert ret == 0
+    got, ed, cnt = _encode(hip, p, pcm, device_expand=1, plan_margin=1e30, stream=0, chunks=2)
+    assert got == want
+    assert ed[0] == 0 and cnt[1] > 0
+
+
+def test_silence_keeps_the_host_tables(oracle, hip):
+    """all-zero mask words: a block inside a super-frame can be SILENT, the device tables are not used"""
+    pcm = W.music_like(2, 400000, 16, seed=5)
+    pcm[:, 100000:140000] = 0
+    pcm[:, 390000:] = 0
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096)
+    ret, want = oracle.encode_whole(p, pcm)
+    assert ret == 0
+    got, ed, _ = _encode(hip, p, pcm, device_expand=1, stream=0)
+    assert got == want
+    assert ed[0] == 0
+
+
+def test_silent_last_superframe(oracle, hip):
+    """no all-zero mask word, but the file ends in a few zero samples that make a SILENT last super-frame"""
+    n = 4096 * 30 + 40
+    pcm = W.music_like(1, n, 16, seed=9)
+    pcm[:, 4096 * 30:] = 0
+    p = S.make_params(1, 16, 48000, 16, 1, 8, 0, 1, 4096)
+    ret, want = oracle.encode_whole(p, pcm)
+    assert ret == 0
+    got, ed, _ = _encode(hip, p, pcm, device_expand=1, stream=0)
+    assert got == want
+
+
+def test_expand_launcher_rejects_bad_arguments(hip):
+    L = hip.lib()
+    assert L.sla_hip_launch_expand(None, 0, None, None, None, 1, 0, None, None, 0, None, None, None, None, 0, None, 1, None) != 0
+
+
+def test_handle_reuse_across_routes(oracle, hip):
+    """one handle, files of different kinds one after the other: the sequence word and the running counters restart"""
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096)
+    enc = hip.Encoder(p.cap_channels, p.cap_block_samples, p.cap_parcor_order, p.cap_longterm_order, p.cap_lms_order)
+    try:
+        enc.set_option("stream", 0)
+        enc.set_wave_format(2, 16, 48000)
+        enc.set_encode_parameter(16, 1, 8, 1, 1, 4096)
+        for i, n in enumerate([200000, 4096 * 300, 50001, 200000]):
+            pcm = W.music_like(2, n, 16, seed=20 + i)
+            if i == 2:
+                pcm[:, 10000:30000] = 0
+            ret, want = oracle.encode_whole(p, pcm)
+            assert ret == 0
+            assert enc.encode_whole(pcm) == want
+            assert (enc.last_expand()[0] == 0) == (i == 2)
+    finally:
+        enc.close()
