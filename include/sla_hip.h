@@ -132,10 +132,11 @@ typedef struct sla_hip_tuning {
   uint32_t lpc_pack;            /* windows per workgroup of k_lpc / k_lpc_blocks, 0 = automatic                      */
   uint32_t lpc_threads;         /* 256 or 512 threads per k_lpc workgroup, 0 = automatic                             */
   uint32_t lpc_blocks_chains;   /* 1: chosen blocks through k_lpc's serial chains instead of k_lpc_blocks            */
-  uint32_t tail_waves;          /* waves per k_tail workgroup (1..4), 0 = automatic (1)                              */
+  uint32_t tail_waves;          /* waves per tail workgroup (1..4), 0 = automatic (k_tailk 4, round-2 kernels 1)      */
   uint32_t lpc_tile;            /* steps per tile of k_lpc_blocks' wide packs: 24, or 0 / 48 = 48 where it fits         */
-  uint32_t tail_lanes;          /* lanes per tail job in units of the LMS order: 1 = one (k_tail2, two taps per lane), 2 = two (k_tail, one tap per lane),
-                                   3 = ONE lane per job (k_tail1, LMS order <= 16), 0 = by the number of jobs */
+  uint32_t tail_lanes;          /* tail kernel: 0 = k_tailk with 1 or 2 taps of each history per lane, by the number of jobs (default);
+                                   6 / 4 / 5 = k_tailk with 1 / 2 / 4 taps; round-2 kernels: 1 = k_tail2 (LMS order lanes per job),
+                                   2 = k_tail (twice that), 3 = k_tail1 (ONE lane per job, LMS order <= 16) */
   double   plan_margin;         /* certification margin of k_plan, 0 = 1e-4 (tests raise it to force the host plan)  */
   uint32_t acf_classic;         /* 1: long-term autocorrelation through k_ltm_acf (one LDS pass per step) instead of k_ltm_acf2 */
   uint32_t pad_;
@@ -531,8 +532,9 @@ int sla_hip_get_trace(struct SLAEncoder* encoder, sla_hip_trace* trace);
 
 /* Options of one encoder handle, by name (the environment variable of the same meaning, read once in
  * SLAEncoder_Create, is given in brackets).  Layout knobs: "lpc_pack" [SLA_HIP_LPC_PACK], "lpc_threads"
- * [SLA_HIP_LPC_THREADS], "lpc_tile" (24 / 48 / 0 = automatic), "tail_waves" [SLA_HIP_TAIL_WAVES], "tail_lanes" (1: two
- * taps per lane, 2: one tap per lane, 3: one lane per job, 0: by the number of jobs) [SLA_HIP_TAIL_LANES], "chunks" [SLA_HIP_CHUNKS],
+ * [SLA_HIP_LPC_THREADS], "lpc_tile" (24 / 48 / 0 = automatic), "tail_waves" [SLA_HIP_TAIL_WAVES], "tail_lanes" (0: k_tailk, taps
+ * per lane by the number of jobs; 6 / 4 / 5: k_tailk with 1 / 2 / 4 taps of each history per lane; 1 / 2 / 3: the round-2 kernels k_tail2 /
+ * k_tail / k_tail1) [SLA_HIP_TAIL_LANES], "chunks" [SLA_HIP_CHUNKS],
  * "threads" (host pool) [SLA_HIP_THREADS].  Route switches -- every route gives the same bytes; tests force the
  * slower exact ones through these: "search_exact" (0: no tile-sum search) [SLA_HIP_SEARCH=chain], "exact_bits"
  * (log2 of the tile-sum energy limit, 1..53) [SLA_HIP_EXACT_BITS], "cert_safety" (safety factor of the certificate for

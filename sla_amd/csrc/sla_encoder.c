@@ -214,7 +214,8 @@ struct slai_pool {
   uint32_t busy;                     /* atomic: workers that have not finished the current generation */
 };
 
-#define POOL_SPINS 40000u            /* ~200 us of pause instructions before a worker sleeps */
+static uint32_t g_pool_spins = 8000u;       /* pause instructions before an idle worker sleeps (SLA_HIP_POOL_SPINS, read in SLAEncoder_Create) */
+#define POOL_SPINS g_pool_spins
 
 static void pool_drain(struct slai_pool* p)
 {
@@ -398,13 +399,15 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   env = getenv("SLA_HIP_PLAN_COPY");
   e->plan_copy_down = (env != NULL && strcmp(env, "down") == 0);
   e->trace = (getenv("SLA_HIP_TRACE") != NULL);
+  env = getenv("SLA_HIP_POOL_SPINS");
+  if (env != NULL && atoi(env) >= 0) { g_pool_spins = (uint32_t)atoi(env); }
   g_trace_on = e->trace;
   env = getenv("SLA_HIP_LPC_PACK");
   if (env != NULL && atoi(env) >= 1) { e->tune.lpc_pack = (uint32_t)atoi(env); }
   env = getenv("SLA_HIP_UPLOAD24");
   if (env != NULL) { e->upload24 = (atoi(env) != 0); }
   env = getenv("SLA_HIP_TAIL_LANES");
-  if (env != NULL && atoi(env) >= 0 && atoi(env) <= 3) { e->tune.tail_lanes = (uint32_t)atoi(env); }
+  if (env != NULL && atoi(env) >= 0 && atoi(env) <= 6) { e->tune.tail_lanes = (uint32_t)atoi(env); }
   env = getenv("SLA_HIP_ACF");
   if (env != NULL && strcmp(env, "classic") == 0) { e->tune.acf_classic = 1; }
   env = getenv("SLA_HIP_LPC_THREADS");
@@ -432,7 +435,12 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
     e->threads /= ranks;
   }
   if (e->threads < 1) { e->threads = 1; }
-  if (e->threads > 10) { e->threads = 10; }       /* the loops are short: more workers only add wake-up and join time */
+  /* The loops are short: more workers only add wake-up and join time.  Six, and a short spin before an idle worker sleeps:
+   * ten workers that spin for most of a millisecond after every loop kept ten cores busy through back-to-back calls, and
+   * in a container with a CPU quota (the GPU boxes here: 16 cores' worth per 100 ms) that leaves little room before the
+   * whole process is throttled for the rest of the period -- 4 - 10 ms stalls in 1.3 ms steps (tests/tools/step_jitter.py).
+   * The steps themselves do not notice: C2 1.32 ms, C3-600 s 2.48, C5-120 s 4.77 with 4, 6 or 10 workers. */
+  if (e->threads > 6) { e->threads = 6; }
   env = getenv("SLA_HIP_THREADS");
   if (env != NULL && atoi(env) > 0) { e->threads = (uint32_t)atoi(env); }
   e->pool = pool_create(e->threads);
@@ -1901,7 +1909,7 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   else if (strcmp(name, "tail_waves") == 0)        { OPT_RANGE(0, 4); e->tune.tail_waves = (uint32_t)iv; }
   else if (strcmp(name, "lpc_tile") == 0)          { if (iv != 0 && iv != 24 && iv != 48) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.lpc_tile = (uint32_t)iv; }
   else if (strcmp(name, "acf_classic") == 0)       { OPT_RANGE(0, 1); e->tune.acf_classic = (uint32_t)iv; }
-  else if (strcmp(name, "tail_lanes") == 0)        { OPT_RANGE(0, 3); e->tune.tail_lanes = (uint32_t)iv; }
+  else if (strcmp(name, "tail_lanes") == 0)        { OPT_RANGE(0, 6); e->tune.tail_lanes = (uint32_t)iv; }
   else if (strcmp(name, "lpc_blocks_chains") == 0) { OPT_RANGE(0, 1); e->tune.lpc_blocks_chains = (uint32_t)iv; if (iv) { e->fuse_lattice = 0; } }
   /* the certification margins may only be widened: below the built-in values byte-identity is no longer guaranteed */
   else if (strcmp(name, "plan_margin") == 0)       { if (value != 0.0 && !(value >= 1e-4)) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.plan_margin = value; }

@@ -2237,6 +2237,235 @@ void k_tail2(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_tailk: the same stage with K taps of each history per lane (2 K coefficients), ORDER / K lanes per job -- for files
+// with so many (block, channel) jobs that what counts is instructions per job and sample, not the length of one job's
+// chain.  Measured (tests/tools/ubench_int.hip, one wave on a SIMD): an instruction that needs the result of a recent one
+// issues 3.3 ns after it, an independent one 1.7 - 1.9 ns, a dependent DPP step with its wait states 6.8 ns -- and a
+// 32-bit v_mul_lo costs what an add costs.  So a lone wave pays for every instruction of the per-sample loop (k_tail:
+// 22 + 4 wait states = 105 ns per sample, which is the whole C2 launch), two or more waves per SIMD fill each other's
+// stalls, and then the work per sample is what is left to cut: everything that is computed once per job and sample
+// (the sum's last steps, error, logarithm, step, history shift: ~20 instructions) is shared by 64 / (ORDER / K) jobs
+// of a wave instead of 4 (k_tail) or 8 (k_tail2), against 4 K instructions more for the lane's own products and
+// updates.  ORDER 8: k_tail2 ~30 instructions per sample for 8 jobs, K = 2 ~37 for 16, K = 4 ~53 for 32.
+//
+// Layout.  The jobs of a DPP row (16 lanes) are interleaved: lane r of the row is lane r / JPR of job r % JPR (JPR = jobs
+// per row), so a shift of the history to the job's next lane is row_shr:JPR for all jobs at once -- the first lane of
+// every job has no source inside the row and keeps `old`, which is the new input / prediction: no select -- and the
+// job's sum is log2(lanes) row rotations.  A lane keeps its K history values in place: at step u of the unrolled block
+// the tap of age a sits in slot (a - u) mod K, the slot of the value that leaves for the next lane takes the one that
+// arrives, and the signs are kept beside the values (one sign per arriving value instead of one per tap and sample).
+// ---------------------------------------------------------------------------------------------
+template <int LPJ>
+__device__ __forceinline__ uint32_t job_sum(uint32_t x)          // over the lanes r, r + JPR, r + 2 JPR, .. of a row
+{
+  x += dpp_u32<0x128>(x);                                  // row_ror:8
+  if (LPJ >= 4) { x += dpp_u32<0x124>(x); }                // row_ror:4
+  if (LPJ >= 8) { x += dpp_u32<0x122>(x); }                // row_ror:2
+  if (LPJ >= 16) { x += dpp_u32<0x121>(x); }               // row_ror:1
+  return x;
+}
+
+// Samples cross global memory 32 at a time per job (TAILK_BLK): the job's lanes each move a run of 32 / lanes consecutive
+// samples as 16-byte accesses, so a job touches each of its cache lines once.  (Per-sample accesses of 2 - 4 lanes per
+// job made a wave's load touch 16 - 32 lines for 8 bytes each: the first version of this kernel was bound by those
+// line fetches and lost to k_tail2 -- C3 60 min 4.6 against 3.6 ms with four taps per lane.)
+#define TAILK_BLK 32
+typedef int32_t tk_i32x4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef int32_t tk_i32x2 __attribute__((ext_vector_type(2), aligned(4)));
+
+template <int N>
+__device__ __forceinline__ void tk_load_run(const int32_t* __restrict__ p, int32_t (&v)[N])      // N consecutive words, 4-byte aligned
+{
+  if constexpr (N % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < N / 4; q++) {
+      const tk_i32x4 x = *reinterpret_cast<const tk_i32x4*>(p + 4 * q);
+      v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < N / 2; q++) {
+      const tk_i32x2 x = *reinterpret_cast<const tk_i32x2*>(p + 2 * q);
+      v[2 * q] = x.x; v[2 * q + 1] = x.y;
+    }
+  }
+}
+template <int N>
+__device__ __forceinline__ void tk_store_run(int32_t* __restrict__ p, const int32_t (&v)[N])
+{
+  if constexpr (N % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < N / 4; q++) {
+      tk_i32x4 x; x.x = v[4 * q]; x.y = v[4 * q + 1]; x.z = v[4 * q + 2]; x.w = v[4 * q + 3];
+      *reinterpret_cast<tk_i32x4*>(p + 4 * q) = x;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < N / 2; q++) {
+      tk_i32x2 x; x.x = v[2 * q]; x.y = v[2 * q + 1];
+      *reinterpret_cast<tk_i32x2*>(p + 2 * q) = x;
+    }
+  }
+}
+
+template <int ORDER, int K, bool FIRST>
+__device__ __forceinline__ void tailk_block(const int32_t (&vm)[TAILK_BLK * K / ORDER], int32_t (&em)[TAILK_BLK * K / ORDER],
+                                            const int (&addr)[ORDER / K], uint32_t L,
+                                            int32_t (&ca)[K], int32_t (&cb)[K], int32_t (&ha)[K], int32_t (&hb)[K],
+                                            int32_t (&sa)[K], int32_t (&sb)[K])
+{
+  constexpr int LPJ = ORDER / K, JPR = 16 / LPJ, SPL = TAILK_BLK / LPJ;
+  constexpr int SHR = 0x110 + JPR;                         // row_shr:JPR
+#pragma unroll
+  for (int u0 = 0; u0 < TAILK_BLK; u0 += 8) {
+    // sample u of the block was fetched by the job's lane u / SPL as its element u % SPL; eight at a time, all requested
+    // before the first is used, so that no step of the chain waits for the LDS crossbar
+    int32_t vs[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) { vs[w] = __builtin_amdgcn_ds_bpermute(addr[(u0 + w) / SPL], vm[(u0 + w) % SPL]); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+      const int u = u0 + w;
+      const int32_t v = vs[w];
+      int32_t e, ph;
+      if (FIRST && u < ORDER) {
+        e = v; ph = v;                                     // the first ORDER samples only prime both histories
+      } else {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int a = 0; a < K; a++) {
+          const int slot = ((a - u) % K + K) % K;
+          acc += (uint32_t)ca[a] * (uint32_t)ha[slot];
+          acc += (uint32_t)cb[a] * (uint32_t)hb[slot];
+        }
+        const uint32_t sum = job_sum<LPJ>(acc) + (1u << 9);
+        const int32_t p = (int32_t)sum >> 10;
+        e = (int32_t)((uint32_t)v - (uint32_t)p);
+        const int32_t ne = (int32_t)((uint32_t)p - (uint32_t)v);
+        const uint32_t mag = (uint32_t)max(e, ne);
+        const int32_t lg = 32 - (int32_t)__clz((int)mag);
+        const int32_t g = __mul24(sgn(e), lg >> 1);        // step table src/SLAPredictor.c:123-144 times sign(e)
+#pragma unroll
+        for (int a = 0; a < K; a++) {
+          const int slot = ((a - u) % K + K) % K;
+          ca[a] = mad24(g, sa[slot], ca[a]);
+          cb[a] = mad24(g, sb[slot], cb[a]);
+        }
+        ph = p;
+      }
+      const int put = (K - 1 - (u % K));                   // the slot of the lane's oldest value takes the arriving one
+      ha[put] = (int32_t)__builtin_amdgcn_update_dpp(v, ha[put], SHR, 0xF, 0xF, false);
+      hb[put] = (int32_t)__builtin_amdgcn_update_dpp(ph, hb[put], SHR, 0xF, 0xF, false);
+      sa[put] = sgn(ha[put]);
+      sb[put] = sgn(hb[put]);
+      em[u % SPL] = (L == (uint32_t)(u / SPL)) ? e : em[u % SPL];
+    }
+  }
+}
+
+template <int ORDER, int K>
+__global__ __launch_bounds__(256)
+void k_tailk(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, uint64_t stride,
+             const sla_hip_tail_job* __restrict__ jobs, uint32_t num_jobs, uint32_t ntaps,
+             uint64_t* __restrict__ fold_sum, unsigned long long* span, uint32_t stage_flags)
+{
+  span_begin(span);
+  constexpr int LPJ = ORDER / K;               // lanes per job: 2 .. 16
+  constexpr int JPR = 16 / LPJ;                // jobs per DPP row
+  constexpr int JPW = 4 * JPR;                 // jobs per wave
+  constexpr int SPL = TAILK_BLK / LPJ;         // consecutive samples a lane moves per block of 32: 2 .. 16
+  static_assert(ORDER % K == 0 && LPJ >= 2 && LPJ <= 16 && (LPJ & (LPJ - 1)) == 0 && TAILK_BLK % ORDER == 0, "lanes per job");
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t row = lane >> 4, r = lane & 15u;
+  const uint32_t jr = r % JPR, L = r / JPR;
+  const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t j = wave * JPW + row * JPR + jr;
+  const bool have = (j < num_jobs);
+  const sla_hip_tail_job job = jobs[have ? j : 0];
+  const uint32_t n = have ? job.blk_len : 0;
+  const int32_t* in = res_in + (uint64_t)job.channel * stride + job.blk_off;
+  int32_t* out = res_out + (uint64_t)job.channel * stride + job.blk_off;
+  const uint32_t delay = job.pitch + (ntaps >> 1);
+  const bool use_ltm = (job.pitch >= 3);
+  const bool pass = (n < (uint32_t)ORDER) || (stage_flags & 1u);      // fewer samples than taps, or no LMS stage wanted: everything passes through
+  const uint32_t nmax = umax_wave(n);
+
+  // the lane's run of block s0: samples [s0 + L SPL, + SPL), behind the long-term stage   src/SLAPredictor.c:1063-1099
+  auto fetch_run = [&](uint32_t s0, int32_t (&v)[SPL]) {
+    const uint32_t s = s0 + L * SPL;
+    if (s + SPL <= n && (!use_ltm || s >= delay)) {
+      tk_load_run<SPL>(in + s, v);
+      if (use_ltm) {
+        int32_t win[SPL + 4];                              // in[s - delay .. s - delay + SPL + ntaps - 2]
+        const int32_t* w = in + (s - delay);
+#pragma unroll
+        for (int i = 0; i < SPL + 4; i++) { win[i] = ((uint32_t)i < SPL + ntaps - 1) ? w[i] : 0; }
+#pragma unroll
+        for (int i = 0; i < SPL; i++) {
+          int64_t acc = (int64_t)1 << 30;
+#pragma unroll
+          for (int k = 0; k < 5; k++) { if ((uint32_t)k < ntaps) { acc += (int64_t)job.ltm_coef[k] * (int64_t)win[i + k]; } }
+          v[i] = (int32_t)((uint32_t)v[i] - (uint32_t)(int32_t)(acc >> 31));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < SPL; i++) {
+        const uint32_t si = s + (uint32_t)i;
+        int32_t x = 0;
+        if (si < n) {
+          x = in[si];
+          if (use_ltm && si >= delay) {
+            int64_t acc = (int64_t)1 << 30;
+            for (uint32_t k = 0; k < ntaps; k++) { acc += (int64_t)job.ltm_coef[k] * (int64_t)in[si - delay + k]; }
+            x = (int32_t)((uint32_t)x - (uint32_t)(int32_t)(acc >> 31));
+          }
+        }
+        v[i] = x;
+      }
+    }
+  };
+
+  int addr[LPJ];                                     // ds_bpermute byte address of the job's lane l
+#pragma unroll
+  for (int l = 0; l < LPJ; l++) { addr[l] = (int)((row * 16 + (uint32_t)l * JPR + jr) * 4); }
+  int32_t ca[K], cb[K], ha[K], hb[K], sa[K], sb[K];
+#pragma unroll
+  for (int a = 0; a < K; a++) { ca[a] = cb[a] = ha[a] = hb[a] = sa[a] = sb[a] = 0; }
+  uint64_t fsum = 0;
+  int32_t vm_next[SPL];
+  fetch_run(0, vm_next);
+  for (uint32_t s0 = 0; s0 < nmax; s0 += TAILK_BLK) {
+    int32_t vm[SPL], em[SPL];
+#pragma unroll
+    for (int m = 0; m < SPL; m++) { vm[m] = vm_next[m]; em[m] = 0; }
+    fetch_run(s0 + TAILK_BLK, vm_next);                // the next block travels while this one computes
+    if (s0 == 0) { tailk_block<ORDER, K, true>(vm, em, addr, L, ca, cb, ha, hb, sa, sb); }
+    else { tailk_block<ORDER, K, false>(vm, em, addr, L, ca, cb, ha, hb, sa, sb); }
+    const uint32_t s = s0 + L * SPL;
+#pragma unroll
+    for (int m = 0; m < SPL; m++) {
+      em[m] = pass ? vm[m] : em[m];
+      if (s + (uint32_t)m < n) { fsum += (em[m] < 0) ? ~((uint32_t)em[m] << 1) : ((uint32_t)em[m] << 1); }      // zig-zag fold, src/SLAUtility.h:37
+    }
+    if (s + SPL <= n) { tk_store_run<SPL>(out + s, em); }
+    else {
+#pragma unroll
+      for (int m = 0; m < SPL; m++) { if (s + (uint32_t)m < n) { out[s + m] = em[m]; } }
+    }
+  }
+#pragma unroll
+  for (int off = JPR; off < 16; off <<= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)fsum, off);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(fsum >> 32), off);
+    fsum += ((uint64_t)hi << 32) | lo;
+  }
+  if (have && L == 0) { fold_sum[j] = fsum; }
+  span_end(span);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_tail1: the same stage with ONE LANE per job -- for files with tens of thousands of (block, channel) jobs.  k_tail
 // and k_tail2 spread a job's taps over 8 - 16 lanes to shorten the serial chain per sample, which is what a short file
 // needs (its duration is one block's chain); a long file has more jobs than the chip has lanes, and then what counts is
@@ -3624,6 +3853,8 @@ extern "C" int sla_hip_launch_tail_stages(const int32_t* d_res_in, int32_t* d_re
                           skip_lms ? 1u : 0u);
 }
 
+/* one-tap-per-lane waves of k_tailk beyond which two taps per lane are chosen (1024 SIMDs) */
+#define TAILK2_WAVES 2048u
 static int launch_tail_impl(const int32_t* d_res_in, int32_t* d_res_out, uint64_t plane_stride,
                             const sla_hip_tail_job* d_jobs, uint32_t num_jobs, uint32_t longterm_order,
                             uint32_t lms_order, uint64_t* d_fold_sum, sla_hip_stream_t stream, uint32_t stage_flags)
@@ -3636,10 +3867,8 @@ static int launch_tail_impl(const int32_t* d_res_in, int32_t* d_res_out, uint64_
   const uint32_t tail_waves = (tw >= 1 && tw <= 4) ? tw : 1u;     /* one wave per workgroup: the dispatcher spreads the (few, long-running) waves over all CUs */
   hipStream_t st = (hipStream_t)stream;
   unsigned long long* span = take_span();
-  /* One tap per lane (k_tail) has the shorter dependent chain per sample -- one quarter-rate 32-bit multiply instead of
-   * two -- and wins while the SIMDs hold a few waves each (C2: 1.7 waves per SIMD, 0.44 against 0.59 ms; C5-120 s: 1.30
-   * against 1.48); two taps per lane (k_tail2) halve the waves and win once instruction issue is the limit (C3-600 s:
-   * 3.4 waves per SIMD, 1.01 -> 0.79 ms).  Automatic: k_tail2 above three one-tap waves per SIMD of an MI355X. */
+  /* Round 2's kernels, now behind the knob only (tail_lanes 2 / 1): one coefficient per lane (k_tail, 2 * order lanes per
+   * job) and two (k_tail2, order lanes per job), both fetching one sample per lane and step. */
   const uint32_t one_tap_waves = (num_jobs + (64 / (2 * lms_order)) - 1) / (64 / (2 * lms_order));
   const uint32_t lanes_knob = tuning().tail_lanes;
   /* One lane per job (k_tail1; LMS orders 4 - 16, the histories live in registers): only on request.  Measured against
@@ -3655,7 +3884,52 @@ static int launch_tail_impl(const int32_t* d_res_in, int32_t* d_res_out, uint64_
     }
     return hip_rc(hipGetLastError());
   }
-  if (lanes_knob == 1 || (lanes_knob == 0 && one_tap_waves > 3u * 1024u)) {      /* two taps per lane: `order` lanes per job */
+  /* K taps of each history per lane (k_tailk), the automatic choice.  Measured (tests/tools/chunk_sweep.py, LMS order 8,
+   * ms per launch; k_tail / k_tail2 are the round-2 kernels, still behind the knob):
+   *   jobs     blocks          k_tail  k_tail2   K = 1   K = 2   K = 4
+   *    3.5 k   4096 (C2 300 s)   0.42    0.49     0.35    0.43    0.62
+   *    7 k     4096 (C2)         0.44    0.57     0.37    0.43    0.62
+   *   14 k     4096 (C3 600 s)   0.99    0.78     0.50    0.49    0.68
+   *   11 k     8192 (C5 120 s)   1.26    1.46     0.96    0.95    1.33
+   *   90 k     4096 (C3)         4.33    3.60     1.95    1.46    1.55
+   *  169 k     8192 (C5)        16.5    13.2      7.45    5.45    6.70
+   * One tap per lane has the shortest chain per sample (0.35 ms per 4096 samples) and holds up to about two waves per SIMD;
+   * beyond that two taps per lane halve the work per job.  Four never won: its 16-sample runs per lane cost more in the
+   * long-term stage and registers than the shared per-sample work saves. */
+  {
+    uint32_t k = 0;
+    const uint32_t k1_waves = (num_jobs * lms_order + 63u) / 64u;        /* waves of K = 1 */
+    if (lanes_knob == 4 || lanes_knob == 5) { k = (lanes_knob == 4) ? 2u : 4u; }
+    else if (lanes_knob == 6 && lms_order <= 16) { k = 1; }
+    else if (lanes_knob == 0) { k = (lms_order > 16 || (k1_waves > TAILK2_WAVES && lms_order >= 4)) ? 2u : 1u; }
+    if (k > lms_order / 2) { k = lms_order / 2; }          /* at least two lanes per job */
+    if (k >= 1) {
+      /* four waves per workgroup: one workgroup fills a CU's four SIMDs with one wave each (one-wave workgroups landed two
+       * on a SIMD while other CUs stood empty: C2 0.44 against 0.37 ms, C3 1.83 against 1.46) */
+      const uint32_t twk = (tw >= 1 && tw <= 4) ? tw : 4u;
+      const uint32_t jpw = 64 / (lms_order / k);
+      const uint32_t jpb = twk * jpw;
+      dim3 gridk((num_jobs + jpb - 1) / jpb), blockk(64 * twk);
+#define LAUNCH_TAILK(O, KK) hipLaunchKernelGGL((k_tailk<O, KK>), gridk, blockk, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags)
+      switch (lms_order * 16 + k) {
+        case 4 * 16 + 1:  LAUNCH_TAILK(4, 1); break;
+        case 8 * 16 + 1:  LAUNCH_TAILK(8, 1); break;
+        case 16 * 16 + 1: LAUNCH_TAILK(16, 1); break;
+        case 4 * 16 + 2:  LAUNCH_TAILK(4, 2); break;
+        case 8 * 16 + 2:  LAUNCH_TAILK(8, 2); break;
+        case 8 * 16 + 4:  LAUNCH_TAILK(8, 4); break;
+        case 16 * 16 + 2: LAUNCH_TAILK(16, 2); break;
+        case 16 * 16 + 4: LAUNCH_TAILK(16, 4); break;
+        case 32 * 16 + 2: LAUNCH_TAILK(32, 2); break;
+        case 32 * 16 + 4: LAUNCH_TAILK(32, 4); break;
+        default: return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY;
+      }
+#undef LAUNCH_TAILK
+      return hip_rc(hipGetLastError());
+    }
+  }
+  (void)one_tap_waves;
+  if (lanes_knob == 1) {      /* two taps per lane: `order` lanes per job */
     const uint32_t jpb = tail_waves * (64 / lms_order);
     dim3 grid2((num_jobs + jpb - 1) / jpb), block2(64 * tail_waves);
     switch (lms_order) {

@@ -160,7 +160,26 @@ def test_tail_orders(oracle, hip, lms, ltm):
     assert got == want
     got, _ = _encode_with_options(hip, p, pcm, tail_lanes=1, tail_waves=2, chunks=1)
     assert got == want
-    got, _ = _encode_with_options(hip, p, pcm, tail_lanes=3)      # one lane per job (k_tail1: the choice for tens of thousands of jobs; order 32 falls back)
+    got, _ = _encode_with_options(hip, p, pcm, tail_lanes=3)      # one lane per job (k_tail1; order 32 falls back)
+    assert got == want
+    got, _ = _encode_with_options(hip, p, pcm, tail_lanes=4)      # two taps of each history per lane (k_tailk<., 2>)
+    assert got == want
+    got, _ = _encode_with_options(hip, p, pcm, tail_lanes=5, tail_waves=4)      # four (k_tailk<., 4>; LMS order 4: two)
+    assert got == want
+    got, _ = _encode_with_options(hip, p, pcm, tail_lanes=6)      # one (k_tailk<., 1>: k_tail2's layout; order 32 takes the automatic choice)
+    assert got == want
+
+
+@pytest.mark.parametrize("lanes", [4, 5, 6])
+@pytest.mark.parametrize("n", [1, 7, 9, 31, 33, 63, 65, 4095, 4097, 20011])
+def test_tail_k_taps_per_lane_ragged_blocks(oracle, hip, lanes, n):
+    """k_tailk on blocks shorter than the LMS order, one sample over a multiple of it, and with the last job of a wave
+    missing (3 channels: the job count is not a multiple of the jobs per wave)"""
+    pcm = W.music_like(3, n, 16, seed=n)
+    p = S.make_params(3, 16, 48000, 8, 3, 8, 0, 1, 2048)
+    ret, want = oracle.encode_whole(p, pcm)
+    assert ret == 0
+    got, _ = _encode_with_options(hip, p, pcm, tail_lanes=lanes)
     assert got == want
 
 
