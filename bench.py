@@ -341,9 +341,12 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
         dist.barrier()
     kernel_ms = np.zeros(12)
     span_ms[:] = 0.0
+    step_wall = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         kernel_ms += np.array(step())
+        step_wall.append(time.perf_counter() - ts)
     for b in range(nbuf):
         settle(b)                                             # every collective of the timed steps has landed
     torch.cuda.synchronize()
@@ -366,6 +369,10 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
 
     out = {
         "value": round(value, 3), "unit": "Msamples/s", "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
+        # value and ms_per_step are the contract's mean over exactly K steps; the per-step spread beside them (one call
+        # per step, synchronous at N = 1): a host stall -- the boxes' CPU quota, see DESIGN section 7 -- shows as max >> median
+        "ms_per_step_median": round(float(np.median(step_wall)) * 1e3, 3) if step_wall else None,
+        "ms_per_step_max": round(float(np.max(step_wall)) * 1e3, 3) if step_wall else None,
         "config": {"workload": WORKLOAD_NAME[cfg] + (", batch of %d clips on this GPU in one pass" % batch["count"] if batch else "")
                                + (", ONE file of %d x that length sharded over %d ranks" % (world, world) if world > 1 and batch is None and args.scaling == "weak" else "")
                                + (", that ONE file sharded over %d ranks" % world if world > 1 and batch is None and args.scaling == "strong" else ""),

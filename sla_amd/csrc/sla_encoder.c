@@ -1412,17 +1412,6 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c, int mode)
                                (uint32_t*)e->d_rshift.ptr, bs));
     }
     HIPCHK(hipEventRecord(ev[EV_LPCB_E], bs));
-    /* the LPC results go home while lattice and FFT run: the host decides RAW blocks in the meantime */
-    HIPCHK(hipStreamWaitEvent(e->stream_down, ev[EV_LPCB_E], 0));
-    HIPCHK(hipMemcpyAsync((double*)e->h_blk_out.ptr + slot_lo * O2, (double*)e->d_blk_out.ptr + slot_lo * O2, sizeof(double) * nsl * O2, hipMemcpyDeviceToHost, e->stream_down));
-    HIPCHK(hipMemcpyAsync((int32_t*)e->h_code.ptr + slot_lo * O1, (int32_t*)e->d_code.ptr + slot_lo * O1, sizeof(int32_t) * nsl * O1, hipMemcpyDeviceToHost, e->stream_down));
-    HIPCHK(hipMemcpyAsync((int32_t*)e->h_kint.ptr + slot_lo * O1, (int32_t*)e->d_kint.ptr + slot_lo * O1, sizeof(int32_t) * nsl * O1, hipMemcpyDeviceToHost, e->stream_down));
-    HIPCHK(hipMemcpyAsync((uint32_t*)e->h_rshift.ptr + slot_lo, (uint32_t*)e->d_rshift.ptr + slot_lo, sizeof(uint32_t) * nsl, hipMemcpyDeviceToHost, e->stream_down));
-    if (use_cert) {
-      HIPCHK(hipMemcpyAsync((uint32_t*)e->h_cert_flag.ptr + slot_lo, (uint32_t*)e->d_cert_flag.ptr + slot_lo, sizeof(uint32_t) * nsl, hipMemcpyDeviceToHost, e->stream_down));
-      HIPCHK(hipMemcpyAsync((uint32_t*)e->h_cert_flag.ptr + cnt_base + c, (uint32_t*)e->d_fb_count.ptr + c, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream_down));
-    }
-    HIPCHK(hipEventRecord(ev[EV_LPC_DOWN], e->stream_down));
     /* pass 2 (k_lpc_blocks is running): lattice chunks and FFT jobs */
     if (mode == 0) {
       uint32_t g = k->bg_lo;
@@ -1465,6 +1454,19 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c, int mode)
       HIPCHK(hipMemcpyAsync((double*)e->h_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD, (double*)e->d_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD,
                             sizeof(double) * (size_t)ng * SLAI_LTM_ACF_HEAD, hipMemcpyDeviceToHost, e->stream_down));
     }
+    /* The LPC results go home while lattice and FFT run: the host decides RAW blocks in the meantime.  Queued behind every
+     * kernel launch of the stage: seven more API calls between the block kernels and the lattice launch left the device
+     * waiting for the host whenever one of them was slow (seen as 0.3 - 0.6 ms in the lattice stage of some C2 steps). */
+    HIPCHK(hipStreamWaitEvent(e->stream_down, ev[EV_LPCB_E], 0));
+    HIPCHK(hipMemcpyAsync((double*)e->h_blk_out.ptr + slot_lo * O2, (double*)e->d_blk_out.ptr + slot_lo * O2, sizeof(double) * nsl * O2, hipMemcpyDeviceToHost, e->stream_down));
+    HIPCHK(hipMemcpyAsync((int32_t*)e->h_code.ptr + slot_lo * O1, (int32_t*)e->d_code.ptr + slot_lo * O1, sizeof(int32_t) * nsl * O1, hipMemcpyDeviceToHost, e->stream_down));
+    HIPCHK(hipMemcpyAsync((int32_t*)e->h_kint.ptr + slot_lo * O1, (int32_t*)e->d_kint.ptr + slot_lo * O1, sizeof(int32_t) * nsl * O1, hipMemcpyDeviceToHost, e->stream_down));
+    HIPCHK(hipMemcpyAsync((uint32_t*)e->h_rshift.ptr + slot_lo, (uint32_t*)e->d_rshift.ptr + slot_lo, sizeof(uint32_t) * nsl, hipMemcpyDeviceToHost, e->stream_down));
+    if (use_cert) {
+      HIPCHK(hipMemcpyAsync((uint32_t*)e->h_cert_flag.ptr + slot_lo, (uint32_t*)e->d_cert_flag.ptr + slot_lo, sizeof(uint32_t) * nsl, hipMemcpyDeviceToHost, e->stream_down));
+      HIPCHK(hipMemcpyAsync((uint32_t*)e->h_cert_flag.ptr + cnt_base + c, (uint32_t*)e->d_fb_count.ptr + c, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream_down));
+    }
+    HIPCHK(hipEventRecord(ev[EV_LPC_DOWN], e->stream_down));
   } else {
     HIPCHK(hipEventRecord(ev[EV_LPCB_E], bs));
     HIPCHK(hipEventRecord(ev[EV_LPC_DOWN], e->stream_down));

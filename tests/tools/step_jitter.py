@@ -30,10 +30,26 @@ for _ in range(3):
     enc.analyze_device(d_pcm.data_ptr(), stride, n)
 t = np.zeros(steps)
 parts = []
+
+
+def cg():
+    try:
+        d = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat").read().strip().splitlines())
+        return int(d["usage_usec"]), int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0))
+    except OSError:
+        return 0, 0, 0
+
+
+cg0, pt0, w0 = cg(), os.times(), time.perf_counter()
 for i in range(steps):
     t0 = time.perf_counter()
     parts.append(enc.analyze_device(d_pcm.data_ptr(), stride, n))
     t[i] = (time.perf_counter() - t0) * 1e3
+cg1, pt1, w1 = cg(), os.times(), time.perf_counter()
+wall = w1 - w0
+print("wall %.3f s: this process %.2f cores (user %.2f sys %.2f), cgroup %.2f cores, throttled %d times for %.1f ms"
+      % (wall, (pt1[0] + pt1[1] - pt0[0] - pt0[1]) / wall, (pt1[0] - pt0[0]) / wall, (pt1[1] - pt0[1]) / wall,
+         (cg1[0] - cg0[0]) / 1e6 / wall, cg1[1] - cg0[1], (cg1[2] - cg0[2]) / 1e3))
 med = np.median(t)
 print("%s %ds: %d steps, median %.3f mean %.3f min %.3f p90 %.3f p99 %.3f max %.3f ms" % (cfg, seconds, steps, med, t.mean(), t.min(), np.percentile(t, 90), np.percentile(t, 99), t.max()))
 for i in range(steps):
