@@ -850,7 +850,8 @@ def test_random_parameter_walk_chunked(oracle, hip, seed):
     assert_same_as_oracle(oracle, hip, p, pcm, roundtrip=False)
     want = oracle.encode_trace(p, pcm)[1]
     for opts in ({"chunks": 3}, {"chunks": 2, "single_tail": 0}, {"chunks": 3, "device_ltm": 0}, {"chunks": 2, "alt_streams": 1},
-                 {"chunks": 3, "alt_streams": 1}):
+                 {"chunks": 3, "alt_streams": 1}, {"chunks": 2, "device_expand": 0}, {"chunks": 1, "tail_lanes": 4},
+                 {"chunks": 2, "tail_lanes": 5, "tail_waves": 2}):
         got, t = _encode_with_options(hip, p, pcm, **opts)
         assert got == want and t[9] == opts["chunks"], opts
 
