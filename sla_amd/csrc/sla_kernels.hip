@@ -449,6 +449,9 @@ void k_lpc(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32
 }
 
 #define LAT_T 16
+// (Measured and dropped: product and addition as ONE v_mad_u64_u32 whose high half is thrown away.  With two waves on a
+// SIMD it issues every 2.0 ns against 3.3 ns for v_mul_lo_u32 + v_add_u32 (tests/tools/ubench_int.hip), but at the eight
+// waves per SIMD this kernel runs with it takes the two issue slots of the pair: C5 16.1 ms per step either way.)
 __device__ __forceinline__ int32_t lat_term(int32_t k, int32_t v)
 {
   return (int32_t)((uint32_t)k * (uint32_t)v + 16384u) >> 15;

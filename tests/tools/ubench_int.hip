@@ -79,6 +79,34 @@ __global__ void dot_mad(uint32_t* out, uint32_t x) {
   }
   out[threadIdx.x] = a + (c << 16);
 }
+// low 32 bits of k*v + c by v_mad_u64_u32 (the high half is thrown away): is it issued like v_mul_lo_u32 + v_add_u32, or slower?
+__global__ void mad64_indep4(uint32_t* out, uint32_t x) {
+  unsigned long long a = threadIdx.x, b = 1, c = 2, d = 3;
+  const unsigned long long k = 16384;
+  for (int i = 0; i < N; i++) {
+#pragma unroll
+    for (int u = 0; u < U / 4; u++) {
+      asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(a) : "v"(x), "v"((uint32_t)a), "v"(k) : "vcc");
+      asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(b) : "v"(x), "v"((uint32_t)b), "v"(k) : "vcc");
+      asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(c) : "v"(x), "v"((uint32_t)c), "v"(k) : "vcc");
+      asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(x), "v"((uint32_t)d), "v"(k) : "vcc");
+    }
+  }
+  out[threadIdx.x] = (uint32_t)(a + b + c + d);
+}
+__global__ void muladd_indep4(uint32_t* out, uint32_t x) {
+  uint32_t a = threadIdx.x, b = 1, c = 2, d = 3;
+  for (int i = 0; i < N; i++) {
+#pragma unroll
+    for (int u = 0; u < U / 4; u++) {
+      asm volatile("v_mul_lo_u32 %0, %0, %1\n v_add_u32 %0, 0x4000, %0" : "+v"(a) : "v"(x));
+      asm volatile("v_mul_lo_u32 %0, %0, %1\n v_add_u32 %0, 0x4000, %0" : "+v"(b) : "v"(x));
+      asm volatile("v_mul_lo_u32 %0, %0, %1\n v_add_u32 %0, 0x4000, %0" : "+v"(c) : "v"(x));
+      asm volatile("v_mul_lo_u32 %0, %0, %1\n v_add_u32 %0, 0x4000, %0" : "+v"(d) : "v"(x));
+    }
+  }
+  out[threadIdx.x] = a + b + c + d;
+}
 __global__ void clock_probe(unsigned long long* out) {
   unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   uint32_t a = threadIdx.x;
@@ -106,6 +134,8 @@ int main() {
     printf("1 dep + 1 indep add      : %.2f ns per step\n", run([&] { hipLaunchKernelGGL(dep_plus_indep<1>, dim3(1), blk, 0, 0, d, 3u); }) * per);
     printf("1 dep + 2 indep add      : %.2f ns per step\n", run([&] { hipLaunchKernelGGL(dep_plus_indep<2>, dim3(1), blk, 0, 0, d, 3u); }) * per);
     printf("1 dep + 4 indep add      : %.2f ns per step\n", run([&] { hipLaunchKernelGGL(dep_plus_indep<4>, dim3(1), blk, 0, 0, d, 3u); }) * per);
+    printf("4 indep v_mad_u64_u32    : %.2f ns per instr\n", run([&] { hipLaunchKernelGGL(mad64_indep4, dim3(1), blk, 0, 0, d, 3u); }) * per);
+    printf("4 indep mul_lo + add     : %.2f ns per pair\n", run([&] { hipLaunchKernelGGL(muladd_indep4, dim3(1), blk, 0, 0, d, 3u); }) * per);
     printf("dot2_u16 + mad_u32_u16   : %.2f ns per pair\n", run([&] { hipLaunchKernelGGL(dot_mad, dim3(1), blk, 0, 0, d, 0x00030005u); }) * per * 2);
   }
   unsigned long long* q; hipMalloc(&q, 64); unsigned long long h[3];
