@@ -548,6 +548,9 @@ int sla_hip_get_trace(struct SLAEncoder* encoder, sla_hip_trace* trace);
  * instead of one for the file) [SLA_HIP_SINGLE_TAIL], "first_chunk" (1/1000 of the super-frames in pipeline chunk 0;
  * 0: built-in shares), "alt_streams" (block stages of odd and even pipeline chunks on two streams: 0 never, 1 / 2 = default:
  * whenever the file is cut into chunks).  SLAEncoder_EncodeWhole of long files: "stream" (0: never streamed) [SLA_HIP_STREAM],
+ * "device_expand" (1 = default: block tables of certified partitions written on the device, sla_hip_launch_expand, the
+ * host's copy following under the kernels; 0: host tables first) [SLA_HIP_EXPAND], "table_cache" (1 = default: the search
+ * tables of a file without silence are kept for the next file of the same length and parameters) [SLA_HIP_TABLE_CACHE],
  * "upload24" (1 = default: pageable input of 17..24 significant bits crosses the bus as three bytes per sample; DESIGN
  * section 7 has the A/B) [SLA_HIP_UPLOAD24], "stream_piece" (samples per piece, all channels together; default 32 Mi; a file of fewer than two pieces is not
  * streamed), "stream_lanes" (worker lanes, 1..4, default 4).  After a streamed call the handle holds no analysis tables:
@@ -570,8 +573,10 @@ int sla_hip_last_counters(const struct SLAEncoder* encoder, uint32_t* counters);
  * (block, channel) pairs its certificate handed to the exact chain kernels. */
 int sla_hip_last_block_cert(const struct SLAEncoder* encoder, uint32_t* counters);
 
-/* 2 counters of the last analysis: pipeline chunks whose block stage was launched from device-written tables
- * (sla_hip_launch_expand; option "device_expand"), pipeline chunks in all. */
+/* 3 counters: pipeline chunks of the last analysis whose block stage was launched from device-written tables
+ * (sla_hip_launch_expand; option "device_expand"), its pipeline chunks in all, and the analyses since the handle was
+ * created that found their search tables kept from the file before (same length and parameters, no silence; option
+ * "table_cache"). */
 int sla_hip_last_expand(const struct SLAEncoder* encoder, uint32_t* counters);
 
 /* 4 floats [ms]: execution time of k_lpc_blocks, k_lattice, k_ltm_acf, k_tail in the last analysis, summed over

@@ -421,8 +421,9 @@ class Encoder:
         return tuple(c)
 
     def last_expand(self):
-        """(pipeline chunks whose block stage was launched from device-written tables, pipeline chunks)"""
-        c = (C.c_uint32 * 2)()
+        """(pipeline chunks whose block stage was launched from device-written tables, pipeline chunks, analyses of this
+        handle served from kept search tables)"""
+        c = (C.c_uint32 * 3)()
         self._check(self._lib.sla_hip_last_expand(self._h, c), "sla_hip_last_expand")
         return tuple(c)
 

@@ -83,6 +83,14 @@ struct SLAEncoder {
                                      * stage launched from two counts, the host's own tables following under the kernels; 0: host tables first */
   uint32_t expand_seq;              /* sequence number of the last k_expand launch (what the host polls for) */
   uint32_t expanded_chunks;         /* last analysis: pipeline chunks whose block stage was launched from device tables */
+  /* Search tables (super-frames, candidate shapes, groups) of the last file WITHOUT silence, host and device copies, kept for
+   * the next file of the same shape: they depend on the length and the parameters only, and building + uploading them
+   * (40 - 90 us for a ten-minute file) is time the device spends idle behind the prepass.  option "table_cache" */
+  int      table_cache, tab_valid;
+  uint32_t tab_key[10], tab_cnt[12];
+  void*    tab_sf; void* tab_shapes;
+  uint32_t winmap_entries;          /* window list entries k_expand's device copy holds */
+  uint32_t table_hits;              /* analyses served from the kept tables since the handle was created */
   uint32_t blocks_exact;            /* last analysis: (block, channel) pairs the certificate handed to the exact kernel */
   sla_hip_tuning tune;              /* launcher knobs, named to the launchers at every API entry */
   uint32_t host_planned;            /* last analysis: super-frames whose partition the host had to decide */
@@ -372,6 +380,9 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   }
   e->search_exact = 1; e->exact_bits = 53; e->device_plan = 1; e->cert_safety = 64.0;
   e->block_cert = 1; e->block_cert_safety = 16.0;
+  e->table_cache = 1;
+  env = getenv("SLA_HIP_TABLE_CACHE");
+  if (env != NULL) { e->table_cache = (atoi(env) != 0); }
   e->device_expand = 1;
   env = getenv("SLA_HIP_EXPAND");
   if (env != NULL) { e->device_expand = (atoi(env) != 0); }
@@ -504,6 +515,7 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   if (e->fft != NULL) { slai_fft_plan_destroy(e->fft); }
   pool_destroy(e->pool);
   free(e->win_host); free(e->win_len); free(e->win_off);
+  free(e->tab_sf); free(e->tab_shapes);
   free(e->blk); free(e->bc); free(e->parcor); free(e->code); free(e->kint); free(e->parcor_exact);
   free(e);
 }
@@ -621,6 +633,7 @@ typedef struct {
   hipEvent_t* ev;                                 /* [nchunks][EV_PER_CHUNK]             */
   /* device-written block tables (k_expand) */
   int expand;                                     /* this run asks for them                       */
+  int borrowed;                                   /* sf / shapes belong to the encoder's table cache */
   uint32_t dev_blk, dev_bg;                       /* blocks / groups numbered by the device so far */
   uint8_t launched[MAX_CHUNKS];                   /* the chunk's block stage runs from them        */
   uint32_t dev_lo[MAX_CHUNKS][4];                 /* blk_lo, blk_hi, bg_lo, bg_hi it was launched with */
@@ -720,7 +733,8 @@ static void ltm_one(void* vctx, uint32_t rel)
 
 static void actx_free(actx_t* a)
 {
-  free(a->sf); free(a->shapes); free(a->job_blk); free(a->job_ch); free(a->job_grp); free(a->grp_of_slot);
+  if (!a->borrowed) { free(a->sf); free(a->shapes); }
+  free(a->job_blk); free(a->job_ch); free(a->job_grp); free(a->grp_of_slot);
   free(a->parts); free(a->nparts); free(a->status);
 }
 
@@ -906,7 +920,41 @@ static int upload_search_tables(struct SLAEncoder* e, const actx_t* a)
     for (i = 0; i < e->win_entries; i++) { hw[i] = e->win_len[i]; hw[e->win_entries + i] = e->win_off[i]; }
     HIPCHK(hipMemcpyAsync(e->d_sframes.ptr, hs, sizeof(sla_hip_superframe) * a->nsf, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->d_winmap.ptr, hw, sizeof(uint32_t) * 2 * e->win_entries, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemsetAsync(e->d_run.ptr, 0, 16, e->stream));
+    e->winmap_entries = e->win_entries;
+  }
+  return 0;
+}
+
+/* tables of a file without silence: from the cache when the last such file had the same shape, else built, uploaded, kept */
+static int tables_no_silence(struct SLAEncoder* e, actx_t* a)
+{
+  uint32_t key[10];
+  key[0] = e->num_samples; key[1] = e->wave_format.num_channels; key[2] = e->wave_format.bit_per_sample;
+  key[3] = e->encode_param.parcor_order; key[4] = e->encode_param.max_num_block_samples;
+  key[5] = (uint32_t)e->encode_param.window_function_type; key[6] = (uint32_t)(e->device_expand && e->device_plan);
+  key[7] = e->win_entries; key[8] = (uint32_t)e->win_count; key[9] = 1u;
+  if (e->table_cache && e->tab_valid && !e->win_dirty && memcmp(key, e->tab_key, sizeof(key)) == 0) {
+    const uint32_t* c = e->tab_cnt;
+    a->sf = (sframe_t*)e->tab_sf; a->shapes = (shape_t*)e->tab_shapes; a->borrowed = 1;
+    a->nsf = c[0]; a->nshapes = c[1]; a->ncands = c[2]; a->nsgroups = c[3]; a->nslots = c[4]; a->max_window = c[5];
+    a->max_cpg = c[6]; a->nxg = c[7]; a->max_xcands = c[8]; a->blocks_bound = c[9]; a->lchunks_bound = c[10];
+    e->table_hits++;
+    return pipeline_reserve(e, a);
+  }
+  e->tab_valid = 0;
+  free(e->tab_sf); free(e->tab_shapes); e->tab_sf = NULL; e->tab_shapes = NULL;
+  RCCHK(build_tables(e, a, NULL));
+  RCCHK(pipeline_reserve(e, a));
+  RCCHK(upload_search_tables(e, a));
+  if (e->table_cache) {
+    uint32_t* c = e->tab_cnt;
+    /* (the window list may have grown while the tables were built: the key holds what it is now) */
+    key[7] = e->win_entries; key[8] = (uint32_t)e->win_count;
+    c[0] = a->nsf; c[1] = a->nshapes; c[2] = a->ncands; c[3] = a->nsgroups; c[4] = a->nslots; c[5] = a->max_window;
+    c[6] = a->max_cpg; c[7] = a->nxg; c[8] = a->max_xcands; c[9] = a->blocks_bound; c[10] = a->lchunks_bound;
+    memcpy(e->tab_key, key, sizeof(key));
+    e->tab_sf = a->sf; e->tab_shapes = a->shapes; a->borrowed = 1;
+    e->tab_valid = 1;
   }
   return 0;
 }
@@ -926,6 +974,7 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
     /* batch: sla_hip_encode_batch ran the prepass over all files, the whole mask is on the host and the files of
      * this pass share one offset_lshift */
     e->lshift = e->batch_lshift; e->h_or[0] = e->batch_or;
+    e->tab_valid = 0;                                     /* the batch's tables take the place of the kept ones */
     RCCHK(build_tables(e, a, (const uint64_t*)e->h_nz.ptr));
     a->exact = (e->search_exact && SLAI_SEARCH_DELTA == SLA_HIP_XTILE && maxb <= SLA_HIP_XTILE * SLA_HIP_XTILES
                 && sla_hip_search_exact_lags(order) != 0 && e->h_or[0] != 0);
@@ -948,9 +997,7 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
     if (e->nz_ones_cap != e->h_nz.cap) { e->nz_ones_cap = e->h_nz.cap; e->nz_ones_words = 0; }
     if (e->nz_ones_words < nwords) { memset((uint64_t*)e->h_nz.ptr + e->nz_ones_words, 0xFF, (size_t)(nwords - e->nz_ones_words) * 8); }
     e->nz_ones_words = nwords;
-    RCCHK(build_tables(e, a, NULL));
-    RCCHK(pipeline_reserve(e, a));
-    RCCHK(upload_search_tables(e, a));
+    RCCHK(tables_no_silence(e, a));
   } else {
   RCCHK(sla_hip_launch_prepass(e->pcm_dev, e->stride, C, n, bps, ms, (uint32_t*)e->d_or.ptr, (uint64_t*)e->d_nz.ptr, e->stream));
   HIPCHK(hipEventRecord(e->ev[1], e->stream));
@@ -967,9 +1014,7 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
     /* while the prepass runs: the tables of a file without silence (the usual case; checked below), every buffer of
      * the pipeline, and the tables on their way to the device behind the prepass -- so that the first search kernel
      * can follow the host's look at the prepass result without further copies in between */
-    RCCHK(build_tables(e, a, NULL));
-    RCCHK(pipeline_reserve(e, a));
-    RCCHK(upload_search_tables(e, a));
+    RCCHK(tables_no_silence(e, a));
     HIPCHK(hipEventSynchronize(e->ev_prep));
     if (e->h_or[1] != 0) {
       HIPCHK(hipMemcpyAsync(e->h_nz.ptr, e->d_nz.ptr, (size_t)head_words * 8, hipMemcpyDeviceToHost, e->stream));
@@ -1015,7 +1060,9 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
     if (slai_zero_run(nz, f->start, window) >= min_blk) { rebuild = 1; }
   }
   if (rebuild) {
-    free(a->sf); free(a->shapes); a->sf = NULL; a->shapes = NULL;
+    if (!a->borrowed) { free(a->sf); free(a->shapes); }
+    a->borrowed = 0; e->tab_valid = 0;                      /* the tables with silence overwrite the kept ones' device copies */
+    a->sf = NULL; a->shapes = NULL;
     a->nsf = 0; a->nshapes = 0; a->ncands = 0; a->nsgroups = 0; a->nslots = 0; a->nxg = 0;
     a->blocks_bound = 0; a->lchunks_bound = 0;
     RCCHK(build_tables(e, a, nz));
@@ -1028,7 +1075,7 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
    * all-zero word (or the caller vouched for that), so no run of zeros reaches SLA's minimum block length; whole SILENT
    * super-frames (only the file's last one can be, then) are in the table the kernel reads. */
   a->expand = (e->device_expand && e->device_plan && e->nsegs == 0 && !rebuild && e->h_or[1] == 0 && a->nsf > 0
-               && e->win_entries > 0 && e->win_entries <= 256 && a->max_window <= MAX_ANALYSIS_WINDOW
+               && e->winmap_entries > 0 && e->winmap_entries <= 256 && a->max_window <= MAX_ANALYSIS_WINDOW
                && e->d_sframes.ptr != NULL && e->h_counts.ptr != NULL);
   return 0;
 }
@@ -1177,10 +1224,11 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
         volatile uint32_t* hc = (volatile uint32_t*)e->h_counts.ptr + 4 * (size_t)c;
         const uint32_t bps = e->wave_format.bit_per_sample;
         hc[0] = hc[1] = hc[2] = hc[3] = 0;
+        if (c == 0) { HIPCHK(hipMemsetAsync(e->d_run.ptr, 0, 16, e->stream)); }      /* the running block / group numbers restart */
         RCCHK(sla_hip_launch_expand((const sla_hip_superframe*)e->d_sframes.ptr + k->sf_lo, k->sf_hi - k->sf_lo,
                                     (const uint32_t*)e->d_parts.ptr, (const uint32_t*)e->d_nparts.ptr, (const uint32_t*)e->d_pstatus.ptr,
-                                    C, 32 - bps + e->lshift, (const uint32_t*)e->d_winmap.ptr, (const uint32_t*)e->d_winmap.ptr + e->win_entries,
-                                    e->win_entries, (uint32_t*)e->d_run.ptr, (sla_hip_lpc_group*)e->d_bgroups.ptr, (sla_hip_lpc_cand*)e->d_bcands.ptr,
+                                    C, 32 - bps + e->lshift, (const uint32_t*)e->d_winmap.ptr, (const uint32_t*)e->d_winmap.ptr + e->winmap_entries,
+                                    e->winmap_entries, (uint32_t*)e->d_run.ptr, (sla_hip_lpc_group*)e->d_bgroups.ptr, (sla_hip_lpc_cand*)e->d_bcands.ptr,
                                     (sla_hip_acf_job*)e->d_acf_jobs.ptr, a->blocks_bound * C, (uint32_t*)e->h_counts.ptr + 4 * (size_t)c,
                                     e->expand_seq, e->stream));
         HIPCHK(hipEventRecord(ev[EV_EXPANDED], e->stream));
@@ -1930,6 +1978,7 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   else if (strcmp(name, "first_chunk") == 0)       { OPT_RANGE(0, 999); e->first_chunk = (uint32_t)iv; }
   else if (strcmp(name, "alt_streams") == 0)       { OPT_RANGE(0, 2); e->alt_streams = (int)iv; }
   else if (strcmp(name, "device_expand") == 0)     { OPT_RANGE(0, 1); e->device_expand = (int)iv; }
+  else if (strcmp(name, "table_cache") == 0)       { OPT_RANGE(0, 1); e->table_cache = (int)iv; e->tab_valid = 0; }
   else if (strcmp(name, "device_ltm") == 0)        { OPT_RANGE(0, 1); e->device_ltm = (int)iv; }
   else if (strcmp(name, "fuse_lattice") == 0)      { OPT_RANGE(0, 1); e->fuse_lattice = (int)iv && !e->tune.lpc_blocks_chains; }
   else if (strcmp(name, "threads") == 0) {
@@ -2134,7 +2183,7 @@ int sla_hip_last_counters(const struct SLAEncoder* e, uint32_t* counters)
 int sla_hip_last_expand(const struct SLAEncoder* e, uint32_t* counters)
 {
   if (e == NULL || counters == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
-  counters[0] = e->expanded_chunks; counters[1] = (uint32_t)e->timing[9];
+  counters[0] = e->expanded_chunks; counters[1] = (uint32_t)e->timing[9]; counters[2] = e->table_hits;
   return 0;
 }
 

@@ -31,7 +31,7 @@ def _encode(hip, p, pcm, **options):
         enc.set_encode_parameter(p.parcor_order, p.longterm_order, p.lms_order, p.ch_process_method,
                                  p.window_type, p.max_block_samples)
         data = enc.encode_whole(pcm)
-        return data, enc.last_expand(), enc.last_counters()
+        return data, enc.last_expand()[:2], enc.last_counters()
     finally:
         enc.close()
 
@@ -140,5 +140,41 @@ def test_handle_reuse_across_routes(oracle, hip):
             assert ret == 0
             assert enc.encode_whole(pcm) == want
             assert (enc.last_expand()[0] == 0) == (i == 2)
+    finally:
+        enc.close()
+
+
+def test_kept_search_tables(oracle, hip):
+    """option "table_cache": the search tables of a file without silence serve the next file of the same length and
+    parameters; any other file in between (another length, silence, other parameters, a batch) replaces or drops them"""
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096)
+    enc = hip.Encoder(p.cap_channels, p.cap_block_samples, p.cap_parcor_order, p.cap_longterm_order, p.cap_lms_order)
+    try:
+        enc.set_option("stream", 0)
+        enc.set_wave_format(2, 16, 48000)
+        enc.set_encode_parameter(16, 1, 8, 1, 1, 4096)
+        hits = []
+        plan = [(200000, False), (200000, False), (200000, True), (200000, False), (200000, False), (150001, False), (200000, False),
+                (200000, False)]
+        for i, (n, gap) in enumerate(plan):
+            pcm = W.music_like(2, n, 16, seed=40 + i)
+            if gap:
+                pcm[:, 50000:80000] = 0
+            ret, want = oracle.encode_whole(p, pcm)
+            assert ret == 0
+            assert enc.encode_whole(pcm) == want
+            hits.append(enc.last_expand()[2])
+        # file 1 reuses file 0's tables; so does the file with silence at first (the tables are the guess made while the
+        # prepass runs) -- and drops them when the prepass reports silence; 3 rebuilds, 4 reuses; another length replaces them
+        assert hits == [0, 1, 2, 2, 3, 3, 3, 4], hits
+        # other parameters: new tables, and the same bytes as a fresh handle
+        enc.set_encode_parameter(8, 1, 8, 1, 1, 2048)
+        p2 = S.make_params(2, 16, 48000, 8, 1, 8, 1, 1, 2048)
+        pcm = W.music_like(2, 200000, 16, seed=99)
+        ret, want = oracle.encode_whole(p2, pcm)
+        assert ret == 0 and enc.encode_whole(pcm) == want
+        assert enc.last_expand()[2] == 4
+        enc.set_option("table_cache", 0)
+        assert enc.encode_whole(pcm) == want and enc.last_expand()[2] == 4
     finally:
         enc.close()
