@@ -573,10 +573,11 @@ int sla_hip_last_counters(const struct SLAEncoder* encoder, uint32_t* counters);
  * (block, channel) pairs its certificate handed to the exact chain kernels. */
 int sla_hip_last_block_cert(const struct SLAEncoder* encoder, uint32_t* counters);
 
-/* 3 counters: pipeline chunks of the last analysis whose block stage was launched from device-written tables
- * (sla_hip_launch_expand; option "device_expand"), its pipeline chunks in all, and the analyses since the handle was
- * created that found their search tables kept from the file before (same length and parameters, no silence; option
- * "table_cache"). */
+/* 4 counters: pipeline chunks of the last analysis whose block stage was launched from device-written tables
+ * (sla_hip_launch_expand; option "device_expand"), its pipeline chunks in all; since the handle was created: the analyses
+ * that found their search tables kept from the file before (same length and parameters, no silence; option
+ * "table_cache"), and those among them whose searches -- launched behind the prepass on the guess that the file is like
+ * the last one (short files only) -- had to go out again because the prepass said otherwise. */
 int sla_hip_last_expand(const struct SLAEncoder* encoder, uint32_t* counters);
 
 /* 4 floats [ms]: execution time of k_lpc_blocks, k_lattice, k_ltm_acf, k_tail in the last analysis, summed over

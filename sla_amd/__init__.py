@@ -422,8 +422,8 @@ class Encoder:
 
     def last_expand(self):
         """(pipeline chunks whose block stage was launched from device-written tables, pipeline chunks, analyses of this
-        handle served from kept search tables)"""
-        c = (C.c_uint32 * 3)()
+        handle served from kept search tables, searches launched on a wrong guess of the prepass result)"""
+        c = (C.c_uint32 * 4)()
         self._check(self._lib.sla_hip_last_expand(self._h, c), "sla_hip_last_expand")
         return tuple(c)
 

@@ -91,6 +91,8 @@ struct SLAEncoder {
   void*    tab_sf; void* tab_shapes;
   uint32_t winmap_entries;          /* window list entries k_expand's device copy holds */
   uint32_t table_hits;              /* analyses served from the kept tables since the handle was created */
+  int      spec_valid; uint32_t spec_or;    /* the last file had no silence / its OR word: the guess for the next one of its shape */
+  uint32_t spec_misses;             /* guesses that turned out wrong */
   uint32_t blocks_exact;            /* last analysis: (block, channel) pairs the certificate handed to the exact kernel */
   sla_hip_tuning tune;              /* launcher knobs, named to the launchers at every API entry */
   uint32_t host_planned;            /* last analysis: super-frames whose partition the host had to decide */
@@ -602,6 +604,7 @@ static int blocks_push(struct SLAEncoder* e, uint32_t start, uint32_t nsmpl, uin
  * All buffers are sized for the whole file before the first launch: nothing is reallocated in flight. */
 
 #define MAX_CHUNKS 8
+#define SPECULATE_MAX_GROUPS 16384u      /* (super-frame, channel) pairs up to which the searches are launched on a guess */
 enum { EV_SEARCH_S, EV_SEARCH_E, EV_SEARCH_DONE, EV_LPCB_S, EV_LPCB_E, EV_LAT_E, EV_ACF_S, EV_ACF_E, EV_BLOCK_DONE,
        EV_TAIL_S, EV_TAIL_E, EV_TAIL_DONE, EV_UPLOADED, EV_PLANNED, EV_UPLOADED2, EV_LPC_DOWN, EV_SOLVED, EV_EXPANDED, EV_PER_CHUNK };
 typedef char ev_array_holds_every_chunk[(2 + MAX_CHUNKS * EV_PER_CHUNK <= 2 + 8 * 20) ? 1 : -1];
@@ -634,6 +637,10 @@ typedef struct {
   /* device-written block tables (k_expand) */
   int expand;                                     /* this run asks for them                       */
   int borrowed;                                   /* sf / shapes belong to the encoder's table cache */
+  int tab_hit;                                    /* ... and were found there                         */
+  int spec;                                       /* the searches are in flight on a guess of the prepass result */
+  uint32_t or_word;                               /* OR of all input words the search was launched with */
+  int trace; double t_begin;                      /* for the timeline when the searches go out from pipeline_prepare */
   uint32_t dev_blk, dev_bg;                       /* blocks / groups numbered by the device so far */
   uint8_t launched[MAX_CHUNKS];                   /* the chunk's block stage runs from them        */
   uint32_t dev_lo[MAX_CHUNKS][4];                 /* blk_lo, blk_hi, bg_lo, bg_hi it was launched with */
@@ -935,7 +942,7 @@ static int tables_no_silence(struct SLAEncoder* e, actx_t* a)
   key[7] = e->win_entries; key[8] = (uint32_t)e->win_count; key[9] = 1u;
   if (e->table_cache && e->tab_valid && !e->win_dirty && memcmp(key, e->tab_key, sizeof(key)) == 0) {
     const uint32_t* c = e->tab_cnt;
-    a->sf = (sframe_t*)e->tab_sf; a->shapes = (shape_t*)e->tab_shapes; a->borrowed = 1;
+    a->sf = (sframe_t*)e->tab_sf; a->shapes = (shape_t*)e->tab_shapes; a->borrowed = 1; a->tab_hit = 1;
     a->nsf = c[0]; a->nshapes = c[1]; a->ncands = c[2]; a->nsgroups = c[3]; a->nslots = c[4]; a->max_window = c[5];
     a->max_cpg = c[6]; a->nxg = c[7]; a->max_xcands = c[8]; a->blocks_bound = c[9]; a->lchunks_bound = c[10];
     e->table_hits++;
@@ -959,10 +966,41 @@ static int tables_no_silence(struct SLAEncoder* e, actx_t* a)
   return 0;
 }
 
+/* SLA_HIP_TRACE=1: host-side timeline of one analysis on stderr (ms since the start of run_pipeline) */
+#define TRACE(label, c) do { if (trace) { fprintf(stderr, "[sla_hip] %8.3f ms  %s %d\n", now_ms() - t_begin, (label), (int)(c)); } } while (0)
+static int launch_searches(struct SLAEncoder* e, actx_t* a, int preset_blocks, int trace, double t_begin);
+
+/* offset_lshift = bps - (32 - ntz(OR of all words))          src/SLAEncoder.c:425-455 */
+static int lshift_of(uint32_t mask, uint32_t bps, uint32_t* lshift)
+{
+  *lshift = 0;
+  if (mask != 0) {
+    const uint32_t ntz = (uint32_t)__builtin_ctz(mask);
+    if (bps < 32 - ntz) { return SLA_APIRESULT_INVALID_ARGUMENT; }   /* samples wider than declared */
+    *lshift = bps - (32 - ntz);
+    if (*lshift >= bps) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  }
+  return 0;
+}
+
+/* routes that depend on what the prepass found (or is guessed to find): tile-sum search, device-written block tables */
+static void decide_routes(struct SLAEncoder* e, actx_t* a, uint32_t or_word, int silence)
+{
+  const uint32_t order = e->encode_param.parcor_order, maxb = e->encode_param.max_num_block_samples;
+  a->or_word = or_word;
+  a->exact = (e->search_exact && SLAI_SEARCH_DELTA == SLA_HIP_XTILE && maxb <= SLA_HIP_XTILE * SLA_HIP_XTILES
+              && sla_hip_search_exact_lags(order) != 0 && or_word != 0);
+  /* Block tables on the device (k_expand) where no block inside a searched super-frame can be SILENT: the mask has no
+   * all-zero word (or the caller vouched for that), so no run of zeros reaches SLA's minimum block length; whole SILENT
+   * super-frames (only the file's last one can be, then) are in the table the kernel reads. */
+  a->expand = (e->device_expand && e->device_plan && e->nsegs == 0 && !silence && a->nsf > 0
+               && e->winmap_entries > 0 && e->winmap_entries <= 256 && a->max_window <= MAX_ANALYSIS_WINDOW
+               && e->d_sframes.ptr != NULL && e->h_counts.ptr != NULL);
+}
+
 static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
 {
   const uint32_t C = e->wave_format.num_channels, bps = e->wave_format.bit_per_sample;
-  const uint32_t order = e->encode_param.parcor_order;
   const uint32_t ms = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
   const uint32_t n = e->num_samples, maxb = e->encode_param.max_num_block_samples;
   const uint64_t nwords = ((uint64_t)n + 63) / 64;
@@ -976,10 +1014,9 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
     e->lshift = e->batch_lshift; e->h_or[0] = e->batch_or;
     e->tab_valid = 0;                                     /* the batch's tables take the place of the kept ones */
     RCCHK(build_tables(e, a, (const uint64_t*)e->h_nz.ptr));
-    a->exact = (e->search_exact && SLAI_SEARCH_DELTA == SLA_HIP_XTILE && maxb <= SLA_HIP_XTILE * SLA_HIP_XTILES
-                && sla_hip_search_exact_lags(order) != 0 && e->h_or[0] != 0);
     RCCHK(pipeline_reserve(e, a));
     RCCHK(upload_search_tables(e, a));
+    decide_routes(e, a, e->h_or[0], 1);
     return 0;
   }
   RCCHK(dev_reserve(&e->d_or, 64));
@@ -1015,6 +1052,18 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
      * the pipeline, and the tables on their way to the device behind the prepass -- so that the first search kernel
      * can follow the host's look at the prepass result without further copies in between */
     RCCHK(tables_no_silence(e, a));
+    /* The kept tables are a file like the last one: when that one had no silence, guess that this one has none either and
+     * the same OR word, and put the searches on the stream right behind the prepass instead of behind the host's look at
+     * its result (50 - 60 us of launch calls, during which the device would stand idle).  The guess is checked below; a
+     * wrong one costs the device one search of a short file (the guess is not made for long ones) before the right one. */
+    if (a->tab_hit && e->spec_valid && e->table_cache && (uint64_t)a->nsf * C <= SPECULATE_MAX_GROUPS) {
+      const uint32_t guess = (e->file_or_word != 0) ? e->file_or_word : e->spec_or;
+      if (guess != 0 && lshift_of(guess, bps, &e->lshift) == 0) {
+        decide_routes(e, a, guess, 0);
+        a->spec = 1;
+        RCCHK(launch_searches(e, a, 0, a->trace, a->t_begin));
+      }
+    }
     HIPCHK(hipEventSynchronize(e->ev_prep));
     if (e->h_or[1] != 0) {
       HIPCHK(hipMemcpyAsync(e->h_nz.ptr, e->d_nz.ptr, (size_t)head_words * 8, hipMemcpyDeviceToHost, e->stream));
@@ -1038,17 +1087,7 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
   }
   PTRACE("prepass + mask on the host");
 
-  /* offset_lshift = bps - (32 - ntz(OR of all words))          src/SLAEncoder.c:425-455 */
-  {
-    const uint32_t mask = e->h_or[0];
-    e->lshift = 0;
-    if (mask != 0) {
-      const uint32_t ntz = (uint32_t)__builtin_ctz(mask);
-      if (bps < 32 - ntz) { return SLA_APIRESULT_INVALID_ARGUMENT; }   /* samples wider than declared */
-      e->lshift = bps - (32 - ntz);
-      if (e->lshift >= bps) { return SLA_APIRESULT_INVALID_ARGUMENT; }
-    }
-  }
+  RCCHK(lshift_of(e->h_or[0], bps, &e->lshift));
 
   /* without all-zero mask words only the last super-frame can still be silent (its minimum block length is what
    * is left of the file) */
@@ -1069,14 +1108,12 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
     RCCHK(pipeline_reserve(e, a));
     RCCHK(upload_search_tables(e, a));
   }
-  a->exact = (e->search_exact && SLAI_SEARCH_DELTA == SLA_HIP_XTILE && maxb <= SLA_HIP_XTILE * SLA_HIP_XTILES
-              && sla_hip_search_exact_lags(order) != 0 && e->h_or[0] != 0);
-  /* Block tables on the device (k_expand) where no block inside a searched super-frame can be SILENT: the mask has no
-   * all-zero word (or the caller vouched for that), so no run of zeros reaches SLA's minimum block length; whole SILENT
-   * super-frames (only the file's last one can be, then) are in the table the kernel reads. */
-  a->expand = (e->device_expand && e->device_plan && e->nsegs == 0 && !rebuild && e->h_or[1] == 0 && a->nsf > 0
-               && e->winmap_entries > 0 && e->winmap_entries <= 256 && a->max_window <= MAX_ANALYSIS_WINDOW
-               && e->d_sframes.ptr != NULL && e->h_counts.ptr != NULL);
+  {
+    const int silence = (rebuild || e->h_or[1] != 0);
+    if (a->spec && (silence || e->h_or[0] != a->or_word)) { a->spec = 0; e->spec_misses++; }      /* guessed wrong: the searches go out again */
+    decide_routes(e, a, e->h_or[0], silence);
+    e->spec_valid = !silence; e->spec_or = e->h_or[0];
+  }
   return 0;
 }
 
@@ -1189,7 +1226,7 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     sla_hip_lpc_group* dx = (sla_hip_lpc_group*)e->d_xgroups.ptr + k->xg_lo;
     if (a->exact) {
       /* unit of the samples the search sees: 2^(ntz-31), halved by the mid channel's /2 */
-      const int ntz = __builtin_ctz(e->h_or[0]);
+      const int ntz = __builtin_ctz(a->or_word);
       const double limit = ldexp(1.0, e->exact_bits + 2 * (ntz - 31 - (int)ms));
       HIPCHK(hipEventRecord(ev[EV_SEARCH_S], e->stream));
       /* windows over the exactness limit (loud material wider than 16 bits): with the device plan their tile sums are
@@ -1679,9 +1716,90 @@ static int wait_counts(volatile const uint32_t* hc, uint32_t seq, hipEvent_t don
 
 static float ev_ms(hipEvent_t s, hipEvent_t t) { float ms = 0.f; return (hipEventElapsedTime(&ms, s, t) == hipSuccess) ? ms : 0.f; }
 
+/* spans, chunk cuts and the search kernels of every chunk (+ k_plan, k_expand and the copies behind them).  Called once
+ * the prepass result is known -- or, on a guess, while the prepass is still running (pipeline_prepare). */
+static int launch_searches(struct SLAEncoder* e, actx_t* a, int preset_blocks, int trace, double t_begin)
+{
+  const uint32_t C = e->wave_format.num_channels;
+  uint32_t c, i, want_chunks;
+  int rc = 0;
+  e->expand_seq += 1; if (e->expand_seq == 0) { e->expand_seq = 1; }
+  memset(a->ck, 0, sizeof(a->ck));
+  /* the span slots are cleared on the search stream: every kernel that writes one is launched after the host has seen a
+   * search of this run complete, i.e. behind this memset */
+  if (dev_reserve(&e->d_spans, sizeof(unsigned long long) * MAX_CHUNKS * 4 * 2) != 0
+      || hipMemsetAsync(e->d_spans.ptr, 0, sizeof(unsigned long long) * MAX_CHUNKS * 4 * 2, e->stream) != hipSuccess
+      || (preset_blocks && hipStreamSynchronize(e->stream) != hipSuccess)) { return SLA_APIRESULT_NG; }
+  TRACE("reserved", 0);
+
+  /* chunking: equal runs of super-frames */
+  want_chunks = e->chunks;
+  /* chunks pay off once the kernels are throughput-bound; a short file (a 10-second clip: 118 super-frames) is one
+   * block's serial LMS / Rice chain per stage however it is cut, and every extra chunk adds one more of those */
+  if (preset_blocks || (a->nsf < 1024 && !e->chunks_forced)) { want_chunks = 1; }
+  /* Chunks exist to plan one part of the file on the host while the device works on another.  With device-written block
+   * tables nothing waits for the host, and one chunk saves the second set of launches and of half-filled kernels
+   * (tests/tools/chunk_sweep.py: C2 1.57 -> 1.39 ms, C3-600 s 2.89 -> 2.82, C5-120 s 5.15 -> 5.05) */
+  if (a->expand && !e->chunks_forced) { want_chunks = 1; }
+  if (want_chunks > a->nsf / 32 + 1) { want_chunks = a->nsf / 32 + 1; }
+  if (want_chunks > MAX_CHUNKS) { want_chunks = MAX_CHUNKS; }
+  if (want_chunks < 1) { want_chunks = 1; }
+  a->nchunks = want_chunks;
+  /* the block stages of the two chunks on two streams, so that one chunk's lattice / FFT kernels fill the gaps of the
+   * other's block stage.  Round 2 kept this to big files (k_lpc_blocks of a ten-minute mono file was too short to share
+   * the device: 2.32 -> 2.43 ms); with the certified block stage of round 3 the ten-minute mono file gains the most
+   * (1.61 -> 1.52 ms), C3-600 s 3.03 -> 2.96, C5-120 s 5.26 -> 5.33 (within the run-to-run spread): on whenever chunked */
+  e->alt_now = (e->alt_streams != 0);
+  if (!(e->device_ltm && e->single_tail) || a->nchunks < 2) { e->alt_now = 0; }
+  /* chunk boundaries in 1/1000 of the super-frames: equal parts unless SLA_HIP_CHUNK_SPLIT gave the shares */
+  if (e->first_chunk != 0 && a->nchunks >= 2) {
+    /* option first_chunk: that many 1/1000 of the super-frames in chunk 0, the others share the rest equally */
+    e->chunk_cut[0] = 0;
+    for (c = 1; c <= a->nchunks; c++) { e->chunk_cut[c] = e->first_chunk + (1000u - e->first_chunk) * (c - 1) / (a->nchunks - 1); }
+  } else if (e->split_count != a->nchunks && a->nchunks == 2) {
+    /* measured on C2, C3-600 s, C5-120 s (tests/tools/chunk_sweep.py, medians of interleaved rounds): two chunks, the
+     * first one short -- the host plans it while nothing else can run, and plans the second under the first one's
+     * kernels.  With one k_tail for the file (device long-term solve) 25 % / 75 % is best: 2.32 / 5.94 / 11.97 ms
+     * against 2.46 / 6.23 / 12.24 ms in one chunk; a third chunk only adds launches.  With a k_tail per chunk
+     * (host solve) every chunk costs one more serial LMS chain, and 40 % / 60 % was the best cut. */
+    e->chunk_cut[0] = 0; e->chunk_cut[1] = (e->device_ltm && e->single_tail && !e->alt_now) ? 250 : 400; e->chunk_cut[2] = 1000;
+  } else if (e->split_count != a->nchunks && a->nchunks == 3) {
+    e->chunk_cut[0] = 0; e->chunk_cut[1] = 250; e->chunk_cut[2] = 625; e->chunk_cut[3] = 1000;
+  } else if (e->split_count != a->nchunks) {
+    for (c = 0; c <= a->nchunks; c++) { e->chunk_cut[c] = 1000u * c / a->nchunks; }
+  } else {
+    uint32_t acc = 0, sum = 0;
+    for (c = 0; c < a->nchunks; c++) { sum += e->split[c]; }
+    for (c = 0; c <= a->nchunks; c++) { e->chunk_cut[c] = 1000u * acc / sum; if (c < a->nchunks) { acc += e->split[c]; } }
+  }
+  for (c = 0; c < a->nchunks; c++) {
+    chunk_t* k = &a->ck[c];
+    k->sf_lo = (uint32_t)((uint64_t)a->nsf * e->chunk_cut[c] / 1000);
+    k->sf_hi = (c + 1 == a->nchunks) ? a->nsf : (uint32_t)((uint64_t)a->nsf * e->chunk_cut[c + 1] / 1000);
+    if (!preset_blocks && k->sf_hi > k->sf_lo) {
+      uint32_t last_live = 0xFFFFFFFFu, first_live = 0xFFFFFFFFu;
+      k->grp_lo = a->sf[k->sf_lo].grp_lo; k->grp_hi = a->sf[k->sf_hi - 1].grp_hi;
+      for (i = k->sf_lo; i < k->sf_hi; i++) { if (a->sf[i].shape != 0xFFFFFFFFu) { if (first_live == 0xFFFFFFFFu) { first_live = i; } last_live = i; } }
+      if (first_live != 0xFFFFFFFFu) {
+        k->slot_lo = a->sf[first_live].slot_base;
+        k->slot_hi = a->sf[last_live].slot_base + C * a->shapes[a->sf[last_live].shape].ncand;
+        k->xg_lo = a->sf[first_live].xg; k->xg_hi = a->sf[last_live].xg + C;
+      }
+    }
+  }
+
+  if (!preset_blocks) {
+    if (hipMemsetAsync((uint32_t*)e->d_or.ptr + 2, 0, sizeof(uint32_t), e->stream) != hipSuccess) { rc = SLA_APIRESULT_NG; }      /* groups rerun as serial chains */
+    for (c = 0; c < a->nchunks && rc == 0; c++) { rc = search_launch(e, a, c); }
+    TRACE("search launched", a->nchunks);
+  } else {
+    a->ck[0].blk_lo = 0; a->ck[0].blk_hi = e->num_blocks;
+  }
+  return rc;
+}
+
 /* run the pipeline.  preset_blocks != 0: the block table is already in e->blk (EncodeBlock), no search. */
 /* SLA_HIP_TRACE=1: host-side timeline of one analysis on stderr (ms since the start of run_pipeline) */
-#define TRACE(label, c) do { if (trace) { fprintf(stderr, "[sla_hip] %8.3f ms  %s %d\n", now_ms() - t_begin, (label), (int)(c)); } } while (0)
 
 static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
 {
@@ -1689,7 +1807,7 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   const double t_begin = now_ms();
   const uint32_t C = e->wave_format.num_channels;
   actx_t a;
-  uint32_t c, i, want_chunks;
+  uint32_t c, i;
   double t_host = 0.0, t0;
   int rc = 0, tail_queued = 0;
   memset(&a, 0, sizeof(a));
@@ -1697,9 +1815,9 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
 
   e->fallback_groups = 0; e->host_planned = 0; e->blocks_exact = 0; e->cert_broken = 0;
   e->expanded_chunks = 0;
-  e->expand_seq += 1; if (e->expand_seq == 0) { e->expand_seq = 1; }
   e->cert_now = (e->block_cert && !(e->fuse_lattice && e->encode_param.parcor_order <= 64) && !e->tune.lpc_blocks_chains
                  && sla_hip_search_exact_lags(e->encode_param.parcor_order) != 0);
+  a.trace = trace; a.t_begin = t_begin;
   if (!preset_blocks) {
     e->num_blocks = 0;
     if ((rc = pipeline_prepare(e, &a)) != 0) { actx_free(&a); return rc; }
@@ -1727,76 +1845,7 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   }
   TRACE("prepared (prepass + tables)", a.nsf);
   if (preset_blocks && (rc = pipeline_reserve(e, &a)) != 0) { actx_free(&a); return rc; }      /* (otherwise done while the prepass ran) */
-  /* the span slots are cleared on the search stream: every kernel that writes one is launched after the host has seen a
-   * search of this run complete, i.e. behind this memset */
-  if (dev_reserve(&e->d_spans, sizeof(unsigned long long) * MAX_CHUNKS * 4 * 2) != 0
-      || hipMemsetAsync(e->d_spans.ptr, 0, sizeof(unsigned long long) * MAX_CHUNKS * 4 * 2, e->stream) != hipSuccess
-      || (preset_blocks && hipStreamSynchronize(e->stream) != hipSuccess)) { actx_free(&a); return SLA_APIRESULT_NG; }
-  TRACE("reserved", 0);
-
-  /* chunking: equal runs of super-frames */
-  want_chunks = e->chunks;
-  /* chunks pay off once the kernels are throughput-bound; a short file (a 10-second clip: 118 super-frames) is one
-   * block's serial LMS / Rice chain per stage however it is cut, and every extra chunk adds one more of those */
-  if (preset_blocks || (a.nsf < 1024 && !e->chunks_forced)) { want_chunks = 1; }
-  /* Chunks exist to plan one part of the file on the host while the device works on another.  With device-written block
-   * tables nothing waits for the host, and one chunk saves the second set of launches and of half-filled kernels
-   * (tests/tools/chunk_sweep.py: C2 1.57 -> 1.39 ms, C3-600 s 2.89 -> 2.82, C5-120 s 5.15 -> 5.05) */
-  if (a.expand && !e->chunks_forced) { want_chunks = 1; }
-  if (want_chunks > a.nsf / 32 + 1) { want_chunks = a.nsf / 32 + 1; }
-  if (want_chunks > MAX_CHUNKS) { want_chunks = MAX_CHUNKS; }
-  if (want_chunks < 1) { want_chunks = 1; }
-  a.nchunks = want_chunks;
-  /* the block stages of the two chunks on two streams, so that one chunk's lattice / FFT kernels fill the gaps of the
-   * other's block stage.  Round 2 kept this to big files (k_lpc_blocks of a ten-minute mono file was too short to share
-   * the device: 2.32 -> 2.43 ms); with the certified block stage of round 3 the ten-minute mono file gains the most
-   * (1.61 -> 1.52 ms), C3-600 s 3.03 -> 2.96, C5-120 s 5.26 -> 5.33 (within the run-to-run spread): on whenever chunked */
-  e->alt_now = (e->alt_streams != 0);
-  if (!(e->device_ltm && e->single_tail) || a.nchunks < 2) { e->alt_now = 0; }
-  /* chunk boundaries in 1/1000 of the super-frames: equal parts unless SLA_HIP_CHUNK_SPLIT gave the shares */
-  if (e->first_chunk != 0 && a.nchunks >= 2) {
-    /* option first_chunk: that many 1/1000 of the super-frames in chunk 0, the others share the rest equally */
-    e->chunk_cut[0] = 0;
-    for (c = 1; c <= a.nchunks; c++) { e->chunk_cut[c] = e->first_chunk + (1000u - e->first_chunk) * (c - 1) / (a.nchunks - 1); }
-  } else if (e->split_count != a.nchunks && a.nchunks == 2) {
-    /* measured on C2, C3-600 s, C5-120 s (tests/tools/chunk_sweep.py, medians of interleaved rounds): two chunks, the
-     * first one short -- the host plans it while nothing else can run, and plans the second under the first one's
-     * kernels.  With one k_tail for the file (device long-term solve) 25 % / 75 % is best: 2.32 / 5.94 / 11.97 ms
-     * against 2.46 / 6.23 / 12.24 ms in one chunk; a third chunk only adds launches.  With a k_tail per chunk
-     * (host solve) every chunk costs one more serial LMS chain, and 40 % / 60 % was the best cut. */
-    e->chunk_cut[0] = 0; e->chunk_cut[1] = (e->device_ltm && e->single_tail && !e->alt_now) ? 250 : 400; e->chunk_cut[2] = 1000;
-  } else if (e->split_count != a.nchunks && a.nchunks == 3) {
-    e->chunk_cut[0] = 0; e->chunk_cut[1] = 250; e->chunk_cut[2] = 625; e->chunk_cut[3] = 1000;
-  } else if (e->split_count != a.nchunks) {
-    for (c = 0; c <= a.nchunks; c++) { e->chunk_cut[c] = 1000u * c / a.nchunks; }
-  } else {
-    uint32_t acc = 0, sum = 0;
-    for (c = 0; c < a.nchunks; c++) { sum += e->split[c]; }
-    for (c = 0; c <= a.nchunks; c++) { e->chunk_cut[c] = 1000u * acc / sum; if (c < a.nchunks) { acc += e->split[c]; } }
-  }
-  for (c = 0; c < a.nchunks; c++) {
-    chunk_t* k = &a.ck[c];
-    k->sf_lo = (uint32_t)((uint64_t)a.nsf * e->chunk_cut[c] / 1000);
-    k->sf_hi = (c + 1 == a.nchunks) ? a.nsf : (uint32_t)((uint64_t)a.nsf * e->chunk_cut[c + 1] / 1000);
-    if (!preset_blocks && k->sf_hi > k->sf_lo) {
-      uint32_t last_live = 0xFFFFFFFFu, first_live = 0xFFFFFFFFu;
-      k->grp_lo = a.sf[k->sf_lo].grp_lo; k->grp_hi = a.sf[k->sf_hi - 1].grp_hi;
-      for (i = k->sf_lo; i < k->sf_hi; i++) { if (a.sf[i].shape != 0xFFFFFFFFu) { if (first_live == 0xFFFFFFFFu) { first_live = i; } last_live = i; } }
-      if (first_live != 0xFFFFFFFFu) {
-        k->slot_lo = a.sf[first_live].slot_base;
-        k->slot_hi = a.sf[last_live].slot_base + C * a.shapes[a.sf[last_live].shape].ncand;
-        k->xg_lo = a.sf[first_live].xg; k->xg_hi = a.sf[last_live].xg + C;
-      }
-    }
-  }
-
-  if (!preset_blocks) {
-    if (hipMemsetAsync((uint32_t*)e->d_or.ptr + 2, 0, sizeof(uint32_t), e->stream) != hipSuccess) { rc = SLA_APIRESULT_NG; }      /* groups rerun as serial chains */
-    for (c = 0; c < a.nchunks && rc == 0; c++) { rc = search_launch(e, &a, c); }
-    TRACE("search launched", a.nchunks);
-  } else {
-    a.ck[0].blk_lo = 0; a.ck[0].blk_hi = e->num_blocks;
-  }
+  if (!a.spec && (rc = launch_searches(e, &a, preset_blocks, trace, t_begin)) != 0) { actx_free(&a); return rc; }
   /* device-written block tables: every chunk's block stage goes out as soon as its two counts are in, then the one tail
    * -- the device has its whole queue before the host starts on its own copy of the tables.  A chunk the device could
    * not finish (a partition that needs the host's logarithms) ends this: it and the chunks behind it take the host route. */
@@ -1978,7 +2027,7 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   else if (strcmp(name, "first_chunk") == 0)       { OPT_RANGE(0, 999); e->first_chunk = (uint32_t)iv; }
   else if (strcmp(name, "alt_streams") == 0)       { OPT_RANGE(0, 2); e->alt_streams = (int)iv; }
   else if (strcmp(name, "device_expand") == 0)     { OPT_RANGE(0, 1); e->device_expand = (int)iv; }
-  else if (strcmp(name, "table_cache") == 0)       { OPT_RANGE(0, 1); e->table_cache = (int)iv; e->tab_valid = 0; }
+  else if (strcmp(name, "table_cache") == 0)       { OPT_RANGE(0, 1); e->table_cache = (int)iv; e->tab_valid = 0; e->spec_valid = 0; }
   else if (strcmp(name, "device_ltm") == 0)        { OPT_RANGE(0, 1); e->device_ltm = (int)iv; }
   else if (strcmp(name, "fuse_lattice") == 0)      { OPT_RANGE(0, 1); e->fuse_lattice = (int)iv && !e->tune.lpc_blocks_chains; }
   else if (strcmp(name, "threads") == 0) {
@@ -2183,7 +2232,7 @@ int sla_hip_last_counters(const struct SLAEncoder* e, uint32_t* counters)
 int sla_hip_last_expand(const struct SLAEncoder* e, uint32_t* counters)
 {
   if (e == NULL || counters == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
-  counters[0] = e->expanded_chunks; counters[1] = (uint32_t)e->timing[9]; counters[2] = e->table_hits;
+  counters[0] = e->expanded_chunks; counters[1] = (uint32_t)e->timing[9]; counters[2] = e->table_hits; counters[3] = e->spec_misses;
   return 0;
 }
 

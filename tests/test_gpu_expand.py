@@ -167,14 +167,25 @@ def test_kept_search_tables(oracle, hip):
         # file 1 reuses file 0's tables; so does the file with silence at first (the tables are the guess made while the
         # prepass runs) -- and drops them when the prepass reports silence; 3 rebuilds, 4 reuses; another length replaces them
         assert hits == [0, 1, 2, 2, 3, 3, 3, 4], hits
+        # the searches of files 1, 2, 4 and 7 went out on the guess "like the file before"; file 2 (silence) proved it wrong
+        assert enc.last_expand()[3] == 1
+        # same shape, another OR word (two low bits always zero: offset_lshift 2): the guess is wrong, the bytes are not
+        pcm = (W.music_like(2, 200000, 16, seed=77) >> 18) << 18
+        ret, want = oracle.encode_whole(p, pcm)
+        assert ret == 0 and enc.encode_whole(pcm) == want
+        assert enc.last_expand()[2:] == (5, 2)
+        pcm = W.music_like(2, 200000, 16, seed=78)
+        ret, want = oracle.encode_whole(p, pcm)
+        assert ret == 0 and enc.encode_whole(pcm) == want
+        assert enc.last_expand()[2:] == (6, 3)
         # other parameters: new tables, and the same bytes as a fresh handle
         enc.set_encode_parameter(8, 1, 8, 1, 1, 2048)
         p2 = S.make_params(2, 16, 48000, 8, 1, 8, 1, 1, 2048)
         pcm = W.music_like(2, 200000, 16, seed=99)
         ret, want = oracle.encode_whole(p2, pcm)
         assert ret == 0 and enc.encode_whole(pcm) == want
-        assert enc.last_expand()[2] == 4
+        assert enc.last_expand()[2] == 6
         enc.set_option("table_cache", 0)
-        assert enc.encode_whole(pcm) == want and enc.last_expand()[2] == 4
+        assert enc.encode_whole(pcm) == want and enc.last_expand()[2] == 6
     finally:
         enc.close()
