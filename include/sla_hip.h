@@ -249,6 +249,8 @@ int sla_hip_launch_plan(const sla_hip_lpc_group* d_groups, uint32_t num_superfra
  * that is a single SILENT block (live == SLA_HIP_NOT_LIVE) takes one block index and produces no group.  No block of
  * a live super-frame is treated as silent: the caller uses this only for input whose non-zero mask has no all-zero
  * word (sla_hip_launch_prepass: d_or_mask[1] == 0), where a block of SLA's minimum length cannot be.
+ * d_run: 4 words, zeroed by the caller before the first run of a file; d_prefix: 2 * num_superframes words of scratch (the
+ * numbering is done by one workgroup, k_expand_scan, the descriptors are written by the whole device, k_expand_write).
  * Per (block, channel), numbered on from d_run[0] blocks / d_run[1] groups: d_groups[g] (windowed form: win_off looked
  * up by block length in the d_win_len / d_win_off list, cand_first = g, slot_first = block * num_channels + channel),
  * d_cands[g] = {0, length}, d_acf_jobs[g].  counts (which may be page-locked host memory: the caller can poll
@@ -266,7 +268,7 @@ int sla_hip_launch_expand(const sla_hip_superframe* d_superframes, uint32_t num_
                           const uint32_t* d_parts, const uint32_t* d_num_parts, const uint32_t* d_status,
                           uint32_t num_channels, uint32_t int_shift,
                           const uint32_t* d_win_len, const uint32_t* d_win_off, uint32_t num_windows,
-                          uint32_t* d_run, sla_hip_lpc_group* d_groups, sla_hip_lpc_cand* d_cands,
+                          uint32_t* d_run, uint32_t* d_prefix, sla_hip_lpc_group* d_groups, sla_hip_lpc_cand* d_cands,
                           sla_hip_acf_job* d_acf_jobs, uint32_t group_capacity,
                           uint32_t* counts, uint32_t sequence, sla_hip_stream_t stream);
 

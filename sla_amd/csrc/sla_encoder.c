@@ -106,7 +106,7 @@ struct SLAEncoder {
   devbuf_t d_pcm, d_res1, d_res2, d_or, d_nz, d_groups, d_cands, d_lpc_out, d_code, d_kint, d_rshift,
            d_winpool, d_chunks, d_jobs, d_fold, d_acf_jobs, d_acf, d_acf_scratch, d_twiddle, d_bgroups, d_bcands, d_blk_out, d_kk, d_pk_jobs, d_pk_blocks, d_pk_hdr, d_image,
            d_xgroups, d_tile_sums, d_fgroups, d_parts, d_nparts, d_pstatus, d_spans, d_cert_flag, d_fb_list, d_fb_count,
-           d_sframes, d_winmap, d_run;
+           d_sframes, d_winmap, d_run, d_expref;
   int twiddle_ready;
   /* pinned host staging */
   pinbuf_t h_nz, h_groups, h_cands, h_lpc_out, h_code, h_kint, h_rshift, h_chunks, h_jobs, h_fold, h_res, h_pcm, h_acf_jobs, h_acf,
@@ -467,7 +467,7 @@ fail:
 
 void SLAEncoder_Destroy(struct SLAEncoder* e)
 {
-  devbuf_t* d[40];
+  devbuf_t* d[41];
   pinbuf_t* h[29];
   int i;
   if (e == NULL) { return; }
@@ -487,8 +487,8 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   d[27] = &e->d_xgroups; d[28] = &e->d_tile_sums; d[29] = &e->d_fgroups;
   d[30] = &e->d_parts; d[31] = &e->d_nparts; d[32] = &e->d_pstatus; d[33] = &e->d_spans;
   d[34] = &e->d_cert_flag; d[35] = &e->d_fb_list; d[36] = &e->d_fb_count;
-  d[37] = &e->d_sframes; d[38] = &e->d_winmap; d[39] = &e->d_run;
-  for (i = 0; i < 40; i++) { if (d[i]->ptr != NULL) { (void)hipFree(d[i]->ptr); } }
+  d[37] = &e->d_sframes; d[38] = &e->d_winmap; d[39] = &e->d_run; d[40] = &e->d_expref;
+  for (i = 0; i < 41; i++) { if (d[i]->ptr != NULL) { (void)hipFree(d[i]->ptr); } }
   h[0] = &e->h_nz; h[1] = &e->h_groups; h[2] = &e->h_cands; h[3] = &e->h_lpc_out; h[4] = &e->h_code; h[5] = &e->h_kint;
   h[6] = &e->h_rshift; h[7] = &e->h_chunks; h[8] = &e->h_jobs; h[9] = &e->h_fold; h[10] = &e->h_res; h[11] = &e->h_pcm;
   h[12] = &e->h_acf_jobs; h[13] = &e->h_acf; h[14] = &e->h_bgroups; h[15] = &e->h_bcands; h[16] = &e->h_blk_out;
@@ -918,6 +918,7 @@ static int upload_search_tables(struct SLAEncoder* e, const actx_t* a)
     RCCHK(pin_reserve(&e->h_winmap, sizeof(uint32_t) * 2 * e->win_entries));
     RCCHK(dev_reserve(&e->d_winmap, sizeof(uint32_t) * 2 * e->win_entries));
     RCCHK(dev_reserve(&e->d_run, 16));
+    RCCHK(dev_reserve(&e->d_expref, sizeof(uint32_t) * 2 * ((size_t)a->nsf + 1)));
     RCCHK(pin_reserve(&e->h_counts, sizeof(uint32_t) * 4 * MAX_CHUNKS));
     hs = (sla_hip_superframe*)e->h_sframes.ptr; hw = (uint32_t*)e->h_winmap.ptr;
     for (i = 0; i < a->nsf; i++) {
@@ -1265,7 +1266,7 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
         RCCHK(sla_hip_launch_expand((const sla_hip_superframe*)e->d_sframes.ptr + k->sf_lo, k->sf_hi - k->sf_lo,
                                     (const uint32_t*)e->d_parts.ptr, (const uint32_t*)e->d_nparts.ptr, (const uint32_t*)e->d_pstatus.ptr,
                                     C, 32 - bps + e->lshift, (const uint32_t*)e->d_winmap.ptr, (const uint32_t*)e->d_winmap.ptr + e->winmap_entries,
-                                    e->winmap_entries, (uint32_t*)e->d_run.ptr, (sla_hip_lpc_group*)e->d_bgroups.ptr, (sla_hip_lpc_cand*)e->d_bcands.ptr,
+                                    e->winmap_entries, (uint32_t*)e->d_run.ptr, (uint32_t*)e->d_expref.ptr, (sla_hip_lpc_group*)e->d_bgroups.ptr, (sla_hip_lpc_cand*)e->d_bcands.ptr,
                                     (sla_hip_acf_job*)e->d_acf_jobs.ptr, a->blocks_bound * C, (uint32_t*)e->h_counts.ptr + 4 * (size_t)c,
                                     e->expand_seq, e->stream));
         HIPCHK(hipEventRecord(ev[EV_EXPANDED], e->stream));

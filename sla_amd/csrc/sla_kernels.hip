@@ -1814,85 +1814,156 @@ void k_plan(const sla_hip_lpc_group* __restrict__ groups, uint32_t num_sf, uint3
 // and upload them while the device waits.
 // ---------------------------------------------------------------------------------------------
 #define EXPAND_THREADS 1024
+typedef uint32_t ex_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t ex_u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+#define EXPAND_PER 8                               // super-frames per thread and tile
+#define EXPAND_TILE (EXPAND_THREADS * EXPAND_PER)
 #define EXPAND_MAX_WINDOWS 256
-__global__ __launch_bounds__(EXPAND_THREADS)
-void k_expand(const sla_hip_superframe* __restrict__ sf, uint32_t num_sf, const uint32_t* __restrict__ parts,
-              const uint32_t* __restrict__ nparts, const uint32_t* __restrict__ status, uint32_t nch, uint32_t int_shift,
-              const uint32_t* __restrict__ win_len, const uint32_t* __restrict__ win_off, uint32_t num_win,
-              uint32_t* __restrict__ run, sla_hip_lpc_group* __restrict__ groups, sla_hip_lpc_cand* __restrict__ cands,
-              sla_hip_acf_job* __restrict__ acf_jobs, uint32_t capacity, volatile uint32_t* counts, uint32_t sequence)
+#define EXPAND_MAX_LEN 16384u                      // longest block the device analyses (the window lives in LDS)
+// Two kernels.  k_expand_scan (ONE workgroup) numbers the blocks: super-frames in tiles of 8192, thread t owning t,
+// t + 1024, .. so that the loads of a thread's eight super-frames are independent and coalesced across the workgroup, the
+// counts in LDS, where the scan runs; it writes two prefix words per super-frame, validates every block length against the
+// window list and publishes the counts.  k_expand_write (one thread per super-frame, the whole device) writes the
+// descriptors.  (First version: one workgroup did everything, every thread walking a run of consecutive super-frames
+// twice -- 60 us for a ten-minute mono file, 300 us for an hour of stereo, most of it one CU pushing a megabyte of
+// scattered 40-byte records per tile through its store path.)
+__device__ __forceinline__ uint32_t expand_window(const uint32_t* s_wlen, const uint32_t* s_woff, uint32_t num_win, uint32_t len)
 {
-  __shared__ uint32_t s_wlen[EXPAND_MAX_WINDOWS], s_woff[EXPAND_MAX_WINDOWS];
-  __shared__ uint32_t s_blocks[EXPAND_THREADS / 64], s_live[EXPAND_THREADS / 64];
+  for (uint32_t q = 0; q < num_win; q++) { if (s_wlen[q] == len) { return s_woff[q]; } }
+  return SLA_HIP_NO_WINDOW;
+}
+
+__global__ __launch_bounds__(EXPAND_THREADS)
+void k_expand_scan(const sla_hip_superframe* __restrict__ sf, uint32_t num_sf, const uint32_t* __restrict__ parts,
+                   const uint32_t* __restrict__ nparts, const uint32_t* __restrict__ status, uint32_t nch,
+                   const uint32_t* __restrict__ win_len, uint32_t num_win,
+                   uint32_t* __restrict__ run, uint32_t* __restrict__ prefix, uint32_t capacity,
+                   volatile uint32_t* counts, uint32_t sequence)
+{
+  __shared__ uint32_t s_has[EXPAND_MAX_LEN / 32 + 1];             // bit per block length: its window table exists
+  __shared__ uint32_t s_cb[EXPAND_TILE], s_cl[EXPAND_TILE];       // per super-frame of the tile: blocks, blocks of live super-frames
+  __shared__ uint32_t s_wb[EXPAND_THREADS / 64], s_wl[EXPAND_THREADS / 64];
   __shared__ uint32_t s_bad;
   const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const uint32_t per = (num_sf + EXPAND_THREADS - 1) / EXPAND_THREADS;
-  const uint32_t lo = min(num_sf, t * per), hi = min(num_sf, lo + per);
   if (t == 0) { s_bad = (run[2] != 0u || num_win > EXPAND_MAX_WINDOWS) ? 1u : 0u; }
-  for (uint32_t i = t; i < num_win && i < EXPAND_MAX_WINDOWS; i += EXPAND_THREADS) { s_wlen[i] = win_len[i]; s_woff[i] = win_off[i]; }
-  // blocks of my super-frames; live ones (every block of a live super-frame is a COMPRESS candidate with nch groups)
-  uint32_t my_blocks = 0, my_live = 0, bad = 0;
-  for (uint32_t i = lo; i < hi; i++) {
-    const uint32_t li = sf[i].live;
-    if (li == SLA_HIP_NOT_LIVE) { my_blocks += 1; continue; }
-    const uint32_t np = nparts[li];
-    if (status[li] != 0u || np == 0u || np > PLAN_NODES) { bad = 1; continue; }
-    my_blocks += np; my_live += np;
-  }
-  // exclusive scan over the workgroup: within the wave by shuffles, across the 16 waves through LDS
-  uint32_t inc_b = my_blocks, inc_l = my_live;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t ob = (uint32_t)__shfl_up((int)inc_b, off), ol = (uint32_t)__shfl_up((int)inc_l, off);
-    if (lane >= (uint32_t)off) { inc_b += ob; inc_l += ol; }
-  }
-  if (lane == 63) { s_blocks[wv] = inc_b; s_live[wv] = inc_l; }
+  for (uint32_t i = t; i < EXPAND_MAX_LEN / 32 + 1; i += EXPAND_THREADS) { s_has[i] = 0u; }
   __syncthreads();
-  if (bad) { s_bad = 1u; }
-  uint32_t base_b = 0, base_l = 0, total_b = 0, total_l = 0;
-  for (uint32_t w = 0; w < EXPAND_THREADS / 64; w++) {
-    const uint32_t vb = s_blocks[w], vl = s_live[w];
-    if (w < wv) { base_b += vb; base_l += vl; }
-    total_b += vb; total_l += vl;
+  for (uint32_t i = t; i < num_win && i < EXPAND_MAX_WINDOWS; i += EXPAND_THREADS) {
+    const uint32_t len = win_len[i];
+    if (len != 0u && len <= EXPAND_MAX_LEN) { atomicOr(&s_has[len >> 5], 1u << (len & 31u)); }
   }
-  __syncthreads();
   const uint32_t run_b = run[0], run_g = run[1];
-  bool ok = (s_bad == 0u) && ((uint64_t)run_g + (uint64_t)total_l * nch <= (uint64_t)capacity);
-  __syncthreads();                                   // (s_bad is written again below)
-  if (ok) {
-    uint32_t b = run_b + base_b + (inc_b - my_blocks);
-    uint32_t l = base_l + (inc_l - my_live);
-    for (uint32_t i = lo; i < hi; i++) {
-      const sla_hip_superframe f = sf[i];
-      if (f.live == SLA_HIP_NOT_LIVE) { b += 1; continue; }
-      const uint32_t np = nparts[f.live];
-      uint32_t at = f.start;
-      for (uint32_t p = 0; p < np; p++, b++, l++) {
-        const uint32_t len = parts[(uint64_t)f.live * PLAN_NODES + p];
-        uint32_t woff = SLA_HIP_NO_WINDOW;
-        for (uint32_t k = 0; k < num_win; k++) { if (s_wlen[k] == len) { woff = s_woff[k]; break; } }
-        if (woff == SLA_HIP_NO_WINDOW || len == 0u) { s_bad = 1u; }
-        for (uint32_t ch = 0; ch < nch; ch++) {
-          const uint32_t g = run_g + l * nch + ch;
-          sla_hip_lpc_group gr;
-          gr.pcm_off = at; gr.num_samples = len; gr.channel = ch; gr.win_off = woff; gr.int_shift = int_shift;
-          gr.cand_first = g; gr.cand_count = 1; gr.slot_first = b * nch + ch; gr.pad_ = 0;
-          groups[g] = gr;
-          cands[g].start = 0; cands[g].len = len;
-          acf_jobs[g].blk_off = at; acf_jobs[g].blk_len = len; acf_jobs[g].channel = ch;
-        }
-        at += len;
-      }
+  uint32_t base_b = 0, base_l = 0;                 // blocks / live blocks of the tiles before this one
+  bool bad = false;
+  __syncthreads();
+  for (uint32_t t0 = 0; t0 < num_sf; t0 += EXPAND_TILE) {
+    // my super-frames' plan rows and first block lengths: two rounds of loads, each round's eight requested before the
+    // first is used (a super-frame is one block more often than not: its length rides along)
+    uint32_t live[EXPAND_PER], np[EXPAND_PER], st[EXPAND_PER], len0[EXPAND_PER];
+#pragma unroll
+    for (int k = 0; k < EXPAND_PER; k++) {
+      const uint32_t i = t0 + (uint32_t)k * EXPAND_THREADS + t;
+      live[k] = (i < num_sf) ? sf[i].live : SLA_HIP_NOT_LIVE;
     }
+#pragma unroll
+    for (int k = 0; k < EXPAND_PER; k++) {
+      const bool l = (live[k] != SLA_HIP_NOT_LIVE);
+      np[k] = l ? nparts[live[k]] : 0u;
+      st[k] = l ? status[live[k]] : 0u;
+      len0[k] = l ? parts[(uint64_t)live[k] * PLAN_NODES] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < EXPAND_PER; k++) {
+      const uint32_t i = t0 + (uint32_t)k * EXPAND_THREADS + t;
+      const bool l = (live[k] != SLA_HIP_NOT_LIVE);
+      if (l && (st[k] != 0u || np[k] == 0u || np[k] > PLAN_NODES)) { bad = true; np[k] = 0; }
+      for (uint32_t p = 0; l && p < np[k]; p++) {          // every block length must have its window table
+        const uint32_t len = (p == 0) ? len0[k] : parts[(uint64_t)live[k] * PLAN_NODES + p];
+        if (len == 0u || len > EXPAND_MAX_LEN || ((s_has[len >> 5] >> (len & 31u)) & 1u) == 0u) { bad = true; }
+      }
+      s_cb[(uint32_t)k * EXPAND_THREADS + t] = (i < num_sf) ? (l ? np[k] : 1u) : 0u;      // a SILENT super-frame is one block
+      s_cl[(uint32_t)k * EXPAND_THREADS + t] = l ? np[k] : 0u;
+    }
+    __syncthreads();
+    // exclusive scan over the tile, in LDS: thread t sums entries [8 t, 8 t + 8), wave scan, wave totals
+    uint32_t cb[EXPAND_PER], cl[EXPAND_PER], my_b = 0, my_l = 0;
+#pragma unroll
+    for (int k = 0; k < EXPAND_PER; k++) { cb[k] = s_cb[t * EXPAND_PER + k]; cl[k] = s_cl[t * EXPAND_PER + k]; my_b += cb[k]; my_l += cl[k]; }
+    uint32_t inc_b = my_b, inc_l = my_l;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t ob = (uint32_t)__shfl_up((int)inc_b, off), ol = (uint32_t)__shfl_up((int)inc_l, off);
+      if (lane >= (uint32_t)off) { inc_b += ob; inc_l += ol; }
+    }
+    if (lane == 63) { s_wb[wv] = inc_b; s_wl[wv] = inc_l; }
+    __syncthreads();
+    uint32_t off_b = run_b + base_b + (inc_b - my_b), off_l = base_l + (inc_l - my_l), tile_b = 0, tile_l = 0;
+    for (uint32_t w = 0; w < EXPAND_THREADS / 64; w++) {
+      const uint32_t vb = s_wb[w], vl = s_wl[w];
+      if (w < wv) { off_b += vb; off_l += vl; }
+      tile_b += vb; tile_l += vl;
+    }
+    // block number and live-block number of each of my eight consecutive entries: 64 contiguous bytes per thread
+#pragma unroll
+    for (int k = 0; k < EXPAND_PER; k++) {
+      const uint32_t i = t0 + t * EXPAND_PER + (uint32_t)k;
+      if (i < num_sf) { ex_u32x2 w; w.x = off_b; w.y = off_l; *reinterpret_cast<ex_u32x2*>(prefix + 2 * (uint64_t)i) = w; }
+      off_b += cb[k]; off_l += cl[k];
+    }
+    base_b += tile_b; base_l += tile_l;
+    __syncthreads();                                   // s_cb / s_cl are rewritten by the next tile
   }
+  if (bad) { s_bad = 1u; }
   __syncthreads();
   if (t == 0) {
-    ok = ok && (s_bad == 0u);
-    if (ok) { run[0] = run_b + total_b; run[1] = run_g + total_l * nch; } else { run[2] = 1u; }
-    counts[0] = ok ? total_b : 0u; counts[1] = ok ? total_l * nch : 0u; counts[2] = ok ? 1u : 0u;
+    const bool ok = (s_bad == 0u) && ((uint64_t)run_g + (uint64_t)base_l * nch <= (uint64_t)capacity);
+    // run[3]: first group of this run, for k_expand_write (run[1] moves on)
+    run[3] = run_g;
+    if (ok) { run[0] = run_b + base_b; run[1] = run_g + base_l * nch; } else { run[2] = 1u; }
+    counts[0] = ok ? base_b : 0u; counts[1] = ok ? base_l * nch : 0u; counts[2] = ok ? 1u : 0u;
     __threadfence_system();
     counts[3] = sequence;
     __threadfence_system();
+  }
+}
+
+__global__ __launch_bounds__(256)
+void k_expand_write(const sla_hip_superframe* __restrict__ sf, uint32_t num_sf, const uint32_t* __restrict__ parts,
+                    const uint32_t* __restrict__ nparts, uint32_t nch, uint32_t int_shift,
+                    const uint32_t* __restrict__ win_len, const uint32_t* __restrict__ win_off, uint32_t num_win,
+                    const uint32_t* __restrict__ run, const uint32_t* __restrict__ prefix,
+                    sla_hip_lpc_group* __restrict__ groups, sla_hip_lpc_cand* __restrict__ cands, sla_hip_acf_job* __restrict__ acf_jobs)
+{
+  __shared__ uint32_t s_wlen[EXPAND_MAX_WINDOWS], s_woff[EXPAND_MAX_WINDOWS];
+  if (run[2] != 0u) { return; }                        // the scan found this run (or an earlier one) unfit for device tables
+  for (uint32_t i = threadIdx.x; i < num_win && i < EXPAND_MAX_WINDOWS; i += blockDim.x) { s_wlen[i] = win_len[i]; s_woff[i] = win_off[i]; }
+  __syncthreads();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= num_sf) { return; }
+  const sla_hip_superframe f = sf[i];
+  if (f.live == SLA_HIP_NOT_LIVE) { return; }
+  const uint32_t run_g = run[3];
+  const uint32_t np = nparts[f.live];
+  uint32_t b = prefix[2 * (uint64_t)i], l = prefix[2 * (uint64_t)i + 1], at = f.start;
+  for (uint32_t p = 0; p < np; p++, b++, l++) {
+    const uint32_t len = parts[(uint64_t)f.live * PLAN_NODES + p];
+    const uint32_t woff = expand_window(s_wlen, s_woff, num_win, len);
+    for (uint32_t ch = 0; ch < nch; ch++) {
+      const uint32_t g = run_g + l * nch + ch;
+      // 64 bytes per (block, channel), as five wide stores
+      static_assert(sizeof(sla_hip_lpc_group) == 40 && sizeof(sla_hip_lpc_cand) == 8 && sizeof(sla_hip_acf_job) == 16, "descriptor layout");
+      ex_u32x4 w0, w1; ex_u32x2 w2, wc; ex_u32x4 wa;
+      w0.x = at; w0.y = 0u; w0.z = len; w0.w = ch;                       // pcm_off (u64), num_samples, channel
+      w1.x = woff; w1.y = int_shift; w1.z = g; w1.w = 1u;                // win_off, int_shift, cand_first, cand_count
+      w2.x = b * nch + ch; w2.y = 0u;                                    // slot_first, pad_
+      uint32_t* gp = reinterpret_cast<uint32_t*>(groups + g);
+      *reinterpret_cast<ex_u32x4*>(gp) = w0; *reinterpret_cast<ex_u32x4*>(gp + 4) = w1; *reinterpret_cast<ex_u32x2*>(gp + 8) = w2;
+      wc.x = 0u; wc.y = len;
+      *reinterpret_cast<ex_u32x2*>(cands + g) = wc;
+      wa.x = at; wa.y = 0u; wa.z = len; wa.w = ch;                       // blk_off (u64), blk_len, channel
+      *reinterpret_cast<ex_u32x4*>(acf_jobs + g) = wa;
+    }
+    at += len;
   }
 }
 
@@ -3751,17 +3822,22 @@ extern "C" int sla_hip_launch_expand(const sla_hip_superframe* d_superframes, ui
                                      const uint32_t* d_parts, const uint32_t* d_num_parts, const uint32_t* d_status,
                                      uint32_t num_channels, uint32_t int_shift,
                                      const uint32_t* d_win_len, const uint32_t* d_win_off, uint32_t num_windows,
-                                     uint32_t* d_run, sla_hip_lpc_group* d_groups, sla_hip_lpc_cand* d_cands,
+                                     uint32_t* d_run, uint32_t* d_prefix, sla_hip_lpc_group* d_groups, sla_hip_lpc_cand* d_cands,
                                      sla_hip_acf_job* d_acf_jobs, uint32_t group_capacity,
                                      uint32_t* counts, uint32_t sequence, sla_hip_stream_t stream)
 {
   if (d_superframes == nullptr || d_parts == nullptr || d_num_parts == nullptr || d_status == nullptr || d_run == nullptr
-      || d_groups == nullptr || d_cands == nullptr || d_acf_jobs == nullptr || counts == nullptr
+      || d_prefix == nullptr || d_groups == nullptr || d_cands == nullptr || d_acf_jobs == nullptr || counts == nullptr
       || (num_windows != 0 && (d_win_len == nullptr || d_win_off == nullptr))) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (num_channels == 0 || num_channels > 8 || int_shift > 31) { return SLA_APIRESULT_INVALID_ARGUMENT; }
-  hipLaunchKernelGGL(k_expand, dim3(1), dim3(EXPAND_THREADS), 0, (hipStream_t)stream, d_superframes, num_superframes, d_parts,
-                     d_num_parts, d_status, num_channels, int_shift, d_win_len, d_win_off, num_windows, d_run, d_groups, d_cands,
-                     d_acf_jobs, group_capacity, (volatile uint32_t*)counts, sequence);
+  hipLaunchKernelGGL(k_expand_scan, dim3(1), dim3(EXPAND_THREADS), 0, (hipStream_t)stream, d_superframes, num_superframes, d_parts,
+                     d_num_parts, d_status, num_channels, d_win_len, num_windows, d_run, d_prefix, group_capacity,
+                     (volatile uint32_t*)counts, sequence);
+  if (num_superframes != 0) {
+    hipLaunchKernelGGL(k_expand_write, dim3((num_superframes + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_superframes, num_superframes,
+                       d_parts, d_num_parts, num_channels, int_shift, d_win_len, d_win_off, num_windows, d_run, d_prefix, d_groups, d_cands,
+                       d_acf_jobs);
+  }
   return hip_rc(hipGetLastError());
 }
 

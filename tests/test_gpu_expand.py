@@ -121,7 +121,7 @@ def test_silent_last_superframe(oracle, hip):
 
 def test_expand_launcher_rejects_bad_arguments(hip):
     L = hip.lib()
-    assert L.sla_hip_launch_expand(None, 0, None, None, None, 1, 0, None, None, 0, None, None, None, None, 0, None, 1, None) != 0
+    assert L.sla_hip_launch_expand(None, 0, None, None, None, 1, 0, None, None, 0, None, None, None, None, None, 0, None, 1, None) != 0
 
 
 def test_handle_reuse_across_routes(oracle, hip):
