@@ -426,7 +426,7 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
                    "k_ltm_acf": (2.0 * 10.0 * (npts_fft / 2) * lg + 28.0 * npts_fft) / float(maxb)}
     sc_step = float(n_last) * nch
     path_flop = sum(flop_per_sc.values()) * sc_step
-    out["roofline"] = {"bound": "hbm", "kernel": {"k_tail": "k_tailk", "k_ltm_acf": "k_ltm_acf2"}.get(dom, dom), "achieved": round(achieved, 2),
+    out["roofline"] = {"bound": "hbm", "kernel": {"k_tail": "k_tailk", "k_ltm_acf": "k_ltm_acf2", "k_lattice": "k_lattice_groups"}.get(dom, dom), "achieved": round(achieved, 2),
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                        "path_frac": round(sc_step * ALGO_BYTES_PER_SAMPLE / (elapsed / max(args.steps, 1)) / 1e9 / HBM_PEAK_GBS, 5),
                        "fp64_vector_frac": (round(flop_per_sc[dom] * sc_step / launches / (launch_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 5)
@@ -448,7 +448,7 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
     try:       # HBM traffic per launch of that kernel from the committed rocprofv3 --pmc passes of this configuration
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % cfg.lower())))
         pk = dom.split("+")[0]
-        for alias in (pk + "2", pk + "k"):    # the stage "k_ltm_acf" runs k_ltm_acf2, the stage "k_tail" k_tailk
+        for alias in (pk + "2", pk + "k", pk + "_groups"):    # the stage "k_ltm_acf" runs k_ltm_acf2, "k_tail" k_tailk, "k_lattice" k_lattice_groups
             if pk not in pmc["bytes_per_launch"] and alias in pmc["bytes_per_launch"]:
                 pk = alias
         if world == 1 and pk in pmc["bytes_per_launch"]:
