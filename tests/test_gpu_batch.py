@@ -185,3 +185,22 @@ def test_empty_file_inside_a_batch(oracle, hip):
                 assert rc == 0 and data == oracle.encode_whole(p, x)[1]
     finally:
         enc.close()
+
+
+def test_c4_at_its_real_batch_size(oracle, hip):
+    """BASELINE config 4 as bench.py runs it on one GPU: 125 ten-second 48 kHz 16-bit stereo clips in ONE call, every clip
+    byte-identical to the oracle's encode of that clip alone (the other batch tests use <= 10
+    clips).  A few clips carry silence, a few another offset_lshift, so the pass splits; the oracle needs ~13 s for all."""
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096, cap=(2, 4096, 16, 1, 8))
+    n = 480000
+    pcms = []
+    for i in range(125):
+        pcm = S.synth_pcm(2, n, 16, 48000, seed=1000 + i) if i % 3 else W.music_like(2, n, 16, seed=2000 + i)
+        if i % 31 == 7:
+            pcm[:, 100000:160000] = 0                     # silence inside
+        if i % 41 == 11:
+            pcm = (pcm >> 18) << 18                       # offset_lshift 2
+        if i == 124:
+            pcm = pcm[:, :477777]                         # a ragged last clip
+        pcms.append(np.ascontiguousarray(pcm))
+    check_batch(oracle, hip, p, pcms, also_single=False)
