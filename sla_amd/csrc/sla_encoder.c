@@ -79,6 +79,8 @@ struct SLAEncoder {
   double   block_cert_safety;       /* safety factor on the first-order bound of that certificate (16) */
   volatile int cert_broken;         /* a block flagged by the certificate was not redone (internal error) */
   int      cert_now;                /* this run's block stage takes the certified route */
+  int      one_stream;              /* 1: a file that runs as one chunk on device tables keeps search, block stage and tail on ONE stream (measured
+                                     * slower; default 0) */
   int      device_expand;           /* 1 (default): the block table of certified partitions is written on the device (k_expand) and the block
                                      * stage launched from two counts, the host's own tables following under the kernels; 0: host tables first */
   uint32_t expand_seq;              /* sequence number of the last k_expand launch (what the host polls for) */
@@ -639,6 +641,10 @@ typedef struct {
   int borrowed;                                   /* sf / shapes belong to the encoder's table cache */
   int tab_hit;                                    /* ... and were found there                         */
   int spec;                                       /* the searches are in flight on a guess of the prepass result */
+  int clear_in_kernel;                            /* spans, rerun counter and k_expand's numbers are cleared by the first search kernel */
+  int one_stream;                                 /* one chunk on device tables: search, block stage and tail on ONE stream (no
+                                                   * cross-queue event waits between them: 10 - 20 us each on the critical path) */
+  hipStream_t tail_stream;                        /* the stream the last tail kernel was put on */
   uint32_t or_word;                               /* OR of all input words the search was launched with */
   int trace; double t_begin;                      /* for the timeline when the searches go out from pipeline_prepare */
   uint32_t dev_blk, dev_bg;                       /* blocks / groups numbered by the device so far */
@@ -1262,7 +1268,7 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
         volatile uint32_t* hc = (volatile uint32_t*)e->h_counts.ptr + 4 * (size_t)c;
         const uint32_t bps = e->wave_format.bit_per_sample;
         hc[0] = hc[1] = hc[2] = hc[3] = 0;
-        if (c == 0) { HIPCHK(hipMemsetAsync(e->d_run.ptr, 0, 16, e->stream)); }      /* the running block / group numbers restart */
+        if (c == 0 && !a->clear_in_kernel) { HIPCHK(hipMemsetAsync(e->d_run.ptr, 0, 16, e->stream)); }      /* the running block / group numbers restart */
         RCCHK(sla_hip_launch_expand((const sla_hip_superframe*)e->d_sframes.ptr + k->sf_lo, k->sf_hi - k->sf_lo,
                                     (const uint32_t*)e->d_parts.ptr, (const uint32_t*)e->d_nparts.ptr, (const uint32_t*)e->d_pstatus.ptr,
                                     C, 32 - bps + e->lshift, (const uint32_t*)e->d_winmap.ptr, (const uint32_t*)e->d_winmap.ptr + e->winmap_entries,
@@ -1276,7 +1282,8 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
          * they would sit there waiting for every chunk's search in turn, in front of whatever shares that stream's
          * hardware queue (measured with one queue per stream: 2.9 instead of 3.05 ms per C2 step;
          * SLA_HIP_PLAN_COPY=down restores the download stream). */
-        const hipStream_t st = e->plan_copy_down ? e->stream_down : e->stream;
+        /* (one chunk with everything on the search stream: there the copies would sit in front of the block stage) */
+        const hipStream_t st = (e->plan_copy_down || a->one_stream) ? e->stream_down : e->stream;
         if (st != e->stream) { HIPCHK(hipStreamWaitEvent(st, ev[EV_PLANNED], 0)); }
         HIPCHK(hipMemcpyAsync((uint32_t*)e->h_parts.ptr + (size_t)live_lo * SLA_HIP_PLAN_NODES, (uint32_t*)e->d_parts.ptr + (size_t)live_lo * SLA_HIP_PLAN_NODES,
                               sizeof(uint32_t) * (size_t)live * SLA_HIP_PLAN_NODES, hipMemcpyDeviceToHost, st));
@@ -1365,7 +1372,8 @@ static int tail_enqueue(struct SLAEncoder* e, actx_t* a, uint32_t c, uint32_t lo
   hipEvent_t* ev = a->ev + (size_t)c * EV_PER_CHUNK;
   /* one tail per chunk: on its own stream, so that the serial LMS chains (few waves, latency-bound) run beside the next
    * chunk's throughput-bound kernels; one tail for the file: behind the last solve on the kernel stream */
-  hipStream_t ts = e->single_tail ? e->stream2 : e->stream3;
+  hipStream_t ts = (a->one_stream && a->launched[0]) ? e->stream : (e->single_tail ? e->stream2 : e->stream3);
+  a->tail_stream = ts;
   if (!e->single_tail) {
     HIPCHK(hipEventRecord(ev[EV_SOLVED], e->stream2));
     HIPCHK(hipStreamWaitEvent(ts, ev[EV_SOLVED], 0));
@@ -1417,8 +1425,9 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c, int mode)
   const size_t cnt_base = (size_t)a->blocks_bound * C + 1;      /* h_cert_flag: per-slot flags, then one fallback count per chunk */
   /* option alt_streams: odd chunks run their block stage on the third stream, beside the even chunks' (not when the FFT
    * works in the shared global scratch) */
-  hipStream_t bs = (e->alt_now && e->device_ltm && e->single_tail && (c & 1u)
-                    && sizeof(double) * (size_t)fft_size <= SLA_HIP_LDS_BUDGET) ? e->stream3 : e->stream2;
+  hipStream_t bs = (mode == 1 && a->one_stream) ? e->stream
+                   : (e->alt_now && e->device_ltm && e->single_tail && (c & 1u)
+                      && sizeof(double) * (size_t)fft_size <= SLA_HIP_LDS_BUDGET) ? e->stream3 : e->stream2;
   size_t slot_lo, nsl;
 
   if (mode == 1) {
@@ -1728,8 +1737,11 @@ static int launch_searches(struct SLAEncoder* e, actx_t* a, int preset_blocks, i
   memset(a->ck, 0, sizeof(a->ck));
   /* the span slots are cleared on the search stream: every kernel that writes one is launched after the host has seen a
    * search of this run complete, i.e. behind this memset */
+  /* (with the tile-sum search those words, the rerun counter and k_expand's running numbers are cleared by the first search
+   * kernel itself -- slai_next_launch_clear -- instead of by three fill kernels in front of it) */
+  a->clear_in_kernel = (!preset_blocks && a->exact);
   if (dev_reserve(&e->d_spans, sizeof(unsigned long long) * MAX_CHUNKS * 4 * 2) != 0
-      || hipMemsetAsync(e->d_spans.ptr, 0, sizeof(unsigned long long) * MAX_CHUNKS * 4 * 2, e->stream) != hipSuccess
+      || (!a->clear_in_kernel && hipMemsetAsync(e->d_spans.ptr, 0, sizeof(unsigned long long) * MAX_CHUNKS * 4 * 2, e->stream) != hipSuccess)
       || (preset_blocks && hipStreamSynchronize(e->stream) != hipSuccess)) { return SLA_APIRESULT_NG; }
   TRACE("reserved", 0);
 
@@ -1752,6 +1764,7 @@ static int launch_searches(struct SLAEncoder* e, actx_t* a, int preset_blocks, i
    * (1.61 -> 1.52 ms), C3-600 s 3.03 -> 2.96, C5-120 s 5.26 -> 5.33 (within the run-to-run spread): on whenever chunked */
   e->alt_now = (e->alt_streams != 0);
   if (!(e->device_ltm && e->single_tail) || a->nchunks < 2) { e->alt_now = 0; }
+  a->one_stream = (e->one_stream && a->expand && a->nchunks == 1 && e->device_ltm && e->single_tail);
   /* chunk boundaries in 1/1000 of the super-frames: equal parts unless SLA_HIP_CHUNK_SPLIT gave the shares */
   if (e->first_chunk != 0 && a->nchunks >= 2) {
     /* option first_chunk: that many 1/1000 of the super-frames in chunk 0, the others share the rest equally */
@@ -1790,7 +1803,10 @@ static int launch_searches(struct SLAEncoder* e, actx_t* a, int preset_blocks, i
   }
 
   if (!preset_blocks) {
-    if (hipMemsetAsync((uint32_t*)e->d_or.ptr + 2, 0, sizeof(uint32_t), e->stream) != hipSuccess) { rc = SLA_APIRESULT_NG; }      /* groups rerun as serial chains */
+    if (a->clear_in_kernel) {
+      slai_next_launch_clear((uint32_t*)e->d_spans.ptr, MAX_CHUNKS * 4 * 2 * 2, (uint32_t*)e->d_or.ptr + 2, 1,
+                             a->expand ? (uint32_t*)e->d_run.ptr : NULL, 4);
+    } else if (hipMemsetAsync((uint32_t*)e->d_or.ptr + 2, 0, sizeof(uint32_t), e->stream) != hipSuccess) { rc = SLA_APIRESULT_NG; }      /* groups rerun as serial chains */
     for (c = 0; c < a->nchunks && rc == 0; c++) { rc = search_launch(e, a, c); }
     TRACE("search launched", a->nchunks);
   } else {
@@ -1933,7 +1949,7 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
     unsigned long long* sp_host = (unsigned long long*)((uint8_t*)e->h_or + 64);
     int copied = 0;
     if (rc == 0) {
-      hipStream_t last = (e->device_ltm && e->single_tail) ? e->stream2 : e->stream3;      /* the stream the last k_tail runs on */
+      hipStream_t last = (a.tail_stream != NULL) ? a.tail_stream : ((e->device_ltm && e->single_tail) ? e->stream2 : e->stream3);      /* the stream the last k_tail runs on */
       copied = (hipMemcpyAsync(sp_host, e->d_spans.ptr, sizeof(unsigned long long) * MAX_CHUNKS * 4 * 2, hipMemcpyDeviceToHost, last) == hipSuccess);
       if (!preset_blocks && hipMemcpyAsync(e->h_or + 2, (uint32_t*)e->d_or.ptr + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, last) != hipSuccess) { rc = SLA_APIRESULT_NG; }
     }
@@ -2028,6 +2044,7 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   else if (strcmp(name, "first_chunk") == 0)       { OPT_RANGE(0, 999); e->first_chunk = (uint32_t)iv; }
   else if (strcmp(name, "alt_streams") == 0)       { OPT_RANGE(0, 2); e->alt_streams = (int)iv; }
   else if (strcmp(name, "device_expand") == 0)     { OPT_RANGE(0, 1); e->device_expand = (int)iv; }
+  else if (strcmp(name, "one_stream") == 0)        { OPT_RANGE(0, 1); e->one_stream = (int)iv; }
   else if (strcmp(name, "table_cache") == 0)       { OPT_RANGE(0, 1); e->table_cache = (int)iv; e->tab_valid = 0; e->spec_valid = 0; }
   else if (strcmp(name, "device_ltm") == 0)        { OPT_RANGE(0, 1); e->device_ltm = (int)iv; }
   else if (strcmp(name, "fuse_lattice") == 0)      { OPT_RANGE(0, 1); e->fuse_lattice = (int)iv && !e->tune.lpc_blocks_chains; }

@@ -1237,15 +1237,30 @@ __device__ __forceinline__ void acf_tile_fma(const double (&own)[4], const doubl
 
 #define ACF_TILE 256u
 
+// Small device words that have to be zero before the kernels BEHIND this one on the stream use them (counters, flags, the
+// execution spans): cleared by the first workgroup of a kernel that is launched anyway instead of by a memset each -- a
+// 4-byte hipMemsetAsync is a 4 us fill kernel plus a launch boundary, and a ten-minute mono file had five of them on its
+// critical path (45 us of a 1.2 ms step).
+struct clear_list { uint32_t* ptr[4]; uint32_t words[4]; };
+__device__ __forceinline__ void clear_words(const clear_list& cl)
+{
+  if (blockIdx.x != 0) { return; }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    if (cl.ptr[r] != nullptr) { for (uint32_t i = threadIdx.x; i < cl.words[r]; i += blockDim.x) { cl.ptr[r][i] = 0u; } }
+  }
+}
+
 template <int NB>
 __global__ __launch_bounds__(256)
 void k_acf_tiles(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
                  const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, uint32_t tiles_per_group,
-                 double* __restrict__ tile_sums)
+                 double* __restrict__ tile_sums, clear_list cl)
 {
   constexpr uint32_t OL = 64 - NB;             // lanes of a pass that own samples
   constexpr uint32_t STEP = OL * 4, PASSES = (SLA_HIP_XTILE + STEP - 1) / STEP, LAGS = NB * 4;
   __shared__ double s_edge[4][2 * LAGS];       // x[t1-LAGS .. t1+LAGS) of each wave's tile end t1
+  clear_words(cl);
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t w = blockIdx.x * 4 + wv;
   const uint32_t gi = w / tiles_per_group, tile = w - gi * tiles_per_group;
@@ -1350,11 +1365,12 @@ __global__ __launch_bounds__(256, (NB >= 13) ? 3 : 1)      // 52 lags: 104 accum
 void k_acf_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t order,
                   const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups,
                   const double* __restrict__ window_pool, double* __restrict__ out, uint32_t* __restrict__ out_rshift,
-                  unsigned long long* exec_span)
+                  unsigned long long* exec_span, uint32_t* __restrict__ zero_word)
 {
   constexpr uint32_t LAGS = NB * 4, HL = NB + 1;             // HL pairs in front of a tile: all that lags < 4 NB reach
   __shared__ double2 s_e[4][2][64 + HL], s_o[4][2][64 + HL];
   span_begin(exec_span);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && zero_word != nullptr) { *zero_word = 0u; }      // the fallback count k_blocks_finish appends to
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t gi = blockIdx.x * 4 + wv;
   if (gi >= num_groups) { span_end(exec_span); return; }
@@ -2418,8 +2434,12 @@ __device__ __forceinline__ void tailk_block(const int32_t (&vm)[TAILK_BLK * K / 
         e = (int32_t)((uint32_t)v - (uint32_t)p);
         const int32_t ne = (int32_t)((uint32_t)p - (uint32_t)v);
         const uint32_t mag = (uint32_t)max(e, ne);
-        const int32_t lg = 32 - (int32_t)__clz((int)mag);
-        const int32_t g = __mul24(sgn(e), lg >> 1);        // step table src/SLAPredictor.c:123-144 times sign(e)
+        // step = ceil(log2(|e| + 1)) >> 1 (step table src/SLAPredictor.c:123-144), times sign(e).  v_ffbh_u32 answers -1 for
+        // zero, which would make the step 16 -- times sign(0) = 0: no special case (the portable __clz spelling cost five
+        // instructions on this chain, this one three)
+        uint32_t lead;
+        asm("v_ffbh_u32 %0, %1" : "=v"(lead) : "v"(mag));
+        const int32_t g = __mul24(sgn(e), (int32_t)((32u - lead) >> 1));
 #pragma unroll
         for (int a = 0; a < K; a++) {
           const int slot = ((a - u) % K + K) % K;
@@ -3446,6 +3466,13 @@ void k_ltm_solve(const double* __restrict__ acf, const sla_hip_lpc_group* __rest
 static thread_local unsigned long long* t_next_span = nullptr;
 extern "C" void slai_next_launch_span(unsigned long long* d_span) { t_next_span = d_span; }
 static inline unsigned long long* take_span() { unsigned long long* p = t_next_span; t_next_span = nullptr; return p; }
+// words the next sla_hip_launch_search_exact clears on the way (see clear_list): up to three regions, same host thread
+static thread_local clear_list t_next_clear = {{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}};
+extern "C" void slai_next_launch_clear(uint32_t* a, uint32_t na, uint32_t* b, uint32_t nb, uint32_t* c, uint32_t nc)
+{
+  t_next_clear.ptr[0] = a; t_next_clear.words[0] = na; t_next_clear.ptr[1] = b; t_next_clear.words[1] = nb;
+  t_next_clear.ptr[2] = c; t_next_clear.words[2] = nc;
+}
 
 // Tuning knobs of the launchers (include/sla_hip.h: sla_hip_tuning).  They belong to an encoder handle, which reads
 // them ONCE (environment at SLAEncoder_Create, sla_hip_encoder_set_option afterwards) and names its copy to the
@@ -3578,13 +3605,12 @@ extern "C" int sla_hip_launch_lpc_blocks_cert(const int32_t* d_pcm, uint64_t pla
   if (lags == 0) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }      // orders above 52: the exact kernels only
   if (num_groups == 0) { return 0; }
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(d_fallback_count, 0, sizeof(uint32_t), st);
-  if (e != hipSuccess) { return hip_rc(e); }
+  hipError_t e = hipSuccess;
   unsigned long long* span = take_span();
   const dim3 grid((num_groups + 3) / 4), block(256);
 #define SLA_ACFB(NBB) do { \
-    if (mid_side) { hipLaunchKernelGGL((k_acf_blocks<NBB, true>), grid, block, 0, st, d_pcm, plane_stride, order, d_groups, num_groups, d_window_pool, d_out, d_rshift, span); } \
-    else { hipLaunchKernelGGL((k_acf_blocks<NBB, false>), grid, block, 0, st, d_pcm, plane_stride, order, d_groups, num_groups, d_window_pool, d_out, d_rshift, span); } } while (0)
+    if (mid_side) { hipLaunchKernelGGL((k_acf_blocks<NBB, true>), grid, block, 0, st, d_pcm, plane_stride, order, d_groups, num_groups, d_window_pool, d_out, d_rshift, span, d_fallback_count); } \
+    else { hipLaunchKernelGGL((k_acf_blocks<NBB, false>), grid, block, 0, st, d_pcm, plane_stride, order, d_groups, num_groups, d_window_pool, d_out, d_rshift, span, d_fallback_count); } } while (0)
   switch (lags) {
     case 12: SLA_ACFB(3); break;
     case 20: SLA_ACFB(5); break;
@@ -3749,18 +3775,17 @@ extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_
   if (max_window == 0 || max_cands_per_group == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (num_groups == 0) { return 0; }
   hipStream_t st = (hipStream_t)stream;
-  if (d_any_exact != nullptr) {
-    const hipError_t ez = hipMemsetAsync(d_any_exact, 0, sizeof(uint32_t), st);
-    if (ez != hipSuccess) { return hip_rc(ez); }
-  }
+  clear_list cl = t_next_clear;                                       // what the caller asked to have cleared on the way
+  t_next_clear.ptr[0] = t_next_clear.ptr[1] = t_next_clear.ptr[2] = nullptr;
+  cl.ptr[3] = d_any_exact; cl.words[3] = (d_any_exact != nullptr) ? 1u : 0u;      // the flag k_search_finish raises
   const uint32_t tiles = (max_window + SLA_HIP_XTILE - 1) / SLA_HIP_XTILE;       // waves per group
   const uint32_t waves = num_groups * tiles;
   const dim3 grid((waves + 3) / 4), block(256);
   switch (lags) {
-    case 12: hipLaunchKernelGGL(k_acf_tiles<3>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums); break;
-    case 20: hipLaunchKernelGGL(k_acf_tiles<5>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums); break;
-    case 36: hipLaunchKernelGGL(k_acf_tiles<9>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums); break;
-    default: hipLaunchKernelGGL(k_acf_tiles<13>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums); break;
+    case 12: hipLaunchKernelGGL(k_acf_tiles<3>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); break;
+    case 20: hipLaunchKernelGGL(k_acf_tiles<5>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); break;
+    case 36: hipLaunchKernelGGL(k_acf_tiles<9>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); break;
+    default: hipLaunchKernelGGL(k_acf_tiles<13>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); break;
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { return hip_rc(e); }
