@@ -553,6 +553,9 @@ int sla_hip_get_trace(struct SLAEncoder* encoder, sla_hip_trace* trace);
  * "device_expand" (1 = default: block tables of certified partitions written on the device, sla_hip_launch_expand, the
  * host's copy following under the kernels; 0: host tables first) [SLA_HIP_EXPAND], "table_cache" (1 = default: the search
  * tables of a file without silence are kept for the next file of the same length and parameters) [SLA_HIP_TABLE_CACHE],
+ * "prelaunch" (1 = default: short files queue the certified block kernels together with the searches, sized for the most
+ * groups there can be, the kernels reading the number from the device), "one_stream" (1: a one-chunk file keeps search, block
+ * stage and tail on one stream; measured slower, default 0),
  * "upload24" (1 = default: pageable input of 17..24 significant bits crosses the bus as three bytes per sample; DESIGN
  * section 7 has the A/B) [SLA_HIP_UPLOAD24], "stream_piece" (samples per piece, all channels together; default 32 Mi; a file of fewer than two pieces is not
  * streamed), "stream_lanes" (worker lanes, 1..4, default 4).  After a streamed call the handle holds no analysis tables:

@@ -79,6 +79,8 @@ struct SLAEncoder {
   double   block_cert_safety;       /* safety factor on the first-order bound of that certificate (16) */
   volatile int cert_broken;         /* a block flagged by the certificate was not redone (internal error) */
   int      cert_now;                /* this run's block stage takes the certified route */
+  int      prelaunch;               /* 1 (default): short files queue the certified block kernels with the searches, sized for the most groups
+                                     * there can be and counting on the device (search_launch) */
   int      one_stream;              /* 1: a file that runs as one chunk on device tables keeps search, block stage and tail on ONE stream (measured
                                      * slower; default 0) */
   int      device_expand;           /* 1 (default): the block table of certified partitions is written on the device (k_expand) and the block
@@ -387,6 +389,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   e->table_cache = 1;
   env = getenv("SLA_HIP_TABLE_CACHE");
   if (env != NULL) { e->table_cache = (atoi(env) != 0); }
+  e->prelaunch = 1;
   e->device_expand = 1;
   env = getenv("SLA_HIP_EXPAND");
   if (env != NULL) { e->device_expand = (atoi(env) != 0); }
@@ -641,6 +644,7 @@ typedef struct {
   int borrowed;                                   /* sf / shapes belong to the encoder's table cache */
   int tab_hit;                                    /* ... and were found there                         */
   int spec;                                       /* the searches are in flight on a guess of the prepass result */
+  int prelaunched;                                /* chunk 0's certified block kernels were queued with the searches (device-side count) */
   int clear_in_kernel;                            /* spans, rerun counter and k_expand's numbers are cleared by the first search kernel */
   int one_stream;                                 /* one chunk on device tables: search, block stage and tail on ONE stream (no
                                                    * cross-queue event waits between them: 10 - 20 us each on the critical path) */
@@ -1276,6 +1280,28 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
                                     (sla_hip_acf_job*)e->d_acf_jobs.ptr, a->blocks_bound * C, (uint32_t*)e->h_counts.ptr + 4 * (size_t)c,
                                     e->expand_seq, e->stream));
         HIPCHK(hipEventRecord(ev[EV_EXPANDED], e->stream));
+        /* Short files: the first two kernels of the block stage go out right here, sized for the most groups the chunk can
+         * have and reading the number from the device (slai_next_launch_count) -- the device starts on them the moment the
+         * tables are written instead of 40 - 50 us later, when the host has seen the counts and made its first launches;
+         * by then it only has to queue the lattice behind them.  (Long files: their idle workgroups would cost more.) */
+        a->prelaunched = 0;
+        if (c == 0 && a->nchunks == 1 && e->cert_now && !(e->fuse_lattice && order <= 64) && (uint64_t)a->nsf * C <= SPECULATE_MAX_GROUPS
+            && e->device_ltm && e->prelaunch) {
+          const uint32_t ms2 = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
+          const hipStream_t ps = a->one_stream ? e->stream : e->stream2;      /* the stream blocks_launch will continue on */
+          HIPCHK(hipStreamWaitEvent(ps, ev[EV_EXPANDED], 0));
+          HIPCHK(hipEventRecord(ev[EV_LPCB_S], ps));
+          slai_next_launch_span(SPAN_SLOT(e, c, 0));
+          slai_next_launch_count((const uint32_t*)e->d_run.ptr);
+          RCCHK(sla_hip_launch_lpc_blocks_cert(e->pcm_dev, e->stride, ms2, order, (const sla_hip_lpc_group*)e->d_bgroups.ptr, a->blocks_bound * C,
+                                               a->max_window, (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
+                                               (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
+                                               (uint32_t*)e->d_rshift.ptr, (uint32_t*)e->d_cert_flag.ptr,
+                                               (uint32_t*)e->d_fb_list.ptr, (uint32_t*)e->d_fb_count.ptr + c,
+                                               e->block_cert_safety, bps, ps));
+          HIPCHK(hipEventRecord(ev[EV_LPCB_E], ps));
+          a->prelaunched = 1;
+        }
       }
       {
         /* The three small result copies stay on the search stream, in order behind k_plan.  On the download stream
@@ -1422,6 +1448,7 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c, int mode)
   uint32_t b, ch, max_window = 1, ng, nl;
   const int fused = (e->fuse_lattice && order <= 64);
   const int use_cert = e->cert_now;
+  const int pre = (use_cert && mode == 1 && c == 0 && a->prelaunched && !(e->fuse_lattice && order <= 64));
   const size_t cnt_base = (size_t)a->blocks_bound * C + 1;      /* h_cert_flag: per-slot flags, then one fallback count per chunk */
   /* option alt_streams: odd chunks run their block stage on the third stream, beside the even chunks' (not when the FFT
    * works in the shared global scratch) */
@@ -1485,13 +1512,17 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c, int mode)
     } else {
       HIPCHK(hipStreamWaitEvent(bs, ev[EV_EXPANDED], 0));      /* the tables were written on the search stream */
     }
-    HIPCHK(hipEventRecord(ev[EV_LPCB_S], bs));
-    slai_next_launch_span(SPAN_SLOT(e, c, 0));
+    if (!pre) {
+      HIPCHK(hipEventRecord(ev[EV_LPCB_S], bs));
+      slai_next_launch_span(SPAN_SLOT(e, c, 0));
+    }
     if (fused) {
       RCCHK(sla_hip_launch_lpc_blocks(e->pcm_dev, e->stride, ms, order, dg, ng, max_window,
                                       (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
                                       (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
                                       (uint32_t*)e->d_rshift.ptr, RES1(e), bs));
+    } else if (pre) {
+      /* queued with the searches (search_launch), events and span slot included */
     } else if (use_cert) {
       /* any-order autocorrelation + certified quantiser; what does not certify goes through the exact kernels behind it */
       RCCHK(sla_hip_launch_lpc_blocks_cert(e->pcm_dev, e->stride, ms, order, dg, ng, max_window,
@@ -1506,7 +1537,7 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c, int mode)
                                (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
                                (uint32_t*)e->d_rshift.ptr, bs));
     }
-    HIPCHK(hipEventRecord(ev[EV_LPCB_E], bs));
+    if (!pre) { HIPCHK(hipEventRecord(ev[EV_LPCB_E], bs)); }
     /* pass 2 (k_lpc_blocks is running): lattice chunks and FFT jobs */
     if (mode == 0) {
       uint32_t g = k->bg_lo;
@@ -2045,6 +2076,7 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   else if (strcmp(name, "alt_streams") == 0)       { OPT_RANGE(0, 2); e->alt_streams = (int)iv; }
   else if (strcmp(name, "device_expand") == 0)     { OPT_RANGE(0, 1); e->device_expand = (int)iv; }
   else if (strcmp(name, "one_stream") == 0)        { OPT_RANGE(0, 1); e->one_stream = (int)iv; }
+  else if (strcmp(name, "prelaunch") == 0)         { OPT_RANGE(0, 1); e->prelaunch = (int)iv; }
   else if (strcmp(name, "table_cache") == 0)       { OPT_RANGE(0, 1); e->table_cache = (int)iv; e->tab_valid = 0; e->spec_valid = 0; }
   else if (strcmp(name, "device_ltm") == 0)        { OPT_RANGE(0, 1); e->device_ltm = (int)iv; }
   else if (strcmp(name, "fuse_lattice") == 0)      { OPT_RANGE(0, 1); e->fuse_lattice = (int)iv && !e->tune.lpc_blocks_chains; }
@@ -3032,6 +3064,7 @@ static struct SLAEncoder* stream_lane(struct SLAEncoder* e, uint32_t t)
   l->fuse_lattice = e->fuse_lattice; l->device_plan = e->device_plan; l->search_exact = e->search_exact; l->exact_bits = e->exact_bits;
   l->cert_safety = e->cert_safety; l->single_tail = e->single_tail; l->device_ltm = e->device_ltm; l->tune = e->tune;
   l->block_cert = e->block_cert; l->block_cert_safety = e->block_cert_safety; l->alt_streams = e->alt_streams; l->device_expand = e->device_expand;
+  l->table_cache = e->table_cache; l->prelaunch = e->prelaunch; l->one_stream = e->one_stream;
   l->trace = 0;
   return l;
 }

@@ -48,6 +48,7 @@ int      slai_host_check(void);       /* 0: long double / double arithmetic of t
 /* sla_kernels.hip: the next k_lpc_blocks / k_lattice / k_ltm_acf / k_tail launch of this thread records its
  * execution span (2 x u64, zero-initialised device memory: ~min start, max end in 100 MHz ticks) */
 void slai_next_launch_span(unsigned long long* d_span);
+void slai_next_launch_count(const uint32_t* d_run);
 void slai_next_launch_clear(uint32_t* a, uint32_t na, uint32_t* b, uint32_t nb, uint32_t* c, uint32_t nc);
 
 uint32_t slai_zero_run(const uint64_t* nz_mask, uint64_t from, uint64_t limit);

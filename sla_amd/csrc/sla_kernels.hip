@@ -969,9 +969,11 @@ void k_blocks_finish(const sla_hip_lpc_group* __restrict__ groups, uint32_t num_
                      const uint32_t* __restrict__ out_rshift,
                      const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
                      uint32_t* __restrict__ cert_flag, uint32_t* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
-                     double safety, uint32_t bps)
+                     double safety, uint32_t bps, const uint32_t* __restrict__ dyn = nullptr)
 {
-  const uint32_t total = (list != nullptr) ? *list_count : num_groups;
+  // dyn: k_expand_scan's running numbers -- the launch was sized for the most groups the file can have, before the host
+  // knew how many there are (see sla_hip_launch_lpc_blocks_cert)
+  const uint32_t total = (list != nullptr) ? *list_count : ((dyn != nullptr) ? ((dyn[2] != 0u) ? 0u : (dyn[1] - dyn[3])) : num_groups);
   for (uint32_t li = blockIdx.x * 64 + threadIdx.x; li < total; li += gridDim.x * 64) {
   const uint32_t gi = (list != nullptr) ? list[li] : li;
   const uint32_t O1 = order + 1, O2 = order + 2;
@@ -1365,10 +1367,11 @@ __global__ __launch_bounds__(256, (NB >= 13) ? 3 : 1)      // 52 lags: 104 accum
 void k_acf_blocks(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t order,
                   const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups,
                   const double* __restrict__ window_pool, double* __restrict__ out, uint32_t* __restrict__ out_rshift,
-                  unsigned long long* exec_span, uint32_t* __restrict__ zero_word)
+                  unsigned long long* exec_span, uint32_t* __restrict__ zero_word, const uint32_t* __restrict__ dyn)
 {
   constexpr uint32_t LAGS = NB * 4, HL = NB + 1;             // HL pairs in front of a tile: all that lags < 4 NB reach
   __shared__ double2 s_e[4][2][64 + HL], s_o[4][2][64 + HL];
+  if (dyn != nullptr) { num_groups = (dyn[2] != 0u) ? 0u : (dyn[1] - dyn[3]); }      // (see k_blocks_finish)
   span_begin(exec_span);
   if (blockIdx.x == 0 && threadIdx.x == 0 && zero_word != nullptr) { *zero_word = 0u; }      // the fallback count k_blocks_finish appends to
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -3466,6 +3469,10 @@ void k_ltm_solve(const double* __restrict__ acf, const sla_hip_lpc_group* __rest
 static thread_local unsigned long long* t_next_span = nullptr;
 extern "C" void slai_next_launch_span(unsigned long long* d_span) { t_next_span = d_span; }
 static inline unsigned long long* take_span() { unsigned long long* p = t_next_span; t_next_span = nullptr; return p; }
+// the next sla_hip_launch_lpc_blocks_cert takes its group count from k_expand_scan's running numbers on the device (its
+// num_groups argument is then the most there can be): the launch can be queued before the host has seen the count
+static thread_local const uint32_t* t_next_count = nullptr;
+extern "C" void slai_next_launch_count(const uint32_t* d_run) { t_next_count = d_run; }
 // words the next sla_hip_launch_search_exact clears on the way (see clear_list): up to three regions, same host thread
 static thread_local clear_list t_next_clear = {{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}};
 extern "C" void slai_next_launch_clear(uint32_t* a, uint32_t na, uint32_t* b, uint32_t nb, uint32_t* c, uint32_t nc)
@@ -3607,10 +3614,11 @@ extern "C" int sla_hip_launch_lpc_blocks_cert(const int32_t* d_pcm, uint64_t pla
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipSuccess;
   unsigned long long* span = take_span();
+  const uint32_t* dyn = t_next_count; t_next_count = nullptr;      // slai_next_launch_count: num_groups is an upper bound, the kernels read the number
   const dim3 grid((num_groups + 3) / 4), block(256);
 #define SLA_ACFB(NBB) do { \
-    if (mid_side) { hipLaunchKernelGGL((k_acf_blocks<NBB, true>), grid, block, 0, st, d_pcm, plane_stride, order, d_groups, num_groups, d_window_pool, d_out, d_rshift, span, d_fallback_count); } \
-    else { hipLaunchKernelGGL((k_acf_blocks<NBB, false>), grid, block, 0, st, d_pcm, plane_stride, order, d_groups, num_groups, d_window_pool, d_out, d_rshift, span, d_fallback_count); } } while (0)
+    if (mid_side) { hipLaunchKernelGGL((k_acf_blocks<NBB, true>), grid, block, 0, st, d_pcm, plane_stride, order, d_groups, num_groups, d_window_pool, d_out, d_rshift, span, d_fallback_count, dyn); } \
+    else { hipLaunchKernelGGL((k_acf_blocks<NBB, false>), grid, block, 0, st, d_pcm, plane_stride, order, d_groups, num_groups, d_window_pool, d_out, d_rshift, span, d_fallback_count, dyn); } } while (0)
   switch (lags) {
     case 12: SLA_ACFB(3); break;
     case 20: SLA_ACFB(5); break;
@@ -3622,7 +3630,7 @@ extern "C" int sla_hip_launch_lpc_blocks_cert(const int32_t* d_pcm, uint64_t pla
   if (e != hipSuccess) { return hip_rc(e); }
   const dim3 fgrid((num_groups + 63) / 64), fblock(64);
 #define SLA_FINC(PP) hipLaunchKernelGGL((k_blocks_finish<PP, true>), fgrid, fblock, 0, st, d_groups, num_groups, order, d_out, d_code, d_kint, \
-                                        d_rshift, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_cert_flag, d_fallback_list, d_fallback_count, safety, bits_per_sample)
+                                        d_rshift, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_cert_flag, d_fallback_list, d_fallback_count, safety, bits_per_sample, dyn)
   if (order <= 16) { SLA_FINC(16); } else if (order <= 32) { SLA_FINC(32); } else if (order <= 48) { SLA_FINC(48); } else { SLA_FINC(64); }
 #undef SLA_FINC
   e = hipGetLastError();

@@ -65,6 +65,9 @@ def test_device_tables_give_the_host_tables_bytes(oracle, hip, nch, bits, rate, 
     dev, ed, cnt = _encode(hip, p, pcm, device_expand=1, stream=0)
     assert eh[0] == 0
     assert dev == host
+    # the certified block kernels queued with the searches (short files) or after the counts; everything on one stream
+    assert _encode(hip, p, pcm, device_expand=1, stream=0, prelaunch=0)[0] == host
+    assert _encode(hip, p, pcm, device_expand=1, stream=0, one_stream=1)[0] == host
     # every chunk of a file without silence whose partitions all certify runs from device tables
     if cnt[1] == 0:
         assert ed[0] == ed[1] and ed[1] >= 1, ed
