@@ -345,9 +345,12 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   if (hipGetDeviceProperties(&prop, e->device) == hipSuccess) {
     snprintf(g_device_name, sizeof(g_device_name), "%.160s (%.80s)", prop.name, prop.gcnArchName);
   }
-  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess
-      || hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess
-      || hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess) { goto fail; }
+  /* (SLA_HIP_STREAM_ORDER=1 creates them in the opposite order: an experiment behind option "one_stream") */
+  if ((getenv("SLA_HIP_STREAM_ORDER") != NULL && hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess)
+      || (getenv("SLA_HIP_STREAM_ORDER") != NULL && hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess)
+      || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess
+      || (e->stream2 == NULL && hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess)
+      || (e->stream3 == NULL && hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess)) { goto fail; }
   if (getenv("SLA_HIP_COPY_STREAMS") != NULL && atoi(getenv("SLA_HIP_COPY_STREAMS")) == 0) {   /* debugging: copies back on the kernel stream */
     e->stream_up = e->stream2; e->stream_down = e->stream2; e->own_copy_streams = 0;
   } else {
