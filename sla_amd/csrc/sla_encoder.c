@@ -1769,6 +1769,7 @@ static int launch_searches(struct SLAEncoder* e, actx_t* a, int preset_blocks, i
   int rc = 0;
   e->expand_seq += 1; if (e->expand_seq == 0) { e->expand_seq = 1; }
   memset(a->ck, 0, sizeof(a->ck));
+  a->prelaunched = 0;                              /* (a second call after a wrong guess starts from scratch) */
   /* the span slots are cleared on the search stream: every kernel that writes one is launched after the host has seen a
    * search of this run complete, i.e. behind this memset */
   /* (with the tile-sum search those words, the rerun counter and k_expand's running numbers are cleared by the first search
