@@ -139,7 +139,7 @@ typedef struct sla_hip_tuning {
                                    2 = k_tail (twice that), 3 = k_tail1 (ONE lane per job, LMS order <= 16) */
   double   plan_margin;         /* certification margin of k_plan, 0 = 1e-4 (tests raise it to force the host plan)  */
   uint32_t acf_classic;         /* 1: long-term autocorrelation through k_ltm_acf (one LDS pass per step) instead of k_ltm_acf2 */
-  uint32_t pad_;
+  uint32_t rice_lanes;          /* Rice parameter walk: 1 = one lane per job (k_rice_k), 2 = the two-lane pipeline (k_rice_k2), 0 = by the number of jobs */
 } sla_hip_tuning;
 void sla_hip_use_tuning(const sla_hip_tuning* tuning);
 
@@ -556,6 +556,7 @@ int sla_hip_get_trace(struct SLAEncoder* encoder, sla_hip_trace* trace);
  * "prelaunch" (1 = default: short files queue the certified block kernels together with the searches, sized for the most
  * groups there can be, the kernels reading the number from the device), "one_stream" (1: a one-chunk file keeps search, block
  * stage and tail on one stream; measured slower, default 0),
+ * "rice_lanes" (Rice parameter walk of the device pack: 0 = by the number of jobs, 1 = one lane per job, 2 = two-lane pipeline),
  * "upload24" (1 = default: pageable input of 17..24 significant bits crosses the bus as three bytes per sample; DESIGN
  * section 7 has the A/B) [SLA_HIP_UPLOAD24], "stream_piece" (samples per piece, all channels together; default 32 Mi; a file of fewer than two pieces is not
  * streamed), "stream_lanes" (worker lanes, 1..4, default 4).  After a streamed call the handle holds no analysis tables:

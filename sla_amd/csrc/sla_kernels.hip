@@ -4232,6 +4232,121 @@ void k_rice_k(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_ri
   for (; s < n; s++) { ko[s] = (uint16_t)step(in[s]); }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_rice_k2: the same walk as a two-lane pipeline, for files with few (block, channel) jobs -- where k_rice_k's duration
+// is ONE job's serial walk (~105 ns per sample: a ten-second clip waits 0.43 ms for it with the chip empty).
+// What is serial in the walk is only the two recurrences p0' = adapt(p0, v) and p1' = v >= 2^k0 ? adapt(p1, v - 2^k0) : p1;
+// everything around them is a function of one sample: the code terms c = 9 (code << 8) split into c >> 7 and (c & 127) + 64,
+// the exponents k = rice_k(p), the comparison.  So, per batch of 64 samples of a job:
+//   P1  all lanes, lane = sample: fold the residual, the first recurrence's two code terms -> LDS
+//   S   lane A walks p0 over batch t while lane B walks p1 over batch t - 1 -- the SAME instruction stream (B's update is
+//       conditional, A's condition is always true): q = p >> 7, r = p & 127, p' = 119 q + hi + ((119 r + lo) >> 7);
+//       both leave the parameter AS IT STOOD before each sample in LDS
+//   P2  all lanes: k0 = rice_k(p0), the condition v >= 2^k0 and the second recurrence's code terms of v - 2^k0 -> LDS
+//   P3  all lanes, batch t - 1: k1 = rice_k(p1), k0 | k1 << 8 -> global memory
+// Eight jobs per wave (sixteen lanes in S).  Same values as k_rice_k, sample for sample (test_rice_walk_kernels_agree and
+// every byte comparison of the suite: the pack stage chooses by the number of jobs).
+// ---------------------------------------------------------------------------------------------
+#define RK2_JOBS 8
+struct rk2_lds {
+  uint32_t in_a[RK2_JOBS][64][2];      // first recurrence: c >> 7, ((c & 127) + 64) | 1 << 8
+  uint32_t in_b[RK2_JOBS][64][2];      // second recurrence: the same of v - 2^k0, bit 8 = the update happens
+  uint32_t p0[RK2_JOBS][64], p1[RK2_JOBS][64];      // the parameters before each sample
+  uint32_t v[RK2_JOBS][64];            // folded residual
+  uint32_t k0[2][RK2_JOBS][64];        // first exponent, kept for one more step (the second one is a batch behind)
+};
+
+__global__ __launch_bounds__(256)
+void k_rice_k2(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_rice_job* __restrict__ jobs,
+               uint32_t num_jobs, uint16_t* __restrict__ kk)
+{
+  __shared__ rk2_lds s_all[4];
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  rk2_lds& L = s_all[wv];
+  const uint32_t wave = blockIdx.x * 4 + wv;
+  // lane l holds the fields of the wave's job l & 7; a phase that works on job j fetches them with a shuffle
+  const uint32_t jb = wave * RK2_JOBS + (lane & 7u);
+  const bool have = (jb < num_jobs);
+  const sla_hip_rice_job job = jobs[have ? jb : 0];
+  const uint32_t my_n = (have && job.golomb_m == 0) ? job.blk_len : 0u;          // fixed-parameter mode: stateless, nothing to walk
+  const uint64_t my_off = (uint64_t)job.channel * stride + job.blk_off;
+  const uint32_t nmax = umax_wave(my_n);
+  const uint32_t nb = (nmax + 63u) / 64u;
+  // the sixteen walking lanes: lane 2 j is A of job j, lane 2 j + 1 its B
+  const uint32_t js = (lane >> 1) & 7u, role = lane & 1u;
+  uint32_t p = (uint32_t)__shfl((int)(uint32_t)(job.rice_init << 8), (int)js);
+  // the eight jobs' lengths and plane offsets as wave-uniform values (scalar registers), fetched once
+  uint32_t n_of[RK2_JOBS]; uint64_t off_of[RK2_JOBS];
+#pragma unroll
+  for (int j = 0; j < RK2_JOBS; j++) {
+    n_of[j] = (uint32_t)__builtin_amdgcn_readlane((int)my_n, j);
+    off_of[j] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_off >> 32), j) << 32)
+              | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_off, j);
+  }
+  // residuals travel one batch ahead of their use: batch t + 1 is requested before the walk over batch t starts
+  int32_t ahead[RK2_JOBS];
+#pragma unroll
+  for (int j = 0; j < RK2_JOBS; j++) { ahead[j] = (lane < n_of[j]) ? res[off_of[j] + lane] : 0; }
+  for (uint32_t t = 0; t <= nb; t++) {
+    if (t < nb) {
+      // ---- P1: batch t of every job ----
+#pragma unroll
+      for (int j = 0; j < RK2_JOBS; j++) {
+        const uint32_t v = fold_u32(ahead[j]);
+        const uint32_t c = 9u * (v << 8);
+        L.in_a[j][lane][0] = c >> 7; L.in_a[j][lane][1] = ((c & 127u) + 64u) | 256u;
+        L.v[j][lane] = v;
+      }
+#pragma unroll
+      for (int j = 0; j < RK2_JOBS; j++) {
+        const uint32_t sidx = (t + 1u) * 64u + lane;
+        ahead[j] = (sidx < n_of[j]) ? res[off_of[j] + sidx] : 0;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- S: A on batch t, B on batch t - 1 ----
+    if (lane < 2 * RK2_JOBS && (role ? (t >= 1u) : (t < nb))) {
+      const uint32_t (*in)[2] = role ? L.in_b[js] : L.in_a[js];
+      uint32_t* pout = role ? L.p1[js] : L.p0[js];
+#pragma unroll 1
+      for (uint32_t i0 = 0; i0 < 64; i0 += 8) {
+        uint32_t hi[8], lo[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { hi[u] = in[i0 + u][0]; lo[u] = in[i0 + u][1]; }      // eight steps' operands requested at once
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          pout[i0 + u] = p;
+          const uint32_t q = p >> 7, r = p & 127u;
+          const uint32_t np = 119u * q + hi[u] + ((119u * r + (lo[u] & 255u)) >> 7);
+          p = (lo[u] & 256u) ? np : p;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (t < nb) {
+      // ---- P2: batch t ----
+#pragma unroll
+      for (uint32_t j = 0; j < RK2_JOBS; j++) {
+        const uint32_t k0 = rice_k32(L.p0[j][lane]);
+        const uint32_t v = L.v[j][lane], m0 = 1u << k0;
+        const uint32_t c = 9u * ((v - m0) << 8);
+        L.in_b[j][lane][0] = c >> 7; L.in_b[j][lane][1] = ((c & 127u) + 64u) | ((v >= m0) ? 256u : 0u);
+        L.k0[t & 1u][j][lane] = k0;
+      }
+    }
+    if (t >= 1u) {
+      // ---- P3: batch t - 1 ----
+#pragma unroll
+      for (int j = 0; j < RK2_JOBS; j++) {
+        const uint32_t sidx = (t - 1u) * 64u + lane;
+        const uint32_t k1 = rice_k32(L.p1[j][lane]);
+        if (sidx < n_of[j]) { kk[off_of[j] + sidx] = (uint16_t)(L.k0[(t - 1u) & 1u][j][lane] | (k1 << 8)); }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 // total body bits of every (block, channel): one wave per job, lanes stride over the samples
 __global__ __launch_bounds__(256)
 void k_rice_bits(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_rice_job* __restrict__ jobs,
@@ -4376,13 +4491,22 @@ void k_block_crc(const sla_hip_pack_block* __restrict__ blocks, uint32_t num_blo
   }
 }
 
+#define RICE_K2_MAX_JOBS 32768u
 extern "C" int sla_hip_launch_rice_len(const int32_t* d_residual, uint64_t plane_stride, const sla_hip_rice_job* d_jobs,
                                        uint32_t num_jobs, uint16_t* d_kk, uint64_t* d_chan_bits, sla_hip_stream_t stream)
 {
   if (d_residual == nullptr || d_jobs == nullptr || d_kk == nullptr || d_chan_bits == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (num_jobs == 0) { return 0; }
-  hipLaunchKernelGGL(k_rice_k, dim3((num_jobs + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_residual, plane_stride,
-                     d_jobs, num_jobs, d_kk);
+  /* few jobs: the two-lane pipeline (k_rice_k2), whose walk per sample is a third of k_rice_k's; many: one lane per job,
+   * a quarter of the instructions per job and sample.  tuning().rice_lanes: 1 / 2 force one or the other */
+  const uint32_t rl = tuning().rice_lanes;
+  if (rl == 2 || (rl == 0 && num_jobs <= RICE_K2_MAX_JOBS)) {
+    hipLaunchKernelGGL(k_rice_k2, dim3((num_jobs + 4 * RK2_JOBS - 1) / (4 * RK2_JOBS)), dim3(256), 0, (hipStream_t)stream, d_residual, plane_stride,
+                       d_jobs, num_jobs, d_kk);
+  } else {
+    hipLaunchKernelGGL(k_rice_k, dim3((num_jobs + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_residual, plane_stride,
+                       d_jobs, num_jobs, d_kk);
+  }
   hipLaunchKernelGGL(k_rice_bits, dim3((num_jobs + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_residual, plane_stride,
                      d_jobs, num_jobs, d_kk, d_chan_bits);
   return hip_rc(hipGetLastError());

@@ -1122,3 +1122,20 @@ def test_upload24_gives_the_same_bytes(oracle, hip, nch, bits, n):
     assert got == want
     got, _ = _encode_with_options(hip, p, pcm, upload24=1, stream=1, stream_piece=65536)
     assert got == want
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 127, 129, 4095, 4097, 20011, 131072 + 77])
+@pytest.mark.parametrize("kind", ["music", "quiet", "gaps"])
+def test_rice_walk_kernels_agree(oracle, hip, n, kind):
+    """the Rice parameter walk of the device pack as one lane per job (k_rice_k) and as the two-lane pipeline (k_rice_k2):
+    same bytes as the oracle from both, on ragged block lengths (batches of 64 samples: one under / over), job counts that
+    are not a multiple of the eight jobs of a wave (3 channels), fixed-Golomb blocks (quiet material) and silent ones"""
+    pcm = W.music_like(3, n, 16, seed=n % 89, level=0.004 if kind == "quiet" else 0.5)
+    if kind == "gaps" and n > 9000:
+        pcm[:, 3000:8000] = 0
+    p = S.make_params(3, 16, 48000, 8, 1, 8, 0, 1, 2048)
+    ret, want = oracle.encode_whole(p, pcm)
+    assert ret == 0
+    for lanes in (1, 2):
+        got, _ = _encode_with_options(hip, p, pcm, rice_lanes=lanes, stream=0)
+        assert got == want, lanes
