@@ -3491,6 +3491,10 @@ static thread_local bool t_tuning_set = false;
 extern "C" void sla_hip_use_tuning(const sla_hip_tuning* tuning)
 {
   if (tuning != nullptr) { t_tuning_val = *tuning; t_tuning_set = true; } else { t_tuning_set = false; }
+  // every API entry of a handle comes through here: a one-shot request (span slot, words to clear, device-side count) that
+  // an earlier call set and -- leaving on an error -- never used must not reach the next launch of this thread
+  t_next_span = nullptr; t_next_count = nullptr;
+  t_next_clear.ptr[0] = t_next_clear.ptr[1] = t_next_clear.ptr[2] = nullptr;
 }
 static inline sla_hip_tuning tuning()
 {
