@@ -192,3 +192,26 @@ def test_kept_search_tables(oracle, hip):
         assert enc.encode_whole(pcm) == want and enc.last_expand()[2] == 6
     finally:
         enc.close()
+
+
+def test_guess_meets_a_silent_last_superframe(oracle, hip):
+    """two files of one shape on one handle; the second one ends in a few zero samples that make its last super-frame
+    SILENT (no all-zero mask word reports that: the tail words of the mask do) -- the searches launched on the guess
+    "like the file before" are thrown away, the tables rebuilt, the bytes are the oracle's; then the first file again"""
+    n = 4096 * 48 + 40
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096)
+    a = W.music_like(2, n, 16, seed=61)
+    b = W.music_like(2, n, 16, seed=62)
+    b[:, 4096 * 48:] = 0
+    enc = hip.Encoder(p.cap_channels, p.cap_block_samples, p.cap_parcor_order, p.cap_longterm_order, p.cap_lms_order)
+    try:
+        enc.set_option("stream", 0)
+        enc.set_wave_format(2, 16, 48000)
+        enc.set_encode_parameter(16, 1, 8, 1, 1, 4096)
+        for pcm in (a, a, b, a, a, b, b):
+            ret, want = oracle.encode_whole(p, pcm)
+            assert ret == 0
+            assert enc.encode_whole(pcm) == want
+        assert enc.last_expand()[3] >= 2          # both first meetings with b were wrong guesses
+    finally:
+        enc.close()
