@@ -138,7 +138,8 @@ typedef struct sla_hip_tuning {
                                    6 / 4 / 5 = k_tailk with 1 / 2 / 4 taps; round-2 kernels: 1 = k_tail2 (LMS order lanes per job),
                                    2 = k_tail (twice that), 3 = k_tail1 (ONE lane per job, LMS order <= 16) */
   double   plan_margin;         /* certification margin of k_plan, 0 = 1e-4 (tests raise it to force the host plan)  */
-  uint32_t acf_classic;         /* 1: long-term autocorrelation through k_ltm_acf (one LDS pass per step) instead of k_ltm_acf2 */
+  uint32_t acf_classic;         /* 1: round 2's autocorrelation kernels: long-term stage through k_ltm_acf (one LDS pass per step) instead of
+                                   k_ltm_acf2, tile sums at 52 lags through k_acf_tiles (DPP moves) instead of k_acf_tiles_lds */
   uint32_t rice_lanes;          /* Rice parameter walk: 1 = one lane per job (k_rice_k), 2 = the two-lane pipeline (k_rice_k2), 0 = by the number of jobs */
 } sla_hip_tuning;
 void sla_hip_use_tuning(const sla_hip_tuning* tuning);

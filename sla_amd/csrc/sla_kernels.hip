@@ -1346,6 +1346,117 @@ void k_acf_tiles(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_acf_tiles_lds: the tile sums of k_acf_tiles with the partners from LDS (acf_tile_fma) instead of DPP moves -- for 52
+// lags, where the moves are most of the instructions (C5: 489 -> see DESIGN us per launch; at 36 lags and below the DPP
+// kernel is as fast or faster and stays).  acf_tile_fma pairs a sample with the ones BEHIND it; P_t[lag] needs the ones
+// AHEAD (x[m] x[m + lag], m in the tile, m + lag anywhere in the window), so the tile is walked BACKWARDS: in reversed
+// coordinates u = (t1 + 4 HL - 1) - m the partner m + lag is u - lag, the first 4 HL reversed samples -- the ones just
+// above the tile's end -- are the front nobody owns, and the tile's own samples follow as up to four sub-tiles of 256.
+// Samples below t0 count as zero (they are another tile's), samples from the window's end on are zero anyway.  X_t as
+// in k_acf_tiles, from an edge buffer.  (The first LDS port of round 3 kept the forward walk and re-defined P and X by
+// the position of a pair's LATER sample; it was three times slower and was dropped.)
+// ---------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(256, (NB >= 13) ? 3 : 1)
+void k_acf_tiles_lds(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms,
+                     const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, uint32_t tiles_per_group,
+                     double* __restrict__ tile_sums, clear_list cl)
+{
+  constexpr uint32_t LAGS = NB * 4, HL = NB + 1;
+  __shared__ double2 s_e[4][2][64 + HL], s_o[4][2][64 + HL];
+  __shared__ double s_edge[4][2 * LAGS];       // x[t1-LAGS .. t1+LAGS) of each wave's tile end t1 (zero below t0)
+  clear_words(cl);
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t w = blockIdx.x * 4 + wv;
+  const uint32_t gi = w / tiles_per_group, tile = w - gi * tiles_per_group;
+  if (gi >= num_groups) { return; }
+  const sla_hip_lpc_group g = groups[gi];
+  const uint32_t N = g.num_samples, t0 = tile * SLA_HIP_XTILE;
+  if (t0 >= N) { return; }
+  const uint32_t t1 = (t0 + SLA_HIP_XTILE < N) ? (t0 + SLA_HIP_XTILE) : N;
+  const double scale = 4.656612873077392578125e-10;   // 2^-31, exact (same arithmetic as load_f64)
+  const int32_t* p0 = pcm + (ms ? 0 : (uint64_t)g.channel * stride) + g.pcm_off;
+  const int32_t* p1 = pcm + stride + g.pcm_off;
+  auto value = [&](int32_t a, int32_t b) -> double {
+    if (ms) { const double l = (double)a * scale, r = (double)b * scale; return (g.channel == 0) ? ((l + r) / 2) : (l - r); }
+    return (double)a * scale;
+  };
+  // four consecutive samples m0 .. m0+3 (m0 may be negative), zero outside [lo, N)
+  struct raw4 { int32_t a[4]; int32_t b[4]; };
+  auto fetch = [&](int64_t m0, uint32_t lo, raw4& r) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) { r.a[q] = 0; r.b[q] = 0; }
+    if (m0 >= (int64_t)lo && m0 + 3 < (int64_t)N) {
+      const i32x4_u t = *(const i32x4_u*)(p0 + m0);
+      r.a[0] = t.x; r.a[1] = t.y; r.a[2] = t.z; r.a[3] = t.w;
+      if (ms) { const i32x4_u u = *(const i32x4_u*)(p1 + m0); r.b[0] = u.x; r.b[1] = u.y; r.b[2] = u.z; r.b[3] = u.w; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int64_t m = m0 + q;
+        if (m >= (int64_t)lo && m < (int64_t)N) { r.a[q] = p0[m]; if (ms) { r.b[q] = p1[m]; } }
+      }
+    }
+  };
+  // edge buffer for X
+  for (uint32_t i = lane; i < 2 * LAGS; i += 64) {
+    const int64_t m = (int64_t)t1 - (int64_t)LAGS + (int64_t)i;
+    double v = 0.0;
+    if (m >= (int64_t)t0 && m < (int64_t)N) { v = value(p0[m], ms ? p1[m] : 0); }
+    s_edge[wv][i] = v;
+  }
+  // front: the 4 HL samples from t1 on, reversed; lane i < HL holds reversed positions 4 i .. 4 i + 3 = x[t1 + 4 HL - 1 - 4 i] downwards
+  if (lane < HL) {
+    raw4 f;
+    fetch((int64_t)t1 + 4 * (int64_t)HL - 4 - 4 * (int64_t)lane, t0, f);
+    s_e[wv][0][lane] = make_double2(value(f.a[3], f.b[3]), value(f.a[2], f.b[2]));
+    s_o[wv][0][lane] = make_double2(value(f.a[1], f.b[1]), value(f.a[0], f.b[0]));
+  }
+  double acc[LAGS];
+#pragma unroll
+  for (int i = 0; i < (int)LAGS; i++) { acc[i] = 0.0; }
+  const uint32_t nsub = (t1 - t0 + ACF_TILE - 1) / ACF_TILE;
+  raw4 nxt;
+  fetch((int64_t)t1 - (int64_t)ACF_TILE + 4 * (int64_t)(63 - lane), t0, nxt);
+  uint32_t buf = 0;
+  for (uint32_t sub = 0; sub < nsub; sub++, buf ^= 1u) {
+    const raw4 cur = nxt;
+    if (sub + 1 < nsub) { fetch((int64_t)t1 - (int64_t)ACF_TILE * (sub + 2) + 4 * (int64_t)(63 - lane), t0, nxt); }
+    double own[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { own[q] = value(cur.a[3 - q], cur.b[3 - q]); }      // reversed: the lane's highest sample first
+    double2* E = s_e[wv][buf];
+    double2* O = s_o[wv][buf];
+    E[HL + lane] = make_double2(own[0], own[1]);
+    O[HL + lane] = make_double2(own[2], own[3]);
+    if (lane >= 64 - HL) {                     // this sub-tile's last HL pairs are what the next one finds in front of it
+      s_e[wv][buf ^ 1u][lane - (64 - HL)] = make_double2(own[0], own[1]);
+      s_o[wv][buf ^ 1u][lane - (64 - HL)] = make_double2(own[2], own[3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    acf_tile_fma<NB>(own, E, O, lane, acc);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  double* dst = tile_sums + ((uint64_t)gi * SLA_HIP_XTILES + tile) * (2 * LAGS);
+  {
+    constexpr int M = (LAGS <= 16) ? 16 : (LAGS <= 32) ? 32 : 64;
+    double tv[M];
+#pragma unroll
+    for (int i = 0; i < M; i++) { tv[i] = (i < (int)LAGS) ? acc[i] : 0.0; }
+    uint32_t index; bool writer;
+    const double total = wave_transpose_sum<M>(tv, lane, index, writer);
+    if (writer && index < LAGS) { dst[index] = total; }
+  }
+  // pairs that straddle t1: lane = lag
+  if (lane < LAGS) {
+    double x = 0.0;
+    const double* e = s_edge[wv];
+    for (uint32_t j = 0; j < lane; j++) { x = __builtin_fma(e[LAGS - lane + j], e[LAGS + j], x); }
+    dst[LAGS + lane] = x;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_acf_blocks: autocorrelation of the CHOSEN blocks' analysis windows in any summation order (the certified route of
 // the block stage, see k_blocks_finish<.., true>).  One wave per (block, channel) walks the whole window in tiles of 256
 // samples (acf_tile_fma); the accumulators live in registers across the tiles and are reduced over the lanes ONCE per
@@ -3797,7 +3908,10 @@ extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_
     case 12: hipLaunchKernelGGL(k_acf_tiles<3>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); break;
     case 20: hipLaunchKernelGGL(k_acf_tiles<5>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); break;
     case 36: hipLaunchKernelGGL(k_acf_tiles<9>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); break;
-    default: hipLaunchKernelGGL(k_acf_tiles<13>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); break;
+    default:
+      if (tuning().acf_classic) { hipLaunchKernelGGL(k_acf_tiles<13>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); }
+      else { hipLaunchKernelGGL(k_acf_tiles_lds<13>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); }
+      break;
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { return hip_rc(e); }

@@ -1139,3 +1139,18 @@ def test_rice_walk_kernels_agree(oracle, hip, n, kind):
     for lanes in (1, 2):
         got, _ = _encode_with_options(hip, p, pcm, rice_lanes=lanes, stream=0)
         assert got == want, lanes
+
+
+@pytest.mark.parametrize("n,bits,ms", [(8192 * 6 + 333, 24, 0), (8192 * 3 + 40, 16, 0), (4096 * 9 + 1999, 24, 1), (1500, 24, 0)])
+def test_tile_sums_at_52_lags_both_kernels(oracle, hip, n, bits, ms):
+    """orders 33 .. 52 take the tile sums from k_acf_tiles_lds (partners from LDS, tile walked backwards); option
+    acf_classic keeps k_acf_tiles<13> (DPP moves): the oracle's bytes from both, on windows with a short last tile (fewer
+    samples than lags in it), a window shorter than a tile, loud 24-bit material (certified sums) and 16-bit (exact sums)"""
+    nch = 2 if ms else 1
+    pcm = W.music_like(nch, n, bits, seed=n % 71, level=1.0)
+    p = S.make_params(nch, bits, 96000, 48, 3, 8, ms, 1, 8192)
+    ret, want = oracle.encode_whole(p, pcm)
+    assert ret == 0
+    for classic in (0, 1):
+        got, _ = _encode_with_options(hip, p, pcm, acf_classic=classic, stream=0)
+        assert got == want, classic
