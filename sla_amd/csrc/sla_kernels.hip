@@ -3906,8 +3906,14 @@ extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_
   const dim3 grid((waves + 3) / 4), block(256);
   switch (lags) {
     case 12: hipLaunchKernelGGL(k_acf_tiles<3>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); break;
-    case 20: hipLaunchKernelGGL(k_acf_tiles<5>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); break;
-    case 36: hipLaunchKernelGGL(k_acf_tiles<9>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); break;
+    case 20:
+      if (tuning().acf_classic) { hipLaunchKernelGGL(k_acf_tiles<5>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); }
+      else { hipLaunchKernelGGL(k_acf_tiles_lds<5>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); }
+      break;
+    case 36:
+      if (tuning().acf_classic) { hipLaunchKernelGGL(k_acf_tiles<9>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); }
+      else { hipLaunchKernelGGL(k_acf_tiles_lds<9>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); }
+      break;
     default:
       if (tuning().acf_classic) { hipLaunchKernelGGL(k_acf_tiles<13>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); }
       else { hipLaunchKernelGGL(k_acf_tiles_lds<13>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); }
