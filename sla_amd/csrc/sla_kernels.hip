@@ -552,7 +552,7 @@ __device__ __forceinline__ void lattice_chunk_wave_lds(const int32_t* __restrict
       prev = cur;
     }
   }
-  for (uint32_t m = 1; m <= order; m++) {
+  for (uint32_t m = 1; m < order; m++) {
     const int32_t k = kc[m];                       // wave-uniform -> scalar load
     int32_t carry = __shfl_up(b[LAT_T - 1], 1);    // b_{m-1} of the sample just before this lane's run
     if (lane == 0) { carry = 0; }
@@ -567,6 +567,15 @@ __device__ __forceinline__ void lattice_chunk_wave_lds(const int32_t* __restrict
       int32_t nb = (int32_t)((uint32_t)carry - (uint32_t)lat_term(k, f[0]));
       f[0] = nf; b[0] = nb;
     }
+  }
+  if (order >= 1) {
+    // the last stage: only the forward error leaves the lattice, its backward error has no reader (half the stage's work)
+    const int32_t k = kc[order];
+    int32_t carry = __shfl_up(b[LAT_T - 1], 1);
+    if (lane == 0) { carry = 0; }
+#pragma unroll
+    for (int i = LAT_T - 1; i >= 1; i--) { f[i] = (int32_t)((uint32_t)f[i] - (uint32_t)lat_term(k, b[i - 1])); }
+    f[0] = (int32_t)((uint32_t)f[0] - (uint32_t)lat_term(k, carry));
   }
   // results through the tile (slot e = sample base + e now), stored 64 consecutive samples at a time
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
