@@ -28,6 +28,10 @@ enc.bind_residual_planes(d_lat.data_ptr(), d_fin.data_ptr(), stride)
 torch.cuda.synchronize()
 for _ in range(3):
     enc.analyze_device(d_pcm.data_ptr(), stride, n)
+if os.environ.get("SLA_JITTER_NOGC"):
+    import gc
+    gc.collect()
+    gc.disable()
 t = np.zeros(steps)
 parts = []
 
