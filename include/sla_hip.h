@@ -141,6 +141,8 @@ typedef struct sla_hip_tuning {
   uint32_t acf_classic;         /* 1: round 2's autocorrelation kernels: long-term stage through k_ltm_acf (one LDS pass per step) instead of
                                    k_ltm_acf2, tile sums at 52 lags through k_acf_tiles (DPP moves) instead of k_acf_tiles_lds */
   uint32_t rice_lanes;          /* Rice parameter walk: 1 = one lane per job (k_rice_k), 2 = the two-lane pipeline (k_rice_k2), 0 = by the number of jobs */
+  uint32_t lattice_plain;       /* 1: every lattice stage in the wrapping four-instruction form (round 3); 0 = the shortest form each stage's
+                                   operand bound allows (same results: tests run both) */
 } sla_hip_tuning;
 void sla_hip_use_tuning(const sla_hip_tuning* tuning);
 

@@ -2061,6 +2061,7 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   else if (strcmp(name, "lpc_tile") == 0)          { if (iv != 0 && iv != 24 && iv != 48) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.lpc_tile = (uint32_t)iv; }
   else if (strcmp(name, "acf_classic") == 0)       { OPT_RANGE(0, 1); e->tune.acf_classic = (uint32_t)iv; }
   else if (strcmp(name, "rice_lanes") == 0)        { OPT_RANGE(0, 2); e->tune.rice_lanes = (uint32_t)iv; }
+  else if (strcmp(name, "lattice_plain") == 0)     { OPT_RANGE(0, 1); e->tune.lattice_plain = (uint32_t)iv; }
   else if (strcmp(name, "tail_lanes") == 0)        { OPT_RANGE(0, 6); e->tune.tail_lanes = (uint32_t)iv; }
   else if (strcmp(name, "lpc_blocks_chains") == 0) { OPT_RANGE(0, 1); e->tune.lpc_blocks_chains = (uint32_t)iv; if (iv) { e->fuse_lattice = 0; } }
   /* the certification margins may only be widened: below the built-in values byte-identity is no longer guaranteed */

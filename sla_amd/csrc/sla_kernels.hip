@@ -516,31 +516,146 @@ __device__ __forceinline__ void lattice_chunk_wave(const int32_t* __restrict__ p
 // on the wave's SIMD.  Here the wave reads its 1025 contiguous samples 64 at a time (4 transactions per access) into an
 // LDS tile padded by one word per 16 (lane stride 17: conflict-free when the lanes then pick up their runs), and the
 // residuals go back the same way.
+//
+// Round 4: the stages are written out instruction by instruction (the compiler's version of the C loop above carried 17
+// register moves per stage, fetched every coefficient with a VECTOR load it then waited for, and needed 115 VGPRs), and
+// each stage takes the shortest form its operands are PROVEN to allow.  The reference's term is
+//     R(k, v) = (int32)(k * v + 2^14) >> 15        with the 32-bit product wrapping (src/SLAPredictor.c:590,596)
+// and a stage is f[n] -= R(k, b[n-1]), b[n] = b[n-1] - R(k, f[n]).  The wave keeps a bound `bnd` >= every |f|, |b| it holds
+// (the maximum of its own inputs, then bnd += ((|k| bnd + 2^14) >> 15) + 1 per stage) in a scalar register; with
+// T = |k| bnd + 2^14 >= |k v + 2^14| a stage is, in this order of preference (cost = issue time per term in units of one
+// v_add_u32 at eight waves per SIMD, tests/tools/ubench_lattice.hip: only add / sub / logic ops issue at 32 lanes per clock on
+// gfx950, multiplies, shifts and SDWA forms at about half that):
+//   H  T < 2^31 and |k| < 2^14:   the HIGH dword of v_mad_i64_i32(k << 17, v, 2^31) is (k v + 2^14) >> 15 without any wrap, which
+//      is the reference's value when its own product does not wrap; then one subtraction: 2 instructions per term (3.3)
+//   S  T < 2^30, bnd < 2^23:      v_mad_i32_i24(2k, v, 2^15), and the subtraction takes the sign-extended HIGH WORD of that as
+//      its operand (SDWA): (2kv + 2^15) >> 16 = (kv + 2^14) >> 15 while nothing wraps: 2 per term (3.4); 16-bit material, |k| >= 2^14
+//   M  bnd < 2^23:                v_mad_i32_i24(k, v, 2^14), >> 15, subtraction: 3 per term (4.9); the low 32 bits of the 48-bit
+//      product are the wrapped product, so this form needs no statement about wrapping
+//      (measured and dropped: v_mul_lo_u32(2k, v), + 2^15, SDWA subtraction for wide operands, 4.8 -- whenever it applies, H does)
+//   W  otherwise:                 v_mul_lo_u32, + 2^14, >> 15, subtraction: 4 per term (6.4), the reference as it stands
+// Nothing here is approximate: where the bound holds the forms are the same function of (k, v) as W, and where it does not
+// hold W runs.  F[i] = f[n0 + i], B[i] = b[n0 + i - 1] (the backward error one sample late, as the stage wants it): a stage
+// walks i downwards and writes the new backward error of sample n0 + i into B[i + 1], whose old value the step before has
+// used up, so nothing is moved; B[0] arrives from the previous lane's B[16] by one DPP wave shift.  A result is never read
+// by the instruction right behind its producer (two terms are in flight), so the blocks need no wait states.  The two
+// products live in v[60:63] (inline asm cannot name the high half of a 64-bit operand).
 #define LAT_TILE_WORDS 1104         // 1025 samples + one pad word per 16, rounded up
 __device__ __forceinline__ uint32_t lat_pad(uint32_t p) { return p + (p >> 4); }
+
+#define LAT_HI " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+#define LAT_SHIFT_IN "v_mov_b32_dpp %[B0], %[B16] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+// one sample of a full stage: B[j] = B[i] - R(k, F[i]), F[i] -= R(k, B[i])      (j = i + 1)
+#define LAT_W(i, j) "v_mul_lo_u32 v60, %[k], %[F" #i "]\n v_mul_lo_u32 v62, %[k], %[B" #i "]\n v_add_u32 v60, 0x4000, v60\n v_add_u32 v62, 0x4000, v62\n" \
+                    "v_ashrrev_i32 v60, 15, v60\n v_ashrrev_i32 v62, 15, v62\n v_sub_u32 %[B" #j "], %[B" #i "], v60\n v_sub_u32 %[F" #i "], %[F" #i "], v62\n"
+#define LAT_M(i, j) "v_mad_i32_i24 v60, %[k], %[F" #i "], %[c]\n v_mad_i32_i24 v62, %[k], %[B" #i "], %[c]\n v_ashrrev_i32 v60, 15, v60\n v_ashrrev_i32 v62, 15, v62\n" \
+                    "v_sub_u32 %[B" #j "], %[B" #i "], v60\n v_sub_u32 %[F" #i "], %[F" #i "], v62\n"
+#define LAT_S(i, j) "v_mad_i32_i24 v60, %[k2], %[F" #i "], %[c2]\n v_mad_i32_i24 v62, %[k2], %[B" #i "], %[c2]\n" \
+                    "v_sub_u32_sdwa %[B" #j "], %[B" #i "], sext(v60)" LAT_HI "v_sub_u32_sdwa %[F" #i "], %[F" #i "], sext(v62)" LAT_HI
+#define LAT_H(i, j) "v_mad_i64_i32 v[60:61], vcc, %[k17], %[F" #i "], %[c31]\n v_mad_i64_i32 v[62:63], vcc, %[k17], %[B" #i "], %[c31]\n" \
+                    "v_sub_u32 %[B" #j "], %[B" #i "], v61\n v_sub_u32 %[F" #i "], %[F" #i "], v63\n"
+// two samples of the LAST stage, whose backward error has no reader: F[i] -= R(k, B[i]), F[j] -= R(k, B[j])
+#define LAT_W1(i, j) "v_mul_lo_u32 v60, %[k], %[B" #i "]\n v_mul_lo_u32 v62, %[k], %[B" #j "]\n v_add_u32 v60, 0x4000, v60\n v_add_u32 v62, 0x4000, v62\n" \
+                     "v_ashrrev_i32 v60, 15, v60\n v_ashrrev_i32 v62, 15, v62\n v_sub_u32 %[F" #i "], %[F" #i "], v60\n v_sub_u32 %[F" #j "], %[F" #j "], v62\n"
+#define LAT_M1(i, j) "v_mad_i32_i24 v60, %[k], %[B" #i "], %[c]\n v_mad_i32_i24 v62, %[k], %[B" #j "], %[c]\n v_ashrrev_i32 v60, 15, v60\n v_ashrrev_i32 v62, 15, v62\n" \
+                     "v_sub_u32 %[F" #i "], %[F" #i "], v60\n v_sub_u32 %[F" #j "], %[F" #j "], v62\n"
+#define LAT_S1(i, j) "v_mad_i32_i24 v60, %[k2], %[B" #i "], %[c2]\n v_mad_i32_i24 v62, %[k2], %[B" #j "], %[c2]\n" \
+                     "v_sub_u32_sdwa %[F" #i "], %[F" #i "], sext(v60)" LAT_HI "v_sub_u32_sdwa %[F" #j "], %[F" #j "], sext(v62)" LAT_HI
+#define LAT_H1(i, j) "v_mad_i64_i32 v[60:61], vcc, %[k17], %[B" #i "], %[c31]\n v_mad_i64_i32 v[62:63], vcc, %[k17], %[B" #j "], %[c31]\n" \
+                     "v_sub_u32 %[F" #i "], %[F" #i "], v61\n v_sub_u32 %[F" #j "], %[F" #j "], v63\n"
+#define LAT_FULL(S) S(15, 16) S(14, 15) S(13, 14) S(12, 13) S(11, 12) S(10, 11) S(9, 10) S(8, 9) S(7, 8) S(6, 7) S(5, 6) S(4, 5) S(3, 4) S(2, 3) S(1, 2) S(0, 1)
+#define LAT_HALF(S) S(15, 14) S(13, 12) S(11, 10) S(9, 8) S(7, 6) S(5, 4) S(3, 2) S(1, 0)
+// ONE asm statement per stage, the form chosen by scalar branches inside it: with one statement per form the register
+// allocator gave each its own assignment of the 33 state registers and moved (and spilled) them in front of every stage
+#define LAT_DISPATCH(W, M, S, H) LAT_SHIFT_IN \
+  "s_cmp_eq_u32 %[form], 3\n s_cbranch_scc0 .Llat_nh%=\n" \
+  H "s_branch .Llat_end%=\n" \
+  ".Llat_nh%=:\n s_cmp_eq_u32 %[form], 2\n s_cbranch_scc0 .Llat_wm%=\n" \
+  S "s_branch .Llat_end%=\n" \
+  ".Llat_wm%=:\n s_cmp_eq_u32 %[form], 1\n s_cbranch_scc1 .Llat_m%=\n" \
+  W "s_branch .Llat_end%=\n" \
+  ".Llat_m%=:\n" M \
+  ".Llat_end%=:\n"
+#define LAT_REGS [F0] "+v"(F[0]), [F1] "+v"(F[1]), [F2] "+v"(F[2]), [F3] "+v"(F[3]), [F4] "+v"(F[4]), [F5] "+v"(F[5]), [F6] "+v"(F[6]), [F7] "+v"(F[7]), \
+                 [F8] "+v"(F[8]), [F9] "+v"(F[9]), [F10] "+v"(F[10]), [F11] "+v"(F[11]), [F12] "+v"(F[12]), [F13] "+v"(F[13]), [F14] "+v"(F[14]), [F15] "+v"(F[15]), \
+                 [B0] "+v"(B[0]), [B1] "+v"(B[1]), [B2] "+v"(B[2]), [B3] "+v"(B[3]), [B4] "+v"(B[4]), [B5] "+v"(B[5]), [B6] "+v"(B[6]), [B7] "+v"(B[7]), [B8] "+v"(B[8]), \
+                 [B9] "+v"(B[9]), [B10] "+v"(B[10]), [B11] "+v"(B[11]), [B12] "+v"(B[12]), [B13] "+v"(B[13]), [B14] "+v"(B[14]), [B15] "+v"(B[15]), [B16] "+v"(B[16])
+#define LAT_INS [k] "v"(k), [k2] "v"(k * 2), [k17] "v"((int32_t)((uint32_t)k << 17)), [c] "s"(0x4000), [c2] "s"(0x8000), [c31] "s"(0x80000000ll), [form] "s"(form)
+#define LAT_CLOBBERS "scc", "vcc", "v60", "v61", "v62", "v63"
+static_assert(LAT_T == 16, "the stage blocks are written for 16 samples per lane");
+
+// the form of one stage and the bound behind it (all wave-uniform: scalar registers)
+enum { LAT_FORM_W = 0, LAT_FORM_M = 1, LAT_FORM_S = 2, LAT_FORM_H = 3 };
+__device__ __forceinline__ int lat_pick_form(int32_t k, uint32_t& bnd, bool plain)
+{
+  // T = |k| bnd + 2^14 >= |k v + 2^14| for every operand this wave holds; kept as (hi, lo) of the 64-bit product so that every
+  // comparison is a 32-bit scalar one
+  const uint32_t ak = (k < 0) ? (0u - (uint32_t)k) : (uint32_t)k;
+  const uint32_t lo = ak * bnd, hi = __umulhi(ak, bnd);
+  const bool t31 = (hi == 0u) && (lo < 0x80000000u - 16384u);        // T < 2^31: the reference's own product does not wrap
+  const bool t30 = (hi == 0u) && (lo < 0x40000000u - 16384u);        // T < 2^30: 2 (k v + 2^14) is an int32
+  const bool high = t31 && (ak < (1u << 14));                        // k << 17 is an int32
+  const bool v24 = (bnd < (1u << 23)) && (ak < (1u << 22));          // v, k and 2k are 24-bit signed values
+  const int form = plain ? LAT_FORM_W : high ? LAT_FORM_H : !v24 ? LAT_FORM_W : t30 ? LAT_FORM_S : LAT_FORM_M;
+  // |R| <= (|k v| + 2^14) >> 15 rounded up where nothing wraps; a wrapped product still gives |R| <= 2^16
+  const uint32_t grow = t31 ? (((lo + 16384u) >> 15) + 1u) : 65537u;
+  const uint32_t nb = bnd + grow;                                     // bnd <= 2^31, grow <= 2^16 + 1: no overflow
+  bnd = (nb < (1u << 31)) ? nb : (1u << 31);
+  return __builtin_amdgcn_readfirstlane(form);
+}
 
 __device__ __forceinline__ void lattice_chunk_wave_lds(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
                                                        uint64_t blk_off, uint32_t blk_len, uint32_t chunk_start, uint32_t count,
                                                        uint32_t channel, uint32_t int_shift, const int32_t* __restrict__ kc,
-                                                       int32_t* __restrict__ residual, uint32_t lane, bool raw, int32_t* __restrict__ tile)
+                                                       int32_t* __restrict__ residual, uint32_t lane, bool raw, int32_t* __restrict__ tile,
+                                                       bool plain)
 {
   const uint32_t halo_lanes = (order + LAT_T - 1) / LAT_T;
-  const int64_t base = (int64_t)chunk_start - (int64_t)halo_lanes * LAT_T;      // block-relative index of lane 0's first sample
-  // tile slot e holds sample base - 1 + e (e = 0 .. 1024), zero outside the block
+  const int32_t base = (int32_t)chunk_start - (int32_t)(halo_lanes * LAT_T);    // block-relative index of lane 0's first sample (blocks are < 2^31 samples)
+  // tile slot e holds sample base - 1 + e (e = 0 .. 1024), zero outside the block.  Every load is requested before the first
+  // one is looked at (the first version's seventeen guarded loads each waited for its own data), from a clamped in-block
+  // address, and a sample outside the block is zeroed afterwards: no branches, offsets of 32 bits from a scalar base
+  {
+    const int32_t* __restrict__ src = pcm + (ms ? (uint64_t)0 : (uint64_t)channel * stride) + blk_off;
+    int32_t va[17];
+    bool ok[17];
+    uint32_t pc[17];
 #pragma unroll
-  for (int j = 0; j < 17; j++) {
-    const uint32_t e = (uint32_t)j * 64u + lane;
-    if (e <= (uint32_t)(SLA_WAVE * LAT_T)) {
-      const int64_t p = base - 1 + (int64_t)e;
-      int32_t v = 0;
-      if (p >= 0 && p < (int64_t)blk_len) { v = load_int(pcm, stride, ms, channel, blk_off + (uint64_t)p, int_shift); }
-      tile[lat_pad(e)] = v;
+    for (int j = 0; j < 17; j++) {
+      const uint32_t e = (uint32_t)j * 64u + lane;
+      const uint32_t p = (uint32_t)(base - 1) + e;                          // a sample before the block wraps to a huge index
+      ok[j] = (p < blk_len) && (e <= (uint32_t)(SLA_WAVE * LAT_T));
+      pc[j] = ok[j] ? p : 0u;
+    }
+    if (!ms) {
+#pragma unroll
+      for (int j = 0; j < 17; j++) { va[j] = src[pc[j]]; }
+#pragma unroll
+      for (int j = 0; j < 17; j++) { va[j] = ok[j] ? (va[j] >> int_shift) : 0; }
+    } else {
+      // mid = (L+R)>>1 (arithmetic, wrapping sum), side = L-R      src/SLAUtility.c:403-411
+      const int32_t* __restrict__ srcr = src + stride;
+      int32_t vr[17];
+#pragma unroll
+      for (int j = 0; j < 17; j++) { va[j] = src[pc[j]]; vr[j] = srcr[pc[j]]; }
+#pragma unroll
+      for (int j = 0; j < 17; j++) {
+        const int32_t l = va[j] >> int_shift, r = vr[j] >> int_shift;
+        const int32_t v = (channel == 0) ? ((int32_t)((uint32_t)l + (uint32_t)r) >> 1) : (int32_t)((uint32_t)l - (uint32_t)r);
+        va[j] = ok[j] ? v : 0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 17; j++) {
+      const uint32_t e = (uint32_t)j * 64u + lane;
+      if (j < 16 || e <= (uint32_t)(SLA_WAVE * LAT_T)) { tile[lat_pad(e)] = va[j]; }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  int32_t f[LAT_T], b[LAT_T];
+  int32_t F[LAT_T], B[LAT_T + 1];
+  int32_t hi = 0, lo = 0;
   {
     int32_t prev = tile[lat_pad(lane * LAT_T)];
 #pragma unroll
@@ -548,50 +663,44 @@ __device__ __forceinline__ void lattice_chunk_wave_lds(const int32_t* __restrict
       const int32_t cur = tile[lat_pad(lane * LAT_T + 1 + (uint32_t)i)];
       // pre-emphasis y[n] = x[n] - ((x[n-1]*31)>>5); raw: the caller's samples are the lattice input as they are
       const int32_t y = raw ? cur : (int32_t)((uint32_t)cur - (uint32_t)((int32_t)((uint32_t)prev * 31u) >> 5));
-      f[i] = y; b[i] = y;
+      F[i] = y; B[i + 1] = y;
+      hi = max(hi, y); lo = min(lo, y);
       prev = cur;
     }
   }
+  B[0] = 0;
+  // bnd >= |y| of every sample this wave holds (its halo included): max(hi, -lo) as unsigned covers INT32_MIN
+  uint32_t bnd = (uint32_t)__builtin_amdgcn_readfirstlane((int)umax_wave(max((uint32_t)hi, 0u - (uint32_t)lo)));
+  int32_t knext = kc[1];
   for (uint32_t m = 1; m < order; m++) {
-    const int32_t k = kc[m];                       // wave-uniform -> scalar load
-    int32_t carry = __shfl_up(b[LAT_T - 1], 1);    // b_{m-1} of the sample just before this lane's run
-    if (lane == 0) { carry = 0; }
-#pragma unroll
-    for (int i = LAT_T - 1; i >= 1; i--) {
-      int32_t nf = (int32_t)((uint32_t)f[i] - (uint32_t)lat_term(k, b[i - 1]));
-      int32_t nb = (int32_t)((uint32_t)b[i - 1] - (uint32_t)lat_term(k, f[i]));
-      f[i] = nf; b[i] = nb;
-    }
-    {
-      int32_t nf = (int32_t)((uint32_t)f[0] - (uint32_t)lat_term(k, carry));
-      int32_t nb = (int32_t)((uint32_t)carry - (uint32_t)lat_term(k, f[0]));
-      f[0] = nf; b[0] = nb;
-    }
+    const int32_t k = __builtin_amdgcn_readfirstlane(knext);
+    knext = kc[m + 1];                               // (the last full stage fetches the last stage's coefficient)
+    const int form = lat_pick_form(k, bnd, plain);
+    asm volatile(LAT_DISPATCH(LAT_FULL(LAT_W), LAT_FULL(LAT_M), LAT_FULL(LAT_S), LAT_FULL(LAT_H)) : LAT_REGS : LAT_INS : LAT_CLOBBERS);
   }
   if (order >= 1) {
     // the last stage: only the forward error leaves the lattice, its backward error has no reader (half the stage's work)
-    const int32_t k = kc[order];
-    int32_t carry = __shfl_up(b[LAT_T - 1], 1);
-    if (lane == 0) { carry = 0; }
-#pragma unroll
-    for (int i = LAT_T - 1; i >= 1; i--) { f[i] = (int32_t)((uint32_t)f[i] - (uint32_t)lat_term(k, b[i - 1])); }
-    f[0] = (int32_t)((uint32_t)f[0] - (uint32_t)lat_term(k, carry));
+    const int32_t k = __builtin_amdgcn_readfirstlane(knext);
+    const int form = lat_pick_form(k, bnd, plain);
+    asm volatile(LAT_DISPATCH(LAT_HALF(LAT_W1), LAT_HALF(LAT_M1), LAT_HALF(LAT_S1), LAT_HALF(LAT_H1)) : LAT_REGS : LAT_INS : LAT_CLOBBERS);
   }
   // results through the tile (slot e = sample base + e now), stored 64 consecutive samples at a time
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-  for (int i = 0; i < LAT_T; i++) { tile[lat_pad(lane * LAT_T + (uint32_t)i)] = f[i]; }
+  for (int i = 0; i < LAT_T; i++) { tile[lat_pad(lane * LAT_T + (uint32_t)i)] = F[i]; }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  int32_t* dst = residual + (uint64_t)channel * stride + blk_off;
+  int32_t* __restrict__ dst = residual + (uint64_t)channel * stride + blk_off + chunk_start;
+  int32_t out[LAT_T];
+#pragma unroll
+  for (int j = 0; j < LAT_T; j++) { out[j] = tile[lat_pad((uint32_t)j * 64u + lane)]; }
 #pragma unroll
   for (int j = 0; j < LAT_T; j++) {
-    const uint32_t e = (uint32_t)j * 64u + lane;
-    const int64_t p = base + (int64_t)e;
-    if (p >= (int64_t)chunk_start && p < (int64_t)chunk_start + count) { dst[p] = tile[lat_pad(e)]; }
+    const uint32_t q = (uint32_t)j * 64u + lane - halo_lanes * LAT_T;       // chunk-relative index; the halo wraps to a huge one
+    if (q < count) { dst[q] = out[j]; }
   }
 }
 
@@ -2113,33 +2222,35 @@ void k_expand_write(const sla_hip_superframe* __restrict__ sf, uint32_t num_sf, 
 // (the lattice is feed-forward: output n depends on inputs n-order..n only), so chunks are
 // independent and need no LDS and no barrier.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 8)
 void k_lattice(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
                const sla_hip_lattice_chunk* __restrict__ chunks, uint32_t num_chunks,
-               const int32_t* __restrict__ kint, int32_t* __restrict__ residual, unsigned long long* span, uint32_t raw)
+               const int32_t* __restrict__ kint, int32_t* __restrict__ residual, unsigned long long* span, uint32_t flags)
 {
   __shared__ int32_t s_tile[4][LAT_TILE_WORDS];
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t cid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform: descriptors and coefficients by scalar loads
+  const uint32_t cid = blockIdx.x * 4 + wv;
   if (cid >= num_chunks) { return; }
   span_begin(span);
   const sla_hip_lattice_chunk ck = chunks[cid];
   lattice_chunk_wave_lds(pcm, stride, ms, order, ck.blk_off, ck.blk_len, ck.chunk_start, ck.count, ck.channel, ck.int_shift,
-                         kint + (uint64_t)ck.slot * (order + 1), residual, lane, raw != 0, s_tile[threadIdx.x >> 6]);
+                         kint + (uint64_t)ck.slot * (order + 1), residual, lane, (flags & 1u) != 0, s_tile[wv], (flags & 2u) != 0);
   span_end(span);
 }
 
 // The same lattice waves, derived from the block descriptors themselves: wave = (group, chunk index), `cpg` waves reserved
 // per group (enough for the longest block), the ones past a block's end return at once.  Saves the host a descriptor per
 // ~900 samples (4.5 MB for ten minutes of stereo: building and uploading them took longer than k_lpc_blocks runs).
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 8)
 void k_lattice_groups(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t ms, uint32_t order,
                       const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, uint32_t cpg,
-                      const int32_t* __restrict__ kint, int32_t* __restrict__ residual, unsigned long long* span)
+                      const int32_t* __restrict__ kint, int32_t* __restrict__ residual, unsigned long long* span, uint32_t flags)
 {
   __shared__ int32_t s_tile[4][LAT_TILE_WORDS];
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t w = blockIdx.x * 4 + wv;
   const uint32_t gi = w / cpg, c = w - gi * cpg;
   if (gi >= num_groups) { return; }
   span_begin(span);
@@ -2148,7 +2259,7 @@ void k_lattice_groups(const int32_t* __restrict__ pcm, uint64_t stride, uint32_t
   const uint32_t at = c * per;
   if (at < g.num_samples) {
     lattice_chunk_wave_lds(pcm, stride, ms, order, g.pcm_off, g.num_samples, at, (g.num_samples - at < per) ? (g.num_samples - at) : per,
-                           g.channel, g.int_shift, kint + (uint64_t)g.slot_first * (order + 1), residual, lane, false, s_tile[threadIdx.x >> 6]);
+                           g.channel, g.int_shift, kint + (uint64_t)g.slot_first * (order + 1), residual, lane, false, s_tile[wv], (flags & 2u) != 0);
   }
   span_end(span);
 }
@@ -4015,7 +4126,7 @@ extern "C" int sla_hip_launch_lattice(const int32_t* d_pcm, uint64_t plane_strid
   if (order < 1 || order > 255 || (order + LAT_T - 1) / LAT_T >= 32) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (num_chunks == 0) { return 0; }
   hipLaunchKernelGGL(k_lattice, dim3((num_chunks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_pcm, plane_stride,
-                     mid_side, order, d_chunks, num_chunks, d_kint, d_residual, take_span(), 0u);
+                     mid_side, order, d_chunks, num_chunks, d_kint, d_residual, take_span(), tuning().lattice_plain ? 2u : 0u);
   return hip_rc(hipGetLastError());
 }
 
@@ -4031,7 +4142,7 @@ extern "C" int sla_hip_launch_lattice_groups(const int32_t* d_pcm, uint64_t plan
   const uint64_t waves = (uint64_t)num_groups * cpg;
   if (waves > 0x7FFFFFFFull) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
   hipLaunchKernelGGL(k_lattice_groups, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_pcm, plane_stride,
-                     mid_side, order, d_groups, num_groups, cpg, d_kint, d_residual, take_span());
+                     mid_side, order, d_groups, num_groups, cpg, d_kint, d_residual, take_span(), tuning().lattice_plain ? 2u : 0u);
   return hip_rc(hipGetLastError());
 }
 
@@ -4048,7 +4159,7 @@ extern "C" int sla_hip_launch_lattice_raw(const int32_t* d_samples, uint64_t pla
   if (order < 1 || order > 255 || (order + LAT_T - 1) / LAT_T >= 32) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (num_chunks == 0) { return 0; }
   hipLaunchKernelGGL(k_lattice, dim3((num_chunks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_samples, plane_stride,
-                     0u, order, d_chunks, num_chunks, d_kint, d_residual, take_span(), 1u);
+                     0u, order, d_chunks, num_chunks, d_kint, d_residual, take_span(), 1u | (tuning().lattice_plain ? 2u : 0u));
   return hip_rc(hipGetLastError());
 }
 
