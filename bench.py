@@ -234,7 +234,9 @@ def cpu_baseline(S, cfg, budget_s, all_cores_seconds):
 def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=None):
     from sla_amd import dist as sdist
     dist = None
-    if world > 1:
+    # the collectives of the N > 1 path run at N = 1 too under --force-collectives: the same calls on a one-rank communicator
+    dist_on = (world > 1) or (args.force_collectives and primary)
+    if dist_on:
         import torch.distributed as dist
     nch, bits, rate, seconds, order, ltm, lms, ms, win, maxb, cap = CONFIGS[cfg]
     if primary and args.seconds is not None:
@@ -283,11 +285,11 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
 
     # N > 1 over RCCL: the all-gather of one step's residual planes travels while the next step is analysed into
     # a second set of planes (two sets take turns), so the collective over xGMI and the kernels overlap
-    overlap = (world > 1 and args.backend == "nccl" and not args.sync_gather)
+    overlap = (dist_on and args.backend == "nccl" and not args.sync_gather)
     nbuf = 2 if overlap else 1
     d_lat = [torch.zeros((nch, stride), dtype=torch.int32, device="cuda") for _ in range(nbuf)]
     d_fin = [torch.zeros((nch, stride), dtype=torch.int32, device="cuda") for _ in range(nbuf)]
-    gathered = [torch.empty((world, nch, stride), dtype=torch.int32, device="cuda") for _ in range(nbuf)] if world > 1 else None
+    gathered = [torch.empty((world, nch, stride), dtype=torch.int32, device="cuda") for _ in range(nbuf)] if dist_on else None
     works = [None] * nbuf
 
     enc = sla_amd.Encoder(*cap)
@@ -313,7 +315,7 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
             enc.bind_residual_planes(d_lat[b].data_ptr(), d_fin[b].data_ptr(), stride)
         if batch is not None:
             t, _ = enc.analyze_batch_device(d_pcm.data_ptr(), stride, batch["span"], batch["starts"], batch["lens"])
-        elif world == 1:
+        elif not dist_on:
             t = enc.analyze_device(d_pcm.data_ptr(), stride, n_file)
         else:
             # one file over the ranks (include/sla_hip.h): scan, exchange, bounds, the hot path on the own range
@@ -330,7 +332,7 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
             state["own"], state["file_or"] = (lo, hi), file_or
             t = enc.shard_analyze(d_pcm.data_ptr() + 4 * (lo - base), stride, hi - lo, file_or, no_silence=(mask is None))
         span_ms[:] += np.array(enc.last_kernel_ms())
-        if world > 1:
+        if dist_on:
             if overlap:
                 works[b] = sdist.all_gather_planes(d_fin[b], gathered[b], async_op=True)[1]
             elif args.backend == "nccl":
@@ -356,7 +358,7 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
     for b in range(nbuf):
         settle(b)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     kernel_ms = np.zeros(12)
     span_ms[:] = 0.0
@@ -369,16 +371,16 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
     for b in range(nbuf):
         settle(b)                                             # every collective of the timed steps has landed
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
-    if world > 1:
+    if dist_on:
         elapsed = sdist.max_over_ranks(elapsed, dev_comm)
     kernel_ms /= max(args.steps, 1)
     span_ms /= max(args.steps, 1)
 
-    if batch is not None and world > 1:
+    if batch is not None and dist_on:
         n_all = int(sdist.sum_over_ranks(float(n_own), dev_comm))      # samples per channel all ranks analysed per step
     else:
         n_all = n_file if batch is None else n_own
@@ -404,7 +406,8 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
                    "samples_per_step_all_gpus": int(n_all) * nch,
                    "parallelism": ("super-frames of one file sharded over %d GPUs: OR all-reduce + mask all-gather, then one RCCL all-gather "
                                    "of the residual planes%s" % (world, " overlapped with the next step" if overlap else ""))
-                                  if world > 1 else "1 GPU"},
+                                  if world > 1 else ("1 GPU, the collectives of the N > 1 path on a one-rank communicator: count exchange + all-gather of the residual planes%s"
+                                                     % (" overlapped with the next step" if overlap else "") if dist_on else "1 GPU")},
     }
     if rank != 0:
         enc.close()
@@ -447,15 +450,45 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
                    "k_ltm_acf": (2.0 * 10.0 * (npts_fft / 2) * lg + 28.0 * npts_fft) / float(maxb)}
     sc_step = float(n_last) * nch
     path_flop = sum(flop_per_sc.values()) * sc_step
+    # ---- integer-VALU bound of the integer kernels ----------------------------------------------
+    # k_lattice_groups: 2 terms R(k v) per sample and stage; a stage runs in the form its operand bound allows (sla_kernels.hip):
+    # 24-bit material with its 8-bit coefficients certifies the two-instruction form H (high dword of v_mad_i64_i32 + v_sub_u32)
+    # in every stage, 16-bit material H or S (v_mad_i32_i24 + SDWA subtract).  tests/tools/ubench_lattice.hip measured, at eight
+    # waves per SIMD on all 256 CUs, the sustained rate of each form on registers alone (profiles/r4_ubench_lattice_8w.txt):
+    # H 18.48, S 17.90, round 3's four-instruction form 9.61 T terms/s; plain v_add_u32 61.3 T lane-ops/s = 0.78 of the
+    # nominal 78.6 T (256 CU x 4 SIMD x 32 lanes x 2.4 GHz: the clock under load is ~1.9 GHz), so a term of form H costs 3.3 add slots.
+    # int_valu_frac = terms x add-slots per term / launch time / 78.6 T; int_valu_sustained_frac = terms/s / the ubench's rate.
+    # k_tailk: ~33 wave instructions per sample for 16 jobs (K = 2; many jobs) or ~27 for 8 (K = 1): lane-ops = that x 64 lanes.
+    VALU_PEAK = 78.6e12
+    int_model = {}
+    terms = sc_step * order * 2.0 - sc_step                       # the last stage has one term per sample
+    slots_per_term, sustained = (3.32, 18.48e12) if bits > 16 else (3.4, 17.9e12)
+    int_model["k_lattice"] = {"lane_ops": terms * slots_per_term, "sustained_units": terms, "sustained_rate": sustained,
+                              "what": "2 terms (k v + 2^14) >> 15 per sample and stage, %.2f add-slots per term (form %s)" % (slots_per_term, "H" if bits > 16 else "H / S")}
+    many = (n_last * nch // maxb) * lms // 64 > 2048              # (the launcher's switch: two taps per lane beyond 2048 one-tap waves)
+    per_sample_job = (33.0 / 16.0) if many else (27.0 / 8.0)
+    int_model["k_tail"] = {"lane_ops": sc_step * per_sample_job * 64.0, "sustained_units": None, "sustained_rate": None,
+                           "what": "%.2f wave instructions per sample and job (K = %d taps per lane) x 64 lanes" % (per_sample_job, 2 if many else 1)}
     out["roofline"] = {"bound": "hbm", "kernel": {"k_tail": "k_tailk", "k_ltm_acf": "k_ltm_acf2", "k_lattice": "k_lattice_groups"}.get(dom, dom), "achieved": round(achieved, 2),
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                        "path_frac": round(sc_step * ALGO_BYTES_PER_SAMPLE / (elapsed / max(args.steps, 1)) / 1e9 / HBM_PEAK_GBS, 5),
                        "fp64_vector_frac": (round(flop_per_sc[dom] * sc_step / launches / (launch_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 5)
                                             if dom in flop_per_sc and launch_ms > 0 else None),
+                       "int_valu_frac": (round(int_model[dom]["lane_ops"] / launches / (launch_ms * 1e-3) / VALU_PEAK, 5)
+                                         if dom in int_model and launch_ms > 0 else None),
+                       "int_valu_sustained_frac": (round(int_model[dom]["sustained_units"] / launches / (launch_ms * 1e-3) / int_model[dom]["sustained_rate"], 5)
+                                                   if dom in int_model and int_model[dom]["sustained_rate"] and launch_ms > 0 else None),
+                       "int_valu_model": int_model[dom]["what"] if dom in int_model else None,
+                       "int_valu_frac_by_kernel": {{"k_tail": "k_tailk", "k_lattice": "k_lattice_groups"}[k]:
+                                                   round(v["lane_ops"] / max(kernels[k][1], 1) / (kernels[k][0] / max(kernels[k][1], 1) * 1e-3) / VALU_PEAK, 5)
+                                                   for k, v in int_model.items() if kernels[k][0] > 0},
                        "path_fp64_vector_frac": round(path_flop / (elapsed / max(args.steps, 1)) / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 5),
                        "fp64_flop_per_sample_channel": {k: round(v, 1) for k, v in flop_per_sc.items()},
                        "fp64_peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                       "secondary_note": "path_frac = 8 B x samples x channels of one step / ms_per_step / 8 TB/s; fp64_vector_frac = executed FP64 "
+                       "secondary_note": "int_valu_frac = integer lane-ops of the dominant kernel, each at its measured issue cost in v_add_u32 slots "
+                                         "(tests/tools/ubench_lattice.hip, profiles/r4_ubench_lattice_8w.txt) / launch time / 78.6 T lane-ops/s; int_valu_sustained_frac = "
+                                         "against what the same instruction mix sustains on registers alone; None for an FP64 kernel; "
+                                         "path_frac = 8 B x samples x channels of one step / ms_per_step / 8 TB/s; fp64_vector_frac = executed FP64 "
                                          "flop of the dominant kernel (model in fp64_flop_per_sample_channel; None for an integer kernel) / its "
                                          "launch time / 78.6 TFLOP/s; path_fp64_vector_frac = the FP64 flop of all stages / ms_per_step / 78.6 TFLOP/s",
                        "traffic": None, "kernel_ms": round(float(launch_ms), 4), "launches_per_step": launches,
@@ -526,7 +559,7 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
         m = min(frames * maxb, own_n)
         sub = np.ascontiguousarray(d_pcm[:, own_lo - base:own_lo - base + m].cpu().numpy())
         file_or = state["file_or"]
-        if world > 1:
+        if dist_on:
             ntz = (file_or & -file_or).bit_length() - 1 if file_or else 32
             lshift = bits - (32 - ntz) if file_or else 0
             ret, want = o.encode_range(p, sub, lshift)
@@ -597,7 +630,7 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
     #      on the guess that the file looks like the last one.  `value` is that warm, same-shape steady state (the contract's
     #      K steps after W warm-ups); beside it: the same steps with nothing kept (every step builds and uploads its tables and
     #      waits for its prepass, as files of varying length do) and the first call on the fresh handle (`cold_call_ms`)
-    if world == 1:
+    if world == 1 and not dist_on:
         ex = enc.last_expand()
         out["per_handle_shortcuts"] = {"analyses_served_from_kept_search_tables": int(ex[2]), "searches_launched_on_a_wrong_guess": int(ex[3]),
                                        "chunks_from_device_tables": int(ex[0]), "chunks": int(ex[1])}
@@ -760,6 +793,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
                     help="N > 1: weak = one file N times the configuration's length (per-GPU work fixed); strong = the "
                          "configuration's own length (C4: --total-clips) split over the N ranks")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N = 1: still bring up the process group and run the primary configuration through the N > 1 path (scan, count "
+                         "exchange, bounds, shard analyse, all-gather of the residual planes), so that the RCCL calls execute on a one-GPU box")
     ap.add_argument("--launch-check", action="store_true",
                     help="only bring the ranks up (process group of --backend, no GPU work) and print the line's launch fields")
     args = ap.parse_args()
@@ -807,14 +843,20 @@ def main():
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     dist = None
-    if world > 1:
+    dist_on = (world > 1) or args.force_collectives
+    if dist_on:
         import torch.distributed as dist
+        if world == 1:                    # --force-collectives without a launcher: a one-rank rendezvous of our own
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(args.backend)
 
-    ranks_seen = dist.get_world_size() if world > 1 else 1
+    ranks_seen = dist.get_world_size() if dist_on else 1
     res = run_config(torch, sla_amd, S, args.config, args, rank, world, True, cpu_results)
     if rank == 0:
         out = {"metric": "encode Msamples/s (LPC+residual path), verified bit-exact vs the oracle in this run",
@@ -828,6 +870,9 @@ def main():
                                  (res.get("cpu_baseline") or {}).get("value")]}
         out["summary"] = summary
         out.update(res)
+        if args.force_collectives:
+            out["collectives_forced"] = ("world %d: process group of backend %s, exchange_counts, shard bounds, shard_analyze and the (overlapped) "
+                                         "all-gather of the residual planes run exactly as for N > 1" % (world, args.backend))
         out["device"] = sla_amd.device_name()
         if want_others:
             others = {}
@@ -843,7 +888,7 @@ def main():
             out["other_configs"] = others
         out["summary_again"] = dict(summary)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -2938,12 +2938,33 @@ void k_tail1(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, 
 // ---------------------------------------------------------------------------------------------
 #define ACF_THREADS 512
 
-// LDS layout: complex slot c (re, im = 16 B, always moved as one b128 access) lives at slot c ^ S(c), where
-// S folds the higher nibbles of c into the low one.  Every access pattern of a power-of-two FFT is
-// "base + j * 2^s": without the fold all 16 lanes of an access group hit the same 4 banks (measured: 13
-// bank-conflict cycles per LDS instruction); with it the 16 lanes land on 16 different slots for s >= 4
-// and for the bit-reversed scatter.
-__device__ __forceinline__ uint32_t acf_sw(uint32_t c) { return c ^ (((c >> 4) ^ (c >> 8) ^ (c >> 12)) & 15u); }
+// LDS layout: complex slot c (re, im = 16 B, always moved as one b128 access) lives at slot c ^ S(c), S a GF(2)-linear map
+// of the bits 3.. of c onto the low nibble.  Every access pattern of a power-of-two FFT is "base + j * 2^s": without S all
+// lanes of an access group hit the same 4 banks (measured in round 1: 13 bank-conflict cycles per LDS instruction).
+// Round 3 folded the higher nibbles onto the low one, c ^ ((c >> 4 ^ c >> 8 ^ c >> 12) & 15): 2.0 - 2.2 conflict cycles
+// per LDS instruction were left (profiles/r3_sq_counters_*), and tests/tools/fft_lds_conflicts.py -- a model of every pass
+// of k_ltm_acf2 on gfx950's real access groups: a ds_read_b128 is served 16 lanes at a time, but the lanes are
+// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32), on 64 banks; a ds_write_b128 8 consecutive lanes at a time on 32 banks --
+// reproduces those numbers (2.17 at 4096 points, 1.95 at 8192) and says where they come from: every WRITE of the first pass
+// and of the inverse transform's first pass, every read at half-span 8, the bit-reversed scatter: all two-way.  The fold
+// cannot separate what differs in bit 3 of c on a write (8 slots = 3 bits).  The rows below (bit j of the nibble = parity of
+// (c >> 3) & ACF_SW_ROW<j>; hill-climbed in that script over the three transform sizes) leave 0.24 / 0.36 / 0.37 per
+// instruction (2048 / 4096 / 8192 points), all of it in the middle pass's descending run.  The map costs about twice the
+// instructions of the fold, and the kernel is bound by instruction issue, not by the LDS (the first build with these rows ran
+// 7 % SLOWER: profiles/r4_fft_swizzle_ab.txt): it pays only together with the middle pass computing it four times per thread
+// instead of four times per pair (acf2_middle).  S only reads bits >= 3 (bit 3 only into bits 0..2), so the map is a bijection, an index
+// below 8 is its own image, and S(a + b) = S(a) ^ S(b) when a and b share no bit -- what the passes use.
+#define ACF_SW_ROW0 718u
+#define ACF_SW_ROW1 485u
+#define ACF_SW_ROW2 129u
+#define ACF_SW_ROW3 76u
+static_assert((ACF_SW_ROW3 & 1u) == 0u, "bit 3 of the slot must not depend on itself");
+__device__ __forceinline__ constexpr uint32_t acf_sw(uint32_t c)
+{
+  const uint32_t hi = c >> 3;
+  return c ^ ((uint32_t)__builtin_popcount(hi & ACF_SW_ROW0) & 1u) ^ (((uint32_t)__builtin_popcount(hi & ACF_SW_ROW1) & 1u) << 1)
+           ^ (((uint32_t)__builtin_popcount(hi & ACF_SW_ROW2) & 1u) << 2) ^ (((uint32_t)__builtin_popcount(hi & ACF_SW_ROW3) & 1u) << 3);
+}
 
 // One radix-2 butterfly of the reference's four1 loop (src/SLAUtility.c:220-260): same products, same order.
 __device__ __forceinline__ void acf_bfly(double2& zi, double2& zq, double wr, double wi)
@@ -3265,9 +3286,13 @@ __device__ __forceinline__ void acf2_first_pass(double2* z, const int32_t* __res
     const uint32_t t = tid + it * THREADS;
     if (t >= ngroups) { break; }
     const uint32_t b = __brev(t) >> (32 - (L - R));
+    // Position P*b + m holds complex sample c = t + rev(m) * ngroups.  An odd m has rev(m) >= P/2, i.e. c >= npts/2: beyond any
+    // block (blk_len <= capacity = npts), always zero padding.  The first stage pairs (m, m + 1) under the twiddle (1, 0): with
+    // zq = +0 the reference's products and sums give tr = ti = +0 and both results equal zi bit for bit (an input is
+    // (double)int * 2^-31, never -0): the stage is a copy, and the odd positions are neither loaded nor multiplied.
     double2 v[P];
 #pragma unroll
-    for (uint32_t m = 0; m < P; m++) {
+    for (uint32_t m = 0; m < P; m += 2) {
       const uint32_t c = t + (__brev(m) >> (32 - R)) * ngroups;          // complex sample index of position P*b + m
       if (2 * c + 1 < n) {
         const i32x2_u w = *(const i32x2_u*)(src + 2 * c);
@@ -3275,9 +3300,19 @@ __device__ __forceinline__ void acf2_first_pass(double2* z, const int32_t* __res
       } else {
         v[m] = make_double2((2 * c < n) ? (double)src[2 * c] * scale : 0.0, 0.0);
       }
+      v[m + 1] = v[m];
+    }
+    if (n > (1u << L)) {
+      // (a caller of the launcher with blocks longer than half the transform: the odd positions hold samples; wave-uniform)
+#pragma unroll
+      for (uint32_t m = 1; m < P; m += 2) {
+        const uint32_t c = t + (__brev(m) >> (32 - R)) * ngroups;
+        v[m] = make_double2((2 * c < n) ? (double)src[2 * c] * scale : 0.0, (2 * c + 1 < n) ? (double)src[2 * c + 1] * scale : 0.0);
+        acf_bfly(v[m - 1], v[m], twr[0], twi[0]);
+      }
     }
 #pragma unroll
-    for (int st = 0; st < R; st++) {
+    for (int st = 1; st < R; st++) {
       constexpr uint32_t one = 1u;
       const uint32_t hs = one << st;
 #pragma unroll
@@ -3287,7 +3322,7 @@ __device__ __forceinline__ void acf2_first_pass(double2* z, const int32_t* __res
         acf_bfly(v[m], v[m + (1u << st)], twr[hs - 1 + k], twi[hs - 1 + k]);      // the same twiddle in every lane: scalar loads
       }
     }
-    const uint32_t a0 = acf_sw(P * b);                                    // (m < 16 is its own swizzle)
+    const uint32_t a0 = acf_sw(P * b);                                    // (m < 8 is its own swizzle)
 #pragma unroll
     for (uint32_t m = 0; m < P; m++) { z[a0 ^ m] = v[m]; }
   }
@@ -3383,26 +3418,36 @@ __device__ __forceinline__ void acf2_recombine(double2& A, double2& B, double c2
 template <int L, int THREADS>
 __device__ __forceinline__ void acf2_middle(double2* z, __amdgpu_buffer_rsrc_t tw2)
 {
-  constexpr uint32_t npts = 1u << L, pairs = (npts >> 1) - 1, K = (pairs + THREADS - 1) / THREADS;
+  // Thread tid takes the pairs (A = slot c, B = slot npts - c), c = tid + k THREADS in 1 .. npts/2 - 1 (c = 0: the DC / Nyquist
+  // slot and the middle slot no pair touches, thread 0).  The swizzle is linear over GF(2) and tid, k THREADS share no bit:
+  //   slot c            = tid ^ (k THREADS)                       -> S(tid) ^ literal
+  //   slot npts - c     = u ^ ((Q - 1 - k) THREADS), u = THREADS - tid, Q = npts / THREADS   (tid = 0: (Q - k) THREADS, u = 0)
+  // and the bit-reversed places of the scatter likewise (bit reversal is linear too): four swizzles per thread at run time
+  // instead of four per pair (round 3 took c = tid + 1 + k THREADS, whose carry defeats this; its run also started one slot
+  // off the 16-slot grid: two-way conflicts on every read of A).
+  constexpr uint32_t npts = 1u << L, half = npts >> 1, K = half / THREADS, Q = npts / THREADS;
+  static_assert(half % THREADS == 0 && K >= 1, "pairs per thread");
   double2 A[K], B[K];
   uint32_t tid = threadIdx.x;                                               // (opaque per phase, as in acf2_pass)
   asm volatile("" : "+v"(tid));
+  const uint32_t u = (THREADS - tid) & (THREADS - 1u);
+  const bool t0 = (tid == 0u);
+  const uint32_t sa = acf_sw(tid), sb = acf_sw(u);
 #pragma unroll
   for (uint32_t k = 0; k < K; k++) {
-    const uint32_t i = 2 + tid + k * THREADS;
-    if (i <= (npts >> 1)) {
-      A[k] = z[acf_sw(i - 1)]; B[k] = z[acf_sw(npts - (i - 1))];
+    if (k > 0 || !t0) {
+      A[k] = z[sa ^ acf_sw(k * THREADS)];
+      B[k] = z[sb ^ (t0 ? acf_sw((Q - k) * THREADS) : acf_sw((Q - 1u - k) * THREADS))];
     }
   }
   double2 dc = make_double2(0.0, 0.0), mid = make_double2(0.0, 0.0);
-  if (threadIdx.x == 0) { dc = z[0]; mid = z[acf_sw(npts >> 1)]; }
+  if (threadIdx.x == 0) { dc = z[0]; mid = z[acf_sw(half)]; }
 #pragma unroll
   for (uint32_t k = 0; k < K; k++) {
-    const uint32_t i = 2 + tid + k * THREADS;
-    if (i <= (npts >> 1)) {
-      // recombination twiddles: pairs [2 npts, 2 npts + npts/2) forward, the next npts/2 inverse
-      const double2 wf = acf2_tw(tw2, (i - 2) << 4, (2u * npts) << 4);
-      const double2 wi = acf2_tw(tw2, (i - 2) << 4, (2u * npts + (npts >> 1)) << 4);
+    if (k > 0 || !t0) {
+      // recombination twiddles: pairs [2 npts, 2 npts + npts/2) forward, the next npts/2 inverse; entry c - 1 of either
+      const double2 wf = acf2_tw(tw2, tid << 4, (2u * npts + k * THREADS - 1u) << 4);
+      const double2 wi = acf2_tw(tw2, tid << 4, (2u * npts + half + k * THREADS - 1u) << 4);
       acf2_recombine(A[k], B[k], -0.5, wf.x, wf.y);
       A[k] = make_double2(A[k].x * A[k].x + A[k].y * A[k].y, 0.0);       // power spectrum  src/SLAPredictor.c:844-851
       B[k] = make_double2(B[k].x * B[k].x + B[k].y * B[k].y, 0.0);
@@ -3418,12 +3463,13 @@ __device__ __forceinline__ void acf2_middle(double2* z, __amdgpu_buffer_rsrc_t t
   }
   __syncthreads();                                                        // every read above is done: the slots may be overwritten
   asm volatile("" : "+v"(tid));
+  // rev_L(tid ^ k THREADS) = rev_L(tid) ^ rev_L(k THREADS)
+  const uint32_t ra = acf_sw(__brev(tid) >> (32 - L)), rb = acf_sw(__brev(u) >> (32 - L));
 #pragma unroll
   for (uint32_t k = 0; k < K; k++) {
-    const uint32_t i = 2 + tid + k * THREADS;
-    if (i <= (npts >> 1)) {
-      z[acf_sw(__brev(i - 1) >> (32 - L))] = A[k];
-      z[acf_sw(__brev(npts - (i - 1)) >> (32 - L))] = B[k];
+    if (k > 0 || !t0) {
+      z[ra ^ acf_sw(__brev(k * THREADS) >> (32 - L))] = A[k];
+      z[rb ^ (t0 ? acf_sw(__brev((Q - k) * THREADS) >> (32 - L)) : acf_sw(__brev((Q - 1u - k) * THREADS) >> (32 - L)))] = B[k];
     }
   }
   if (threadIdx.x == 0) { z[0] = dc; z[acf_sw(1)] = mid; }                // rev(0) = 0, rev(npts/2) = 1

@@ -131,6 +131,11 @@ def sharded_cases():
     b[:, 20000:23000] = 0
     b[:, 44000:47000] = 0
     out.append(("stereo24ms", b, S.make_params(2, 24, 48000, 32, 3, 8, 1, 1, 8192, cap=(2, 8192, 32, 3, 8))))
+    # BASELINE config 5's shape (8 channels, 24 bit, 96 kHz, order 48, 8192-sample blocks), the file's own length split over the
+    # ranks = bench.py --scaling strong: a cut that falls inside a super-frame, a silent stretch on one side of it
+    c = S.synth_pcm(8, 41000, 24, 96000, seed=7)
+    c[:, 26000:29000] = 0
+    out.append(("c5shape8ch", c, S.make_params(8, 24, 96000, 48, 3, 8, 0, 1, 8192, cap=(8, 8192, 48, 3, 8))))
     return out
 
 
