@@ -143,6 +143,9 @@ typedef struct sla_hip_tuning {
   uint32_t rice_lanes;          /* Rice parameter walk: 1 = one lane per job (k_rice_k), 2 = the two-lane pipeline (k_rice_k2), 0 = by the number of jobs */
   uint32_t lattice_plain;       /* 1: every lattice stage in the wrapping four-instruction form (round 3); 0 = the shortest form each stage's
                                    operand bound allows (same results: tests run both) */
+  uint32_t cert_audit;          /* N > 0: every N-th (block, channel) pair that sla_hip_launch_lpc_blocks_cert CERTIFIES is analysed by the
+                                   exact kernels as well, which compare codes, lattice coefficients and the RAW side with what the certified
+                                   run stored: d_cert_flag 4 = audited and equal, 5 = the certificate was wrong (the encoder fails the call) */
 } sla_hip_tuning;
 void sla_hip_use_tuning(const sla_hip_tuning* tuning);
 
@@ -184,7 +187,9 @@ int sla_hip_launch_lpc_blocks(const int32_t* d_pcm, uint64_t plane_stride, uint3
  * src/SLAEncoder.c:567-589) and the RAW decision (:553-565) cannot differ from the reference's although the doubles may
  * differ in their last bits; blocks that do not certify are appended to d_fallback_list (group indices, count in
  * *d_fallback_count) and redone by the exact chain kernels of sla_hip_launch_lpc before the call's work on `stream`
- * ends.  d_cert_flag[slot]: 0 = certified, 2 = exact.  safety >= 1 scales the certificate's bound (the encoder: 16).
+ * ends.  d_cert_flag[slot]: 0 = certified, 2 = exact (4 / 5: audited, see sla_hip_tuning.cert_audit).  safety >= 1 scales the
+ * certificate's bound (the encoder: 16).  The bound is a FIRST-ORDER perturbation bound of the Levinson-Durbin recursion times
+ * that factor, validated empirically -- not a proof; the audit is the standing check on it.
  * Orders above 52 are not covered (SLA_APIRESULT_EXCEED_HANDLE_CAPACITY): use sla_hip_launch_lpc. */
 int sla_hip_launch_lpc_blocks_cert(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
                                    const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
@@ -546,7 +551,8 @@ int sla_hip_get_trace(struct SLAEncoder* encoder, sla_hip_trace* trace);
  * windows over that limit, default 64; 0: no certificate, such windows are rerun as serial chains) [SLA_HIP_CERT],
  * "device_plan" (0: partitions decided on the host) [SLA_HIP_PLAN=host],
  * "block_cert" (0: every chosen block through the exact chain kernel; 1 = default: the certified route of
- * sla_hip_launch_lpc_blocks_cert) [SLA_HIP_BLOCK_CERT], "block_cert_safety" (default 16),
+ * sla_hip_launch_lpc_blocks_cert) [SLA_HIP_BLOCK_CERT], "block_cert_safety" (default 16), "cert_audit" (N > 0: every N-th
+ * certified pair is re-analysed by the exact kernels and compared, a difference fails the call; default 0),
  * "plan_margin" [SLA_HIP_PLAN_MARGIN], "lpc_blocks_chains" [SLA_HIP_LPC_BLOCKS=chains], "fuse_lattice"
  * [SLA_HIP_LATTICE=fused], "device_ltm" (0: long-term pitch + taps solved on the host threads from the downloaded
  * autocorrelations, one k_tail per pipeline chunk) [SLA_HIP_LTM=host], "single_tail" (0: one k_tail per pipeline chunk
@@ -581,6 +587,9 @@ int sla_hip_last_counters(const struct SLAEncoder* encoder, uint32_t* counters);
 /* 2 counters of the last analysis: 1 if the block stage took the certified route (sla_hip_launch_lpc_blocks_cert);
  * (block, channel) pairs its certificate handed to the exact chain kernels. */
 int sla_hip_last_block_cert(const struct SLAEncoder* encoder, uint32_t* counters);
+/* 2 counters of the last analysis under option "cert_audit": certified pairs the exact kernels re-analysed and found equal;
+ * pairs they found DIFFERENT (the analysis that saw one returned SLA_APIRESULT_NG). */
+int sla_hip_last_cert_audit(const struct SLAEncoder* encoder, uint32_t* counters);
 
 /* 4 counters: pipeline chunks of the last analysis whose block stage was launched from device-written tables
  * (sla_hip_launch_expand; option "device_expand"), its pipeline chunks in all; since the handle was created: the analyses

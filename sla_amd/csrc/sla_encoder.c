@@ -77,7 +77,8 @@ struct SLAEncoder {
   int      block_cert;              /* 1 (default): chosen blocks through the any-order autocorrelation where their codes and the RAW decision certify,
                                      * the exact chain kernel for the rest; 0: every block through the exact kernel */
   double   block_cert_safety;       /* safety factor on the first-order bound of that certificate (16) */
-  volatile int cert_broken;         /* a block flagged by the certificate was not redone (internal error) */
+  volatile int cert_broken;         /* a block flagged by the certificate was not redone (internal error), or an audited block differed */
+  volatile uint32_t audit_ok, audit_bad;   /* option cert_audit: certified pairs the exact kernels found equal / different (last analysis) */
   int      cert_now;                /* this run's block stage takes the certified route */
   int      prelaunch;               /* 1 (default): short files queue the certified block kernels with the searches, sized for the most groups
                                      * there can be and counting on the device (search_launch) */
@@ -1631,8 +1632,15 @@ static void raw_one(void* vctx, uint32_t rel)
     memcpy(e->kint + slot * O1, (const int32_t*)e->h_kint.ptr + slot * O1, sizeof(int32_t) * O1);
     e->bc[slot].rshift = ((const uint32_t*)e->h_rshift.ptr)[slot];
     /* certified route: 0 = certified doubles, 2 = redone by the exact kernels (1 would be a block the fallback missed) */
-    e->parcor_exact[slot] = (uint8_t)(e->cert_now ? (((const uint32_t*)e->h_cert_flag.ptr)[slot] == 2u) : 1u);
-    if (e->cert_now && ((const uint32_t*)e->h_cert_flag.ptr)[slot] == 1u) { e->cert_broken = 1; }
+    {
+      /* 4 / 5: an audited pair (option cert_audit): the exact kernels ran on it too -- their doubles are the ones stored -- and
+       * found the certified codes equal / different; 3 would be an audited pair the exact kernels never reached */
+      const uint32_t flag = e->cert_now ? ((const uint32_t*)e->h_cert_flag.ptr)[slot] : 2u;
+      e->parcor_exact[slot] = (uint8_t)(flag == 2u || flag == 4u);
+      if (flag == 1u || flag == 3u || (flag & 7u) == 3u || flag == 5u) { e->cert_broken = 1; }
+      if (flag == 4u) { __sync_fetch_and_add(&e->audit_ok, 1u); }
+      if (flag == 5u) { __sync_fetch_and_add(&e->audit_bad, 1u); }
+    }
     est = slai_code_length(o[0], blk->nsmpl, bps, o + 1, order);
     est = (8 * est) / bps;
     if (est >= SLAI_RAW_THRESHOLD) { blk->type = SLAI_BLK_RAW; break; }
@@ -1865,7 +1873,7 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   memset(&a, 0, sizeof(a));
   a.ev = e->ev + 2;
 
-  e->fallback_groups = 0; e->host_planned = 0; e->blocks_exact = 0; e->cert_broken = 0;
+  e->fallback_groups = 0; e->host_planned = 0; e->blocks_exact = 0; e->cert_broken = 0; e->audit_ok = 0; e->audit_bad = 0;
   e->expanded_chunks = 0;
   e->cert_now = (e->block_cert && !(e->fuse_lattice && e->encode_param.parcor_order <= 64) && !e->tune.lpc_blocks_chains
                  && sla_hip_search_exact_lags(e->encode_param.parcor_order) != 0);
@@ -1995,6 +2003,8 @@ static int run_pipeline(struct SLAEncoder* e, int preset_blocks)
   if (rc == 0 && e->cert_now) {
     const uint32_t* cnt = (const uint32_t*)e->h_cert_flag.ptr + (size_t)a.blocks_bound * C + 1;
     for (c = 0; c < a.nchunks; c++) { if (a.ck[c].bg_hi > a.ck[c].bg_lo) { e->blocks_exact += cnt[c]; } }
+    /* the list the exact kernels walked holds the uncertified pairs and the audited ones: report the former */
+    e->blocks_exact -= (e->audit_ok + e->audit_bad <= e->blocks_exact) ? (e->audit_ok + e->audit_bad) : e->blocks_exact;
     if (e->cert_broken) { rc = SLA_APIRESULT_NG; }
   }
   memset(e->kernel_ms, 0, sizeof(e->kernel_ms));
@@ -2062,6 +2072,7 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   else if (strcmp(name, "acf_classic") == 0)       { OPT_RANGE(0, 1); e->tune.acf_classic = (uint32_t)iv; }
   else if (strcmp(name, "rice_lanes") == 0)        { OPT_RANGE(0, 2); e->tune.rice_lanes = (uint32_t)iv; }
   else if (strcmp(name, "lattice_plain") == 0)     { OPT_RANGE(0, 1); e->tune.lattice_plain = (uint32_t)iv; }
+  else if (strcmp(name, "cert_audit") == 0)        { OPT_RANGE(0, 1 << 30); e->tune.cert_audit = (uint32_t)iv; }
   else if (strcmp(name, "tail_lanes") == 0)        { OPT_RANGE(0, 6); e->tune.tail_lanes = (uint32_t)iv; }
   else if (strcmp(name, "lpc_blocks_chains") == 0) { OPT_RANGE(0, 1); e->tune.lpc_blocks_chains = (uint32_t)iv; if (iv) { e->fuse_lattice = 0; } }
   /* the certification margins may only be widened: below the built-in values byte-identity is no longer guaranteed */
@@ -2296,6 +2307,13 @@ int sla_hip_last_block_cert(const struct SLAEncoder* e, uint32_t* counters)
 {
   if (e == NULL || counters == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   counters[0] = (uint32_t)e->cert_now; counters[1] = e->blocks_exact;
+  return 0;
+}
+
+int sla_hip_last_cert_audit(const struct SLAEncoder* e, uint32_t* counters)
+{
+  if (e == NULL || counters == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  counters[0] = e->audit_ok; counters[1] = e->audit_bad;
   return 0;
 }
 

@@ -1087,7 +1087,7 @@ void k_blocks_finish(const sla_hip_lpc_group* __restrict__ groups, uint32_t num_
                      const uint32_t* __restrict__ out_rshift,
                      const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
                      uint32_t* __restrict__ cert_flag, uint32_t* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
-                     double safety, uint32_t bps, const uint32_t* __restrict__ dyn = nullptr)
+                     double safety, uint32_t bps, const uint32_t* __restrict__ dyn = nullptr, uint32_t audit_every = 0u)
 {
   // dyn: k_expand_scan's running numbers -- the launch was sized for the most groups the file can have, before the host
   // knew how many there are (see sla_hip_launch_lpc_blocks_cert)
@@ -1169,6 +1169,7 @@ void k_blocks_finish(const sla_hip_lpc_group* __restrict__ groups, uint32_t num_
 #undef SLA_CERT_COEF
   o[0] = r[0];
   out_code[slot * O1] = 0; out_kint[slot * O1] = 0;
+  bool codes_same = true;                       // (list mode on an audited pair: what the certified run stored against this run)
 #pragma unroll
   for (int j = 0; j <= P; j++) {
     if ((uint32_t)j <= order) {
@@ -1181,11 +1182,14 @@ void k_blocks_finish(const sla_hip_lpc_group* __restrict__ groups, uint32_t num_
         int32_t code = f64_to_i32_x86(rk);
         code = (code < -lim) ? -lim : code;
         code = (code > lim - 1) ? (lim - 1) : code;
+        const int32_t ki = (int32_t)((uint32_t)code << (16u - qb)) >> rshift;
+        if (!CERT && cert_flag != nullptr && (out_code[slot * O1 + j] != code || out_kint[slot * O1 + j] != ki)) { codes_same = false; }
         out_code[slot * O1 + j] = code;
-        out_kint[slot * O1 + j] = (int32_t)((uint32_t)code << (16u - qb)) >> rshift;
+        out_kint[slot * O1 + j] = ki;
       }
     }
   }
+  bool raw_side = false;
   if (CERT) {
     // RAW decision of the host (slai_code_length, src/SLAPredictor.c:416-468; threshold (double)0.95f on 8*bytes/bps):
     // bits = 1.94.. + (log2(r0 * 2^(2(bps-1)) / n) + sum log2(1 - k^2)) / 2, known here to +- half the widths
@@ -1195,12 +1199,39 @@ void k_blocks_finish(const sla_hip_lpc_group* __restrict__ groups, uint32_t num_
       const double half = 0.5 * (delta / r[0] * 1.4426950408889634 * 2.0 + gain_w) * 1.000001 + 1e-9;
       const double thr = (double)0.95f * (double)bps;
       if (!(fabs(bits - thr) > half)) { sure = false; }
+      raw_side = (bits >= thr);
     } else if (!(power < (double)FLT_MIN * 0.999999)) { sure = false; }
     if (!(r[0] == r[0]) || !(fabs(r[0]) < 1e300)) { sure = false; }
-    cert_flag[slot] = sure ? 0u : 1u;
-    if (!sure) { fb_list[atomicAdd(fb_count, 1u)] = gi; }
+    // audit (option cert_audit = N): every N-th CERTIFIED pair goes on the list as well, after its codes are stored; the exact
+    // kernels then compare instead of overwrite (flag 3 | 8 * "the estimated length is on the RAW side of the threshold")
+    const bool audit = sure && audit_every != 0u && (gi % audit_every) == audit_every - 1u;
+    cert_flag[slot] = !sure ? 1u : !audit ? 0u : (3u | (raw_side ? 8u : 0u));
+    if (!sure || audit) { fb_list[atomicAdd(fb_count, 1u)] = gi; }
   } else if (cert_flag != nullptr) {
-    cert_flag[slot] = 2u;                       // exact: the reference's doubles bit for bit
+    // exact: the reference's doubles bit for bit (2).  An audited pair (3): codes, lattice coefficients and the side of the RAW
+    // threshold the certified run stored must be what this run computes -- 4 = they are, 5 = the certificate was WRONG
+    // (the host fails the call).  The comparison of the estimated length ignores differences below 1e-6 bit (device log2
+    // against itself on two sets of doubles that agree to ~1e-13: only a decision the certificate should never have taken
+    // can differ by more).
+    const uint32_t was = cert_flag[slot];
+    if ((was & 7u) == 3u) {
+      bool same = codes_same;
+      if (bps != 0u) {
+        double gain_e = 0.0;
+        bool pd = true;
+#pragma unroll
+        for (int j = 1; j <= P; j++) { if ((uint32_t)j <= order) { const double om = 1.0 - par[j] * par[j]; if (om > 0.0) { gain_e += log2(om); } else { pd = false; } } }
+        const double power = r[0] * ldexp(1.0, (int)(2 * (bps - 1)));
+        if (pd && power > (double)FLT_MIN * 1.000001) {
+          const double bits = 1.9426950408889634 + 0.5 * (log2(power) - log2((double)g.num_samples) + gain_e);
+          const double thr = (double)0.95f * (double)bps;
+          if (fabs(bits - thr) > 1e-6 && (bits >= thr) != ((was & 8u) != 0u)) { same = false; }
+        } else if (!pd) { same = false; }
+      }
+      cert_flag[slot] = same ? 4u : 5u;
+    } else {
+      cert_flag[slot] = 2u;
+    }
   }
   }
 }
@@ -3853,7 +3884,8 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
                            const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
                            double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
                            sla_hip_stream_t stream, uint32_t mode_flags, uint32_t* d_rerun_counter, int32_t* d_lat_residual,
-                           const uint32_t* list = nullptr, const uint32_t* list_count = nullptr, uint32_t* d_cert_flag = nullptr);
+                           const uint32_t* list = nullptr, const uint32_t* list_count = nullptr, uint32_t* d_cert_flag = nullptr,
+                           uint32_t audit_bps = 0u);
 
 extern "C" int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
                                   const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
@@ -3910,8 +3942,9 @@ extern "C" int sla_hip_launch_lpc_blocks_cert(const int32_t* d_pcm, uint64_t pla
   e = hipGetLastError();
   if (e != hipSuccess) { return hip_rc(e); }
   const dim3 fgrid((num_groups + 63) / 64), fblock(64);
+  const uint32_t audit_every = tuning().cert_audit;
 #define SLA_FINC(PP) hipLaunchKernelGGL((k_blocks_finish<PP, true>), fgrid, fblock, 0, st, d_groups, num_groups, order, d_out, d_code, d_kint, \
-                                        d_rshift, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_cert_flag, d_fallback_list, d_fallback_count, safety, bits_per_sample, dyn)
+                                        d_rshift, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_cert_flag, d_fallback_list, d_fallback_count, safety, bits_per_sample, dyn, audit_every)
   if (order <= 16) { SLA_FINC(16); } else if (order <= 32) { SLA_FINC(32); } else if (order <= 48) { SLA_FINC(48); } else { SLA_FINC(64); }
 #undef SLA_FINC
   e = hipGetLastError();
@@ -3919,7 +3952,7 @@ extern "C" int sla_hip_launch_lpc_blocks_cert(const int32_t* d_pcm, uint64_t pla
   // whatever could not be certified: the exact kernels over the list the finish kernel left (usually empty)
   return launch_lpc_impl(d_pcm, plane_stride, mid_side, order, d_groups, num_groups, max_window, 1, d_cands,
                          d_window_pool, d_out, d_code, d_kint, d_rshift, stream, 0u, nullptr, nullptr,
-                         d_fallback_list, d_fallback_count, d_cert_flag);
+                         d_fallback_list, d_fallback_count, d_cert_flag, bits_per_sample);
 }
 
 extern "C" int sla_hip_launch_lpc_rerun(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
@@ -3937,7 +3970,7 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
                            const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
                            double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
                            sla_hip_stream_t stream, uint32_t mode_flags, uint32_t* d_rerun_counter, int32_t* d_lat_residual,
-                           const uint32_t* list, const uint32_t* list_count, uint32_t* d_cert_flag)
+                           const uint32_t* list, const uint32_t* list_count, uint32_t* d_cert_flag, uint32_t audit_bps)
 {
   if (d_pcm == nullptr || d_groups == nullptr || d_cands == nullptr || d_out == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (order < 1 || order > 255 || max_window == 0 || max_cands_per_group == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
@@ -3995,7 +4028,7 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
       if (defer) {
         const dim3 fgrid((list != nullptr) ? LIST_FINISH_GRID : (num_groups + 63) / 64), fblock(64);
 #define SLA_FIN(PP) hipLaunchKernelGGL((k_blocks_finish<PP, false>), fgrid, fblock, 0, (hipStream_t)stream, d_groups, num_groups, order, d_out, d_code, d_kint, \
-                                       d_rshift, list, list_count, d_cert_flag, (uint32_t*)nullptr, (uint32_t*)nullptr, 0.0, 0u)
+                                       d_rshift, list, list_count, d_cert_flag, (uint32_t*)nullptr, (uint32_t*)nullptr, 0.0, audit_bps)
         if (order <= 16) { SLA_FIN(16); } else if (order <= 32) { SLA_FIN(32); } else if (order <= 48) { SLA_FIN(48); } else { SLA_FIN(64); }
 #undef SLA_FIN
       }
@@ -4538,10 +4571,13 @@ void k_rice_k(const int32_t* __restrict__ res, uint64_t stride, const sla_hip_ri
 // every byte comparison of the suite: the pack stage chooses by the number of jobs).
 // ---------------------------------------------------------------------------------------------
 #define RK2_JOBS 8
+// (Rows of 65 entries: in S sixteen lanes walk sixteen different rows in lock-step.  With rows of 64 every lane's operand sat on
+// the same banks -- a 16-way conflict on each read, 8-way on each store: 6.0 conflict cycles per LDS instruction,
+// profiles/r3_sq_counters_c2.csv.  Now row j of in_a starts at bank 2 j, of in_b at 16 + 2 j; of p0 at j, of p1 at 8 + j.)
 struct rk2_lds {
-  uint32_t in_a[RK2_JOBS][64][2];      // first recurrence: c >> 7, ((c & 127) + 64) | 1 << 8
-  uint32_t in_b[RK2_JOBS][64][2];      // second recurrence: the same of v - 2^k0, bit 8 = the update happens
-  uint32_t p0[RK2_JOBS][64], p1[RK2_JOBS][64];      // the parameters before each sample
+  uint32_t in_a[RK2_JOBS][65][2];      // first recurrence: c >> 7, ((c & 127) + 64) | 1 << 8
+  uint32_t in_b[RK2_JOBS][65][2];      // second recurrence: the same of v - 2^k0, bit 8 = the update happens
+  uint32_t p0[RK2_JOBS][65], p1[RK2_JOBS][65];      // the parameters before each sample
   uint32_t v[RK2_JOBS][64];            // folded residual
   uint32_t k0[2][RK2_JOBS][64];        // first exponent, kept for one more step (the second one is a batch behind)
 };

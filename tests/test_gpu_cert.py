@@ -216,3 +216,157 @@ def test_search_certificate_conditioning_sweep(hip, oracle, order, bits):
                 worst = max(worst, abs(ref - mid) / o[1])
                 bracketed += 1
     assert total == 6 * nwin * len(cand) and bracketed >= total // 3, (total, bracketed, worst)
+
+
+# ------------------------------------------------------------------ the standing audit of the certificate (round 4)
+
+AUDIT_CASES = [("bench", 2, 24, 32, 4096, 1), ("music", 2, 16, 16, 4096, 1), ("bench", 3, 24, 48, 8192, 0), ("tones-60", 2, 24, 48, 8192, 0),
+               ("tones-100", 1, 24, 32, 4096, 0), ("white", 1, 16, 8, 4096, 0)]
+
+
+@pytest.mark.parametrize("name,nch,bits,order,maxb,ms", AUDIT_CASES)
+def test_audited_certificates_hold(hip, oracle, name, nch, bits, order, maxb, ms):
+    """option cert_audit = 1: EVERY certified (block, channel) is analysed by the exact chain kernels as well, which compare
+    codes, lattice coefficients and the RAW side with what the certified run stored -- no difference, the bytes stay the
+    oracle's, the count of pairs the certificate itself handed over does not change; cert_audit = 3: every third pair"""
+    n = 6 * maxb + 777
+    pcm = material(name, nch, n, bits, seed=order + 3)
+    p = S.make_params(nch, bits, 48000, order, 3 if order > 16 else 1, 8, ms, 1, maxb, cap=(nch, 16384, 52, 3, 8))
+    data, tr, (on, redone) = encode(hip, p, pcm)
+    to, comp = check_against_oracle(oracle, p, pcm, data, tr)
+    nb = to.num_blocks
+    certified = int((~tr.parcor_exact[:nb][comp].astype(bool)).sum())
+    for every in (1, 3):
+        enc = hip.Encoder(p.cap_channels, p.cap_block_samples, p.cap_parcor_order, p.cap_longterm_order, p.cap_lms_order)
+        try:
+            enc.set_wave_format(p.num_channels, p.bits_per_sample, p.sampling_rate)
+            enc.set_encode_parameter(p.parcor_order, p.longterm_order, p.lms_order, p.ch_process_method, p.window_type, p.max_block_samples)
+            enc.set_option("stream", 0)
+            enc.set_option("cert_audit", every)
+            d2 = enc.encode_whole(pcm)
+            t2 = enc.trace()
+            ok, bad = enc.last_cert_audit()
+            on2, redone2 = enc.last_block_cert()
+        finally:
+            enc.close()
+        assert d2 == data and bad == 0 and on2 == 1 and redone2 == redone
+        check_against_oracle(oracle, p, pcm, d2, t2)
+        if every == 1:
+            # every certified pair of a compressed block was audited (RAW blocks' pairs are analysed and audited too: >=), and
+            # the doubles the trace shows are now the exact kernels' everywhere
+            assert ok >= certified and bool(t2.parcor_exact[:nb][comp].all())
+            assert np.array_equal(t2.parcor[:nb].view(np.uint64)[comp], to.parcor[:nb].view(np.uint64)[comp])
+        else:
+            assert 0 < ok or certified < 3
+
+
+def _one_block_params(bits, order, n):
+    return S.make_params(1, bits, 48000, order, 1, 8, 0, 1, n, cap=(1, 16384, 52, 3, 8))
+
+
+def boundary_cases(oracle, order, bits, n=4096):
+    """[(pcm, coefficient index m, distance of k_m * 2^(q-1) from the half-integer it was steered to)], all by the oracle's doubles
+    (= the reference's).  Two steps: a mixing gain between two signals is bisected until the two neighbouring integer signals
+    straddle the boundary (that leaves ~1e-7 of a code step: one sample moving by one quantisation step shifts k_m by about
+    that much); then single samples are nudged by one step each -- every one moves k_m by its own small amount, measured one
+    by one, and a random search over subsets of 48 of them picks a combination that lands within ~1e-11 (twice)."""
+    rng = np.random.default_rng(order * 100 + bits)
+    base = W.music_like(1, n, bits, seed=order)[0].astype(np.int64) >> (32 - bits)
+    other = np.rint(rng.standard_normal(n) * (1 << (bits - 6))).astype(np.int64)
+    full = 1 << (bits - 1)
+    p = _one_block_params(bits, order, n)
+
+    def quantised(g):
+        return np.clip(np.rint(base + g * other), -full, full - 1).astype(np.int64)
+
+    def pcm_of(q):
+        return ((q << (32 - bits)).astype(np.int64)).astype(np.int32)[None, :]
+
+    def value(q, m, lim):
+        ret, want, to = oracle.encode_trace(p, pcm_of(q))
+        assert ret == 0
+        if to.num_blocks != 1 or to.blk_type[0] != 0:
+            return None
+        return to.parcor[0][0][m] * lim
+
+    out = []
+    for m in sorted({2, 5, order // 2, order}):
+        lim = float(1 << ((16 if m < 4 else 8) - 1))
+        v0 = value(quantised(0.0), m, lim)
+        if v0 is None:
+            continue
+        target = np.floor(v0) + 0.5
+        lo, hi, flo = 0.0, None, v0 - target
+        for g in np.geomspace(1e-4, 2.0, 40):
+            v1 = value(quantised(g), m, lim)
+            if v1 is None:
+                break
+            if (v1 - target > 0) != (flo > 0):
+                hi = g
+                break
+            lo, flo = g, v1 - target
+        if hi is None:
+            continue
+        for _ in range(200):
+            mid = 0.5 * (lo + hi)
+            if np.array_equal(quantised(mid), quantised(lo)) or np.array_equal(quantised(mid), quantised(hi)):
+                break
+            vm = value(quantised(mid), m, lim)
+            if vm is None:
+                break
+            if (vm - target > 0) == (flo > 0):
+                lo, flo = mid, vm - target
+            else:
+                hi = mid
+        q = quantised(lo)
+        f = value(q, m, lim) - target
+        for _ in range(2):
+            idx = rng.choice(np.nonzero(np.abs(q) < full - 2)[0], 48, replace=False)
+            step = rng.choice([-1, 1], 48)
+            d = np.zeros(48)
+            for j in range(48):
+                q2 = q.copy(); q2[idx[j]] += step[j]
+                v2 = value(q2, m, lim)
+                d[j] = (v2 - target - f) if v2 is not None else 1e9
+            pick = rng.integers(0, 2, (200000, 48)).astype(np.float64)
+            best = pick[np.argmin(np.abs(f + pick @ d))] > 0
+            q3 = q.copy(); q3[idx[best]] += step[best]
+            v3 = value(q3, m, lim)
+            if v3 is not None and abs(v3 - target) < abs(f):
+                q, f = q3, v3 - target
+        out.append((pcm_of(q), m, abs(f)))
+        # and its neighbour on the other side of the boundary: one more sample, the one that crosses by the least
+        idx = rng.choice(np.nonzero(np.abs(q) < full - 2)[0], 24, replace=False)
+        cross = None
+        for j in idx:
+            for st in (-1, 1):
+                q2 = q.copy(); q2[j] += st
+                v2 = value(q2, m, lim)
+                if v2 is not None and ((v2 - target) > 0) != (f > 0) and (cross is None or abs(v2 - target) < cross[1]):
+                    cross = (q2, abs(v2 - target))
+        if cross is not None:
+            out.append((pcm_of(cross[0]), m, cross[1]))
+    return p, out
+
+
+@pytest.mark.parametrize("order,bits", [(16, 24), (32, 24), (48, 24), (16, 16)])
+def test_codes_next_to_a_rounding_boundary(hip, oracle, order, bits):
+    """Adversarial input for the certificate: blocks whose k_m * 2^(q-1) -- the oracle's doubles,
+    i.e. the reference's -- sits as close to a half-integer as integer PCM allows (boundary_cases).  On both sides of the
+    boundary the HIP path must give the oracle's bytes and codes; a pair closer than the narrowest width the certificate can
+    have (>= 16 (n + 64) 2^-53 2^(q-1) ~ 1e-9 of a code step) must have been handed to the exact kernels; and with every
+    certificate audited nothing differs."""
+    p, cases = boundary_cases(oracle, order, bits)
+    assert cases, "no boundary case was constructed"
+    best = min(d for _, _, d in cases)
+    assert best < (1e-11 if bits >= 24 else 1e-7), best
+    for pcm, m, dist in cases:
+        ret, want, to = oracle.encode_trace(p, pcm)
+        assert ret == 0
+        data, tr, (on, redone) = encode(hip, p, pcm)
+        assert on == 1 and data == want, (order, bits, m, dist)
+        assert np.array_equal(tr.code[:1], to.code[:1]) and np.array_equal(tr.kint[:1], to.kint[:1])
+        if dist < 2e-10:
+            assert bool(tr.parcor_exact[0][0]) and redone >= 1, (order, bits, m, dist)
+        d2, t2, _ = encode(hip, p, pcm, cert_audit=1)
+        assert d2 == want
