@@ -630,6 +630,18 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
     #      on the guess that the file looks like the last one.  `value` is that warm, same-shape steady state (the contract's
     #      K steps after W warm-ups); beside it: the same steps with nothing kept (every step builds and uploads its tables and
     #      waits for its prepass, as files of varying length do) and the first call on the fresh handle (`cold_call_ms`)
+    if world == 1 and not dist_on and cert_on:
+        # the standing audit of the block certificate: the same analysis once more with every 16th certified
+        # (block, channel) pair re-analysed by the exact reference-order kernels, which compare codes, lattice coefficients and
+        # the RAW side with what the certified run stored; a difference fails the call (and this bench)
+        enc.set_option("cert_audit", 16)
+        step()
+        torch.cuda.synchronize()
+        aud = enc.last_cert_audit()
+        enc.set_option("cert_audit", 0)
+        out["block_certificate"]["audit"] = {"every": 16, "pairs_audited_equal": int(aud[0]), "pairs_different": int(aud[1])}
+        if aud[1] != 0:
+            raise SystemExit(3)
     if world == 1 and not dist_on:
         ex = enc.last_expand()
         out["per_handle_shortcuts"] = {"analyses_served_from_kept_search_tables": int(ex[2]), "searches_launched_on_a_wrong_guess": int(ex[3]),

@@ -161,6 +161,14 @@ int sla_hip_launch_prepass_tiles(const int32_t* d_pcm, uint64_t plane_stride, ui
                                  uint32_t num_samples, uint32_t bits_per_sample, uint32_t mid_side,
                                  uint32_t* d_or_mask, uint64_t* d_nz_mask, uint32_t* d_tile_or, sla_hip_stream_t stream);
 
+/* Per file of a batch laid out back to back on SLA_HIP_PREPASS_TILE boundaries (sla_hip_analyze_batch_device), from the results
+ * of sla_hip_launch_prepass_tiles: d_info[3 i] = OR of the file's words, [3 i + 1] = all-zero 64-sample mask words inside it,
+ * [3 i + 2] = 1 when its last super-frame (fewer than 127 samples left of it) is all zero.  No zero word and no such tail
+ * anywhere: no block of the batch can be SILENT (reference src/SLAEncoder.c:392-408), the mask never has to leave the device. */
+int sla_hip_launch_batch_scan(const uint64_t* d_nz_mask, const uint32_t* d_tile_or, const uint32_t* d_file_start,
+                              const uint32_t* d_file_len, uint32_t num_files, uint32_t max_block_samples,
+                              uint32_t* d_info, sla_hip_stream_t stream);
+
 /* Autocorrelation + Levinson-Durbin for every candidate of every group.
  * d_out: per slot (order+2) doubles = { r[0], parcor[0..order] }.
  * When d_code/d_kint/d_rshift are non-NULL (chosen blocks: one candidate per

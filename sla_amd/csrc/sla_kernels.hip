@@ -3870,6 +3870,50 @@ extern "C" int sla_hip_launch_prepass(const int32_t* d_pcm, uint64_t plane_strid
   return launch_prepass_impl(d_pcm, plane_stride, num_channels, num_samples, bits_per_sample, mid_side, d_or_mask, d_nz_mask, nullptr, stream);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_batch_scan: what the host needs to know about every file of a batch (files back to back on 1024-sample boundaries,
+// sla_hip_analyze_batch_device) from the prepass results, so that the silence mask itself stays on the device: the OR of the
+// file's tile words (-> its offset_lshift), the number of all-zero 64-sample mask words inside it, and whether its last
+// super-frame -- the one case in which a block can be SILENT without such a word: fewer than 127 samples left,
+// src/SLAEncoder.c:392-408 with the minimum block length shrunk to what is left -- is all zero.  One workgroup per file.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_batch_scan(const uint64_t* __restrict__ nz, const uint32_t* __restrict__ tile_or, const uint32_t* __restrict__ file_start,
+                  const uint32_t* __restrict__ file_len, uint32_t max_block, uint32_t* __restrict__ info)
+{
+  __shared__ uint32_t s_or[4], s_zero[4];
+  const uint32_t f = blockIdx.x, start = file_start[f], len = file_len[f];
+  const uint32_t w0 = start >> 6, nw = len >> 6;                                    // whole mask words of the file (it starts on a word)
+  const uint32_t t0 = start / SLA_HIP_PREPASS_TILE, nt = (len + SLA_HIP_PREPASS_TILE - 1) / SLA_HIP_PREPASS_TILE;
+  uint32_t orw = 0, zeros = 0;
+  for (uint32_t i = threadIdx.x; i < nw; i += 256) { zeros += (nz[w0 + i] == 0ull) ? 1u : 0u; }
+  for (uint32_t i = threadIdx.x; i < nt; i += 256) { orw |= tile_or[t0 + i]; }
+  for (int off = 32; off > 0; off >>= 1) { orw |= (uint32_t)__shfl_xor((int)orw, off); zeros += (uint32_t)__shfl_xor((int)zeros, off); }
+  if ((threadIdx.x & 63) == 0) { s_or[threadIdx.x >> 6] = orw; s_zero[threadIdx.x >> 6] = zeros; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t rem = (max_block != 0u) ? (len % max_block) : 0u;
+    uint32_t tail = 0;
+    if (rem >= 1u && rem < 127u) {
+      tail = 1;
+      for (uint32_t p = start + len - rem; p < start + len; p++) { if ((nz[p >> 6] >> (p & 63u)) & 1ull) { tail = 0; break; } }
+    }
+    info[3 * f] = s_or[0] | s_or[1] | s_or[2] | s_or[3];
+    info[3 * f + 1] = s_zero[0] + s_zero[1] + s_zero[2] + s_zero[3];
+    info[3 * f + 2] = tail;
+  }
+}
+
+extern "C" int sla_hip_launch_batch_scan(const uint64_t* d_nz_mask, const uint32_t* d_tile_or, const uint32_t* d_file_start,
+                                         const uint32_t* d_file_len, uint32_t num_files, uint32_t max_block_samples,
+                                         uint32_t* d_info, sla_hip_stream_t stream)
+{
+  if (d_nz_mask == nullptr || d_tile_or == nullptr || d_file_start == nullptr || d_file_len == nullptr || d_info == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  if (num_files == 0) { return 0; }
+  hipLaunchKernelGGL(k_batch_scan, dim3(num_files), dim3(256), 0, (hipStream_t)stream, d_nz_mask, d_tile_or, d_file_start, d_file_len, max_block_samples, d_info);
+  return hip_rc(hipGetLastError());
+}
+
 extern "C" int sla_hip_launch_prepass_tiles(const int32_t* d_pcm, uint64_t plane_stride, uint32_t num_channels,
                                             uint32_t num_samples, uint32_t bits_per_sample, uint32_t mid_side,
                                             uint32_t* d_or_mask, uint64_t* d_nz_mask, uint32_t* d_tile_or, sla_hip_stream_t stream)

@@ -204,3 +204,111 @@ def test_c4_at_its_real_batch_size(oracle, hip):
             pcm = pcm[:, :477777]                         # a ragged last clip
         pcms.append(np.ascontiguousarray(pcm))
     check_batch(oracle, hip, p, pcms, also_single=False)
+
+
+# ------------------------------------------------------------------ batches on device-written block tables (round 4)
+
+def _device_batch(hip, p, pcms, **options):
+    """sla_hip_analyze_batch_device on the files laid out back to back: (trace, last_expand, starts)"""
+    import torch
+    nch = pcms[0].shape[0]
+    starts, at = [], 0
+    for x in pcms:
+        starts.append(at)
+        at += (x.shape[1] + 1023) // 1024 * 1024
+    span = max(at, 1024)
+    d_pcm = torch.zeros((nch, span), dtype=torch.int32, device="cuda")
+    for s0, x in zip(starts, pcms):
+        d_pcm[:, s0:s0 + x.shape[1]] = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    enc = make_encoder(hip, p)
+    for k, v in options.items():
+        enc.set_option(k, v)
+    return enc, d_pcm, span, starts
+
+
+def _check_trace(oracle, p, tr, starts, pcms):
+    b = 0
+    for s0, x in zip(starts, pcms):
+        ret, _, to = oracle.encode_trace(p, x)
+        assert ret == 0
+        k = to.num_blocks
+        assert np.array_equal(tr.blk_start[b:b + k], to.blk_start[:k] + s0)
+        assert np.array_equal(tr.blk_nsmpl[b:b + k], to.blk_nsmpl[:k]) and np.array_equal(tr.blk_type[b:b + k], to.blk_type[:k])
+        comp = to.blk_type[:k] == 0
+        for f in ("code", "kint", "rshift", "pitch", "rice_init"):
+            assert np.array_equal(getattr(tr, f)[b:b + k][comp], getattr(to, f)[:k][comp]), f
+        for j in np.nonzero(comp)[0]:
+            a, n = int(to.blk_start[j]), int(to.blk_nsmpl[j])
+            assert np.array_equal(tr.res_final[:, s0 + a:s0 + a + n], to.res_final[:, a:a + n])
+        b += k
+    assert b == tr.num_blocks
+
+
+def test_batch_without_silence_takes_device_tables(oracle, hip):
+    """no all-zero mask word and no silent file tail anywhere (k_batch_scan): the mask stays on the device, the block tables
+    are written by k_expand (last_expand says so), the search tables are kept for the next batch of the same layout --
+    and every file is the oracle's, also when the next batch has the same layout and other contents, and on host tables"""
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096, cap=(2, 4096, 16, 1, 8))
+    lens = [30000, 4097, 12288, 2049, 20000, 4096 * 3 + 126]
+    first = [W.music_like(2, n, 16, seed=170 + i) for i, n in enumerate(lens)]
+    second = [S.synth_pcm(2, n, 16, 48000, seed=90 + i) for i, n in enumerate(lens)]
+    enc, d_pcm, span, starts = _device_batch(hip, p, first)
+    import torch
+    try:
+        enc.num_channels, enc.order, enc.ltm_order = 2, 16, 1
+        hits0 = enc.last_expand()[2]
+        enc.analyze_batch_device(d_pcm.data_ptr(), span, span, starts, lens)
+        ex = enc.last_expand()
+        assert ex[0] == ex[1] >= 1, ex                      # every pipeline chunk was launched from device-written tables
+        _check_trace(oracle, p, enc.trace(), starts, first)
+        for s0, x in zip(starts, second):
+            d_pcm[:, s0:s0 + x.shape[1]] = torch.from_numpy(x).cuda()
+        torch.cuda.synchronize()
+        enc.analyze_batch_device(d_pcm.data_ptr(), span, span, starts, lens)
+        ex2 = enc.last_expand()
+        assert ex2[0] == ex2[1] >= 1 and ex2[2] == hits0 + 1, ex2      # same layout: the kept search tables served it
+        _check_trace(oracle, p, enc.trace(), starts, second)
+        # another layout: rebuilt, still right
+        enc.analyze_batch_device(d_pcm.data_ptr(), span, span, starts[:3], lens[:3])
+        _check_trace(oracle, p, enc.trace(), starts[:3], second[:3])
+        enc.set_option("device_expand", 0)                   # host tables: same results
+        enc.analyze_batch_device(d_pcm.data_ptr(), span, span, starts, lens)
+        assert enc.last_expand()[0] == 0
+        _check_trace(oracle, p, enc.trace(), starts, second)
+    finally:
+        enc.close()
+
+
+def test_batch_with_a_silent_tail_or_a_zero_word_takes_the_mask(oracle, hip):
+    """the two things k_batch_scan looks for: a file whose last super-frame (< 127 samples) is all zero -- a SILENT block no
+    all-zero mask word betrays -- and an all-zero 64-sample word inside one file; either sends the batch through the host's
+    mask and tables, bytes as the oracle's"""
+    p = S.make_params(1, 16, 48000, 8, 1, 4, 0, 1, 4096)
+    a = W.music_like(1, 4096 * 2 + 100, 16, seed=5)
+    a[:, 4096 * 2:] = 0                                     # 100 zero samples = the whole last super-frame
+    b = W.music_like(1, 9000, 16, seed=6)
+    c = W.music_like(1, 4096 + 126, 16, seed=7)
+    c[:, 4096:] = 0
+    d = W.music_like(1, 4096 + 126, 16, seed=8)
+    d[:, 4096:-1] = 0                                       # ... all but the last sample: not silent
+    check_batch(oracle, hip, p, [a, b, c, d], also_single=False)
+    e = W.music_like(1, 30000, 16, seed=9)
+    e[:, 10048:10048 + 64] = 0                              # one aligned all-zero word (too short to be a block)
+    check_batch(oracle, hip, p, [b, e, d], also_single=False)
+    enc, d_pcm, span, starts = _device_batch(hip, p, [b, e, d])
+    try:
+        enc.num_channels, enc.order, enc.ltm_order = 1, 8, 1
+        enc.analyze_batch_device(d_pcm.data_ptr(), span, span, starts, [x.shape[1] for x in (b, e, d)])
+        assert enc.last_expand()[0] == 0                     # host tables
+        _check_trace(oracle, p, enc.trace(), starts, [b, e, d])
+    finally:
+        enc.close()
+    enc, d_pcm, span, starts = _device_batch(hip, p, [b, d])
+    try:
+        enc.num_channels, enc.order, enc.ltm_order = 1, 8, 1
+        enc.analyze_batch_device(d_pcm.data_ptr(), span, span, starts, [b.shape[1], d.shape[1]])
+        assert enc.last_expand()[0] >= 1                     # nothing silent: device tables
+        _check_trace(oracle, p, enc.trace(), starts, [b, d])
+    finally:
+        enc.close()
