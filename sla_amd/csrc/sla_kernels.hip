@@ -1765,7 +1765,14 @@ __device__ __forceinline__ double schur_error(const double* __restrict__ rc, dou
   for (int m = 1; m <= P; m++) {
     if ((uint32_t)m <= order) {
       bad = bad || !(u[0] > 0.0);
-      const double k = -v[1] / u[0];
+      // k = -v[1] / u[0] by v_rcp_f64 and two Newton steps (~1e-16 relative) instead of the IEEE division's twenty-odd
+      // instructions: this recursion only has to be ACCURATE -- its result is the end of a bracket whose width is at least
+      // cert (2 order + 1) (n 2^-53) ~ 1e-9 of r0, and the caller widens the logarithms by 1e-11 on top -- not reproducible
+      // bit for bit (nothing of it reaches the stream: DESIGN section 2a)
+      double rc0 = __builtin_amdgcn_rcp(u[0]);
+      rc0 = __builtin_fma(__builtin_fma(-u[0], rc0, 1.0), rc0, rc0);
+      rc0 = __builtin_fma(__builtin_fma(-u[0], rc0, 1.0), rc0, rc0);
+      const double k = -v[1] * rc0;
       bad = bad || !(fabs(k) < 1.0);
       growth *= 1.0 + fabs(k);                            // prod (1 + |k_j|) >= ||a||_1 of every predictor on the way
 #pragma unroll
@@ -4122,6 +4129,126 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
   return hip_rc(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_search_cert: the certificate of the windows over the exactness limit (k_search_finish's mode 1) with its lanes full.
+// A candidate needs TWO Schur recursions, one per end of the bracket; k_search_finish ran them one after the other in the
+// candidate's lane, and an 8192-sample window has 36 candidates: 36 of 64 lanes busy, twice.  Here a lane is (candidate, end):
+// a wave takes 32 consecutive candidate SLOTS of the launch -- the slots of the search groups are numbered consecutively,
+// so a slot number is a flat candidate index and a wave's slots belong to at most two groups of equal size (it finds the
+// group from the quotient and walks on where groups are shorter) -- lanes 0..31 run the end r0 + d, lanes 32..63 the end
+// r0 - d of the same 32 candidates, the results meet through one cross-half exchange.  Same values as mode 1 (the same
+// schur_error on the same operands); 14 KB of sums per wave become 12.5.
+// ---------------------------------------------------------------------------------------------
+#define XC_CANDS 32
+template <int P>
+__global__ __launch_bounds__(64)
+void k_search_cert(uint32_t order, uint32_t lags, uint32_t per_max,
+                   const sla_hip_lpc_group* __restrict__ groups, uint32_t num_groups, const sla_hip_lpc_cand* __restrict__ cands,
+                   const double* __restrict__ tile_sums, double* __restrict__ out, double exact_limit, double cert,
+                   uint32_t* __restrict__ any_exact)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];          // r[XC_CANDS][order + 1]
+  __shared__ uint32_t s_grp[XC_CANDS], s_start[XC_CANDS], s_len[XC_CANDS], s_live[XC_CANDS];
+  __shared__ double s_energy[XC_CANDS];
+  const uint32_t O1 = order + 1, O2 = order + 2;
+  const uint32_t lane = threadIdx.x, half = lane >> 5, cl = lane & 31u;
+  const uint32_t slot0 = groups[0].slot_first;
+  const uint32_t total = groups[num_groups - 1].slot_first + groups[num_groups - 1].cand_count - slot0;
+  const uint32_t s = blockIdx.x * XC_CANDS + cl;                         // slot of this launch (both halves: the same candidate)
+  if (blockIdx.x * XC_CANDS >= total) { return; }
+  if (half == 0) {
+    uint32_t live = 0, g = 0, start = 0, len = 0;
+    double energy = 0.0;
+    if (s < total) {
+      // no group has more than per_max candidates: group index >= s / per_max; walk on over shorter groups
+      g = s / per_max;
+      if (g >= num_groups) { g = num_groups - 1; }
+      for (int i = 0; i < 4 && g + 1 < num_groups && groups[g + 1].slot_first - slot0 <= s; i++) { g++; }
+      if (g + 1 < num_groups && groups[g + 1].slot_first - slot0 <= s) {
+        // many shorter groups in front (a batch of files, each ending in a short super-frame): bisect the rest
+        uint32_t lo = g + 1, hi = num_groups - 1;
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi + 1) >> 1;
+          if (groups[mid].slot_first - slot0 <= s) { lo = mid; } else { hi = mid - 1; }
+        }
+        g = lo;
+      }
+      const sla_hip_lpc_group gr = groups[g];
+      const uint32_t ci = s - (gr.slot_first - slot0);
+      if (ci < gr.cand_count) {
+        const uint32_t ntiles = (gr.num_samples + SLA_HIP_XTILE - 1) / SLA_HIP_XTILE;
+        const double* ts = tile_sums + (uint64_t)g * SLA_HIP_XTILES * 2 * lags;
+        for (uint32_t t = 0; t < ntiles; t++) { energy += ts[(uint64_t)t * 2 * lags]; }
+        if (energy < exact_limit) {
+          if (any_exact != nullptr) { atomicOr(any_exact, 1u); }        // an exact window: the mode-2 launch behind this one takes it
+        } else {
+          const sla_hip_lpc_cand cd = cands[gr.cand_first + ci];
+          live = 1; start = cd.start; len = cd.len;
+        }
+      }
+    }
+    s_grp[cl] = g; s_start[cl] = start; s_len[cl] = len; s_live[cl] = live; s_energy[cl] = energy;
+  }
+  __syncthreads();
+  double* r = lds;
+  for (uint32_t q = lane; q < XC_CANDS * O1; q += 64) {
+    const uint32_t c2 = q / O1, lag = q - c2 * O1;
+    if (s_live[c2]) {
+      const double* ts = tile_sums + (uint64_t)s_grp[c2] * SLA_HIP_XTILES * 2 * lags;
+      const uint32_t st = s_start[c2], ln = s_len[c2], end = st + ln;
+      double sum = 0.0;
+      if (lag < ln) {
+        const uint32_t tl = (end - 1) / SLA_HIP_XTILE;
+        for (uint32_t t = st / SLA_HIP_XTILE; t <= tl; t++) { sum += ts[(uint64_t)t * 2 * lags + lag]; }
+        sum -= ts[(uint64_t)tl * 2 * lags + lags + lag];
+      }
+      r[c2 * O1 + lag] = sum;
+    }
+  }
+  __syncthreads();
+  const double inf = __longlong_as_double(0x7FF0000000000000ll);
+  const double nan = __longlong_as_double(0x7FF8000000000000ll);
+  const double u = 1.1102230246251565e-16;                              // 2^-53
+  const bool live = (s_live[cl] != 0u);
+  const double* rc = r + (size_t)cl * O1;
+  const double r0 = live ? rc[0] : 1.0;
+  const uint32_t len = s_len[cl];
+  const bool valid = live && len >= order && r0 > 2.0 * (double)FLT_EPSILON;   // (the reference zeroes the coefficients below FLT_EPSILON, src/SLAPredictor.c:274)
+  const double delta = ((double)len * u) * r0 + (48.0 * u) * s_energy[cl];
+  const double d = cert * (double)(2 * order + 1) * delta;
+  double e_mine = nan, g_mine = 1.0;
+  if (valid) {
+    const double rb = (half == 0) ? (r0 + d) : (r0 - d);
+    if (half == 0 || r0 - d > (double)FLT_EPSILON) { e_mine = schur_error<P>(rc, rb, order, g_mine); }
+  }
+  // the other end of my candidate's bracket sits 32 lanes away
+  const double e_other = __hiloint2double(__shfl_xor(__double2hiint(e_mine), 32), __shfl_xor(__double2loint(e_mine), 32));
+  const double g_other = __hiloint2double(__shfl_xor(__double2hiint(g_mine), 32), __shfl_xor(__double2loint(g_mine), 32));
+  if (live) {
+    double* o = out + ((uint64_t)slot0 + s) * O2;
+    if (half == 0) {
+      // slot layout of a certified candidate: { r0, width, log2(e_p / r0), 0, .. }
+      const double e_hi = e_mine, e_lo = e_other;
+      double w = inf, lg = 0.0;
+      if (valid) {
+        // (the share of the bound left for the rounding of the reference's Levinson-Durbin run: see k_search_finish)
+        const double gmax = fmax(g_mine, g_other);
+        const bool rounding_covered = ((double)(order + 2) * gmax * u * r0 <= (cert - 1.0) * (double)(2 * order + 1) * delta);
+        if (rounding_covered && e_lo > 0.0 && e_hi >= e_lo && e_hi < inf) {
+          const double lh = log2(e_hi / r0), ll = log2(e_lo / r0);
+          w = 0.5 * (lh - ll) * 1.000001 + 1e-11;                       // (device log2: a few ulp)
+          lg = 0.5 * (lh + ll);
+        }
+      }
+      o[0] = rc[0];
+      o[1] = (w == w) ? w : inf;
+      o[2] = lg;
+    }
+    // the rest of the slot is zero: the two lanes of the candidate share the stores
+    for (uint32_t k = 2 + half; k <= order; k += 2) { o[1 + k] = 0.0; }
+  }
+}
+
 extern "C" uint32_t sla_hip_search_exact_lags(uint32_t order)
 {
   const uint32_t nb = (order + 1 + 3) / 4;
@@ -4188,8 +4315,14 @@ extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_
       if (e != hipSuccess) { return hip_rc(e); } \
       e = ensure_dynamic_lds((const void*)k_search_finish<PP, 2>, lds_r); \
       if (e != hipSuccess) { return hip_rc(e); } \
+      if (cert_safety > 0.0 && !tuning().acf_classic) { \
+        const uint64_t slots_bound = (uint64_t)num_groups * max_cands_per_group; \
+        hipLaunchKernelGGL((k_search_cert<PP>), dim3((uint32_t)((slots_bound + XC_CANDS - 1) / XC_CANDS)), dim3(64), sizeof(double) * XC_CANDS * (order + 1), st, \
+                           order, lags, max_cands_per_group, d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety, d_any_exact); \
+      } else { \
       hipLaunchKernelGGL((k_search_finish<PP, 1>), dim3((num_groups + gpw - 1) / gpw), dim3(64), lds_r, st, order, lags, gpw, per, \
                          d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety, d_any_exact); \
+      } \
       hipLaunchKernelGGL((k_search_finish<PP, 2>), dim3((num_groups + gpw - 1) / gpw), dim3(64), lds_r, st, order, lags, gpw, per, \
                          d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety, d_any_exact); \
     } } while (0)

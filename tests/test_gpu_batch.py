@@ -304,11 +304,16 @@ def test_batch_with_a_silent_tail_or_a_zero_word_takes_the_mask(oracle, hip):
         _check_trace(oracle, p, enc.trace(), starts, [b, e, d])
     finally:
         enc.close()
-    enc, d_pcm, span, starts = _device_batch(hip, p, [b, d])
+    # (d's 125 zeros hold an aligned all-zero word: host tables too.)  A tail of 100 samples that is NOT silent, no zero word:
+    f = W.music_like(1, 4096 * 2 + 100, 16, seed=11)
+    f[0, f[0] == 0] = 1 << 16
+    g = b.copy()
+    g[0, g[0] == 0] = 1 << 16
+    enc, d_pcm, span, starts = _device_batch(hip, p, [g, f])
     try:
         enc.num_channels, enc.order, enc.ltm_order = 1, 8, 1
-        enc.analyze_batch_device(d_pcm.data_ptr(), span, span, starts, [b.shape[1], d.shape[1]])
+        enc.analyze_batch_device(d_pcm.data_ptr(), span, span, starts, [g.shape[1], f.shape[1]])
         assert enc.last_expand()[0] >= 1                     # nothing silent: device tables
-        _check_trace(oracle, p, enc.trace(), starts, [b, d])
+        _check_trace(oracle, p, enc.trace(), starts, [g, f])
     finally:
         enc.close()
