@@ -132,14 +132,10 @@ typedef struct sla_hip_tuning {
   uint32_t lpc_pack;            /* windows per workgroup of k_lpc / k_lpc_blocks, 0 = automatic                      */
   uint32_t lpc_threads;         /* 256 or 512 threads per k_lpc workgroup, 0 = automatic                             */
   uint32_t lpc_blocks_chains;   /* 1: chosen blocks through k_lpc's serial chains instead of k_lpc_blocks            */
-  uint32_t tail_waves;          /* waves per tail workgroup (1..4), 0 = automatic (k_tailk 4, round-2 kernels 1)      */
+  uint32_t tail_waves;          /* waves per tail workgroup (1..4), 0 = automatic (4)                                */
   uint32_t lpc_tile;            /* steps per tile of k_lpc_blocks' wide packs: 24, or 0 / 48 = 48 where it fits         */
-  uint32_t tail_lanes;          /* tail kernel: 0 = k_tailk with 1 or 2 taps of each history per lane, by the number of jobs (default);
-                                   6 / 4 / 5 = k_tailk with 1 / 2 / 4 taps; round-2 kernels: 1 = k_tail2 (LMS order lanes per job),
-                                   2 = k_tail (twice that), 3 = k_tail1 (ONE lane per job, LMS order <= 16) */
+  uint32_t tail_taps;           /* k_tailk: taps of each history per lane, 1 / 2 / 4; 0 = by the number of jobs (default) */
   double   plan_margin;         /* certification margin of k_plan, 0 = 1e-4 (tests raise it to force the host plan)  */
-  uint32_t acf_classic;         /* 1: round 2's autocorrelation kernels: long-term stage through k_ltm_acf (one LDS pass per step) instead of
-                                   k_ltm_acf2, tile sums at 52 lags through k_acf_tiles (DPP moves) instead of k_acf_tiles_lds */
   uint32_t rice_lanes;          /* Rice parameter walk: 1 = one lane per job (k_rice_k), 2 = the two-lane pipeline (k_rice_k2), 0 = by the number of jobs */
   uint32_t lattice_plain;       /* 1: every lattice stage in the wrapping four-instruction form (round 3); 0 = the shortest form each stage's
                                    operand bound allows (same results: tests run both) */
@@ -148,6 +144,36 @@ typedef struct sla_hip_tuning {
                                    run stored: d_cert_flag 4 = audited and equal, 5 = the certificate was wrong (the encoder fails the call) */
 } sla_hip_tuning;
 void sla_hip_use_tuning(const sla_hip_tuning* tuning);
+
+/* Optional extras of ONE launch, for the launchers that have an `_x` twin (same arguments + `const sla_hip_launch_extra*`, NULL =
+ * none; the plain name is the twin with NULL).  What the encoder's driver needs and a caller of a single launcher usually
+ * does not: */
+typedef struct sla_hip_launch_extra {
+  unsigned long long* d_span;       /* two device words (zeroed by the caller): [0] = max(~start), [1] = max(end) of the launch's execution on
+                                       the device's constant 100 MHz clock -- first workgroup in to last workgroup out, without the time the
+                                       launch waits for resources behind kernels of other streams (sla_hip_last_kernel_ms) */
+  const uint32_t* d_group_count;    /* sla_hip_launch_lpc_blocks_cert_x: num_groups is an upper bound, the kernels take the number of groups from
+                                       the running numbers sla_hip_launch_expand keeps on the device (the launch can be queued before the host
+                                       has seen the count) */
+  uint32_t* clear_ptr[3];           /* sla_hip_launch_search_exact_x: up to three regions of device words that the first workgroup of its first */
+  uint32_t  clear_words[3];         /* kernel zeroes on the way (instead of one fill kernel each in front of it) */
+} sla_hip_launch_extra;
+int sla_hip_launch_lpc_x(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                         const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window, uint32_t max_cands_per_group,
+                         const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
+                         double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
+                         sla_hip_stream_t stream, const sla_hip_launch_extra* extra);
+int sla_hip_launch_lpc_blocks_x(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                                const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                                const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
+                                double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
+                                int32_t* d_lattice_residual, sla_hip_stream_t stream, const sla_hip_launch_extra* extra);
+int sla_hip_launch_lpc_blocks_cert_x(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                                     const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                                     const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
+                                     double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
+                                     uint32_t* d_cert_flag, uint32_t* d_fallback_list, uint32_t* d_fallback_count,
+                                     double safety, uint32_t bits_per_sample, sla_hip_stream_t stream, const sla_hip_launch_extra* extra);
 
 /* d_or_mask[0] = OR of every input word, d_or_mask[1] = number of all-zero words of the mask; d_nz_mask: one
  * bit per sample "any channel non-zero after right-justify / mid-side", ceil(num_samples/64) words. */
@@ -241,6 +267,12 @@ int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_stride, uin
                                 const sla_hip_lpc_cand* d_cands, double* d_tile_sums, double* d_out,
                                 double exact_limit, double cert_safety, uint32_t* d_any_exact /* one scratch word, may be NULL */,
                                 sla_hip_stream_t stream);
+int sla_hip_launch_search_exact_x(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                                const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                                uint32_t max_cands_per_group,
+                                const sla_hip_lpc_cand* d_cands, double* d_tile_sums, double* d_out,
+                                double exact_limit, double cert_safety, uint32_t* d_any_exact /* one scratch word, may be NULL */,
+                                sla_hip_stream_t stream, const sla_hip_launch_extra* extra);
 
 /* The scalar tail of the partition search on the device: estimated code length per candidate, adjacency
  * matrix, shortest path (reference src/SLAPredictor.c:416-468, 1521-1581, 1615-1692).  d_groups: the groups of
@@ -322,6 +354,9 @@ int sla_hip_launch_lattice(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
 int sla_hip_launch_lattice_groups(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
                                   const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
                                   const int32_t* d_kint, int32_t* d_residual, sla_hip_stream_t stream);
+int sla_hip_launch_lattice_groups_x(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                                  const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                                  const int32_t* d_kint, int32_t* d_residual, sla_hip_stream_t stream, const sla_hip_launch_extra* extra);
 
 /* Autocorrelation of each job's residual, computed exactly as the reference's real-FFT route does
  * (zero-padded to fft_size, forward, |.|^2, inverse).  head == SLA_HIP_ACF_RECORD: per job a 12-double
@@ -336,6 +371,10 @@ int sla_hip_launch_ltm_acf(const int32_t* d_residual, uint64_t plane_stride,
                            const sla_hip_acf_job* d_jobs, uint32_t num_jobs, uint32_t fft_size,
                            const double* d_twiddles, double* d_scratch, uint32_t scratch_slots,
                            double* d_acf_head, uint32_t head, sla_hip_stream_t stream);
+int sla_hip_launch_ltm_acf_x(const int32_t* d_residual, uint64_t plane_stride,
+                           const sla_hip_acf_job* d_jobs, uint32_t num_jobs, uint32_t fft_size,
+                           const double* d_twiddles, double* d_scratch, uint32_t scratch_slots,
+                           double* d_acf_head, uint32_t head, sla_hip_stream_t stream, const sla_hip_launch_extra* extra);
 
 /* Long-term pitch and taps on the device: one lane per job solves the Wiener system around the lag k_ltm_acf chose
  * (d_acf_records: num_jobs compact records, head SLA_HIP_ACF_RECORD) and writes the job k_tail reads -- position and
@@ -350,6 +389,9 @@ int sla_hip_launch_ltm_solve(const double* d_acf_records, const sla_hip_lpc_grou
 int sla_hip_launch_tail(const int32_t* d_res_in, int32_t* d_res_out, uint64_t plane_stride,
                         const sla_hip_tail_job* d_jobs, uint32_t num_jobs, uint32_t longterm_order,
                         uint32_t lms_order, uint64_t* d_fold_sum, sla_hip_stream_t stream);
+int sla_hip_launch_tail_x(const int32_t* d_res_in, int32_t* d_res_out, uint64_t plane_stride,
+                        const sla_hip_tail_job* d_jobs, uint32_t num_jobs, uint32_t longterm_order,
+                        uint32_t lms_order, uint64_t* d_fold_sum, sla_hip_stream_t stream, const sla_hip_launch_extra* extra);
 
 /* Rice code lengths: per job the log2 of both adaptive moduli for every sample (d_kk, same plane layout
  * as the residual, uint16: k0 | k1 << 8) and the channel's total body bits (d_chan_bits[job]).
@@ -548,36 +590,35 @@ int sla_hip_bind_residual_planes(struct SLAEncoder* encoder, int32_t* d_lattice,
 /* Copy the last analysis into caller arrays. */
 int sla_hip_get_trace(struct SLAEncoder* encoder, sla_hip_trace* trace);
 
-/* Options of one encoder handle, by name (the environment variable of the same meaning, read once in
- * SLAEncoder_Create, is given in brackets).  Layout knobs: "lpc_pack" [SLA_HIP_LPC_PACK], "lpc_threads"
- * [SLA_HIP_LPC_THREADS], "lpc_tile" (24 / 48 / 0 = automatic), "tail_waves" [SLA_HIP_TAIL_WAVES], "tail_lanes" (0: k_tailk, taps
- * per lane by the number of jobs; 6 / 4 / 5: k_tailk with 1 / 2 / 4 taps of each history per lane; 1 / 2 / 3: the round-2 kernels k_tail2 /
- * k_tail / k_tail1) [SLA_HIP_TAIL_LANES], "chunks" [SLA_HIP_CHUNKS],
- * "threads" (host pool) [SLA_HIP_THREADS].  Route switches -- every route gives the same bytes; tests force the
- * slower exact ones through these: "search_exact" (0: no tile-sum search) [SLA_HIP_SEARCH=chain], "exact_bits"
- * (log2 of the tile-sum energy limit, 1..53) [SLA_HIP_EXACT_BITS], "cert_safety" (safety factor of the certificate for
- * windows over that limit, default 64; 0: no certificate, such windows are rerun as serial chains) [SLA_HIP_CERT],
- * "device_plan" (0: partitions decided on the host) [SLA_HIP_PLAN=host],
- * "block_cert" (0: every chosen block through the exact chain kernel; 1 = default: the certified route of
- * sla_hip_launch_lpc_blocks_cert) [SLA_HIP_BLOCK_CERT], "block_cert_safety" (default 16), "cert_audit" (N > 0: every N-th
- * certified pair is re-analysed by the exact kernels and compared, a difference fails the call; default 0),
- * "plan_margin" [SLA_HIP_PLAN_MARGIN], "lpc_blocks_chains" [SLA_HIP_LPC_BLOCKS=chains], "fuse_lattice"
- * [SLA_HIP_LATTICE=fused], "device_ltm" (0: long-term pitch + taps solved on the host threads from the downloaded
- * autocorrelations, one k_tail per pipeline chunk) [SLA_HIP_LTM=host], "single_tail" (0: one k_tail per pipeline chunk
- * instead of one for the file) [SLA_HIP_SINGLE_TAIL], "first_chunk" (1/1000 of the super-frames in pipeline chunk 0;
- * 0: built-in shares), "alt_streams" (block stages of odd and even pipeline chunks on two streams: 0 never, 1 / 2 = default:
- * whenever the file is cut into chunks).  SLAEncoder_EncodeWhole of long files: "stream" (0: never streamed) [SLA_HIP_STREAM],
+/* Options of one encoder handle, by name.  A handle starts with the defaults below; nothing is read from the environment
+ * (SLA_HIP_TRACE=1 alone, at SLAEncoder_Create: a host-side timeline of every analysis on stderr).
+ * Layout knobs: "lpc_pack", "lpc_threads" (256 / 512), "lpc_tile" (24 / 48 / 0 = automatic), "tail_waves" (waves per tail
+ * workgroup, 1..4, 0 = 4), "tail_taps" (k_tailk: taps of each history per lane, 1 / 2 / 4, 0 = by the number of jobs), "chunks"
+ * (pipeline chunks, 1..8), "threads" (host pool; default min(6, CPUs of the process): a one-process-per-GPU launcher that
+ * shares few cores between its ranks sets it), "rice_lanes" (Rice parameter walk of the device pack: 0 = by the number of
+ * jobs, 1 = one lane per job, 2 = two-lane pipeline), "lattice_plain" (1: every lattice stage in the wrapping
+ * four-instruction form).
+ * Route switches -- every route gives the same bytes; tests force the slower exact ones through these: "search_exact" (0: no
+ * tile-sum search), "exact_bits" (log2 of the tile-sum energy limit, 1..53), "cert_safety" (safety factor of the certificate
+ * for windows over that limit, default 64; 0: no certificate, such windows are rerun as serial chains), "device_plan" (0:
+ * partitions decided on the host), "block_cert" (0: every chosen block through the exact chain kernel; 1 = default: the
+ * certified route of sla_hip_launch_lpc_blocks_cert), "block_cert_safety" (default 16), "cert_audit" (N > 0: every N-th
+ * certified pair is re-analysed by the exact kernels and compared, a difference fails the call; default 0), "plan_margin",
+ * "lpc_blocks_chains", "fuse_lattice", "device_ltm" (0: long-term pitch + taps solved on the host threads from the downloaded
+ * autocorrelations, one tail launch per pipeline chunk), "single_tail" (0: one tail launch per pipeline chunk instead of one
+ * for the file), "first_chunk" (1/1000 of the super-frames in pipeline chunk 0; 0: built-in shares), "alt_streams" (block
+ * stages of odd and even pipeline chunks on two streams: 0 never, 1 / 2 = default: whenever the file is cut into chunks),
  * "device_expand" (1 = default: block tables of certified partitions written on the device, sla_hip_launch_expand, the
- * host's copy following under the kernels; 0: host tables first) [SLA_HIP_EXPAND], "table_cache" (1 = default: the search
- * tables of a file without silence are kept for the next file of the same length and parameters) [SLA_HIP_TABLE_CACHE],
- * "prelaunch" (1 = default: short files queue the certified block kernels together with the searches, sized for the most
- * groups there can be, the kernels reading the number from the device), "one_stream" (1: a one-chunk file keeps search, block
- * stage and tail on one stream; measured slower, default 0),
- * "rice_lanes" (Rice parameter walk of the device pack: 0 = by the number of jobs, 1 = one lane per job, 2 = two-lane pipeline),
- * "upload24" (1 = default: pageable input of 17..24 significant bits crosses the bus as three bytes per sample; DESIGN
- * section 7 has the A/B) [SLA_HIP_UPLOAD24], "stream_piece" (samples per piece, all channels together; default 32 Mi; a file of fewer than two pieces is not
- * streamed), "stream_lanes" (worker lanes, 1..4, default 4).  After a streamed call the handle holds no analysis tables:
- * sla_hip_get_trace / sla_hip_pack / sla_hip_final_residual answer SLA_APIRESULT_PARAMETER_NOT_SET (NULL).
+ * host's copy following under the kernels; 0: host tables first), "table_cache" (1 = default: the search tables of a file --
+ * or batch -- without silence are kept for the next one of the same layout and parameters), "prelaunch" (1 = default: short
+ * files queue the certified block kernels together with the searches, sized for the most groups there can be, the kernels
+ * reading the number from the device), "one_stream" (1: a one-chunk file keeps search, block stage and tail on one stream;
+ * measured slower, default 0), "upload24" (1 = default: pageable input of 17..24 significant bits crosses the bus as three
+ * bytes per sample; DESIGN section 7 has the A/B).
+ * SLAEncoder_EncodeWhole of long files: "stream" (0: never streamed), "stream_piece" (samples per piece, all channels
+ * together; default 32 Mi; a file of fewer than two pieces is not streamed), "stream_lanes" (worker lanes, 1..4, default 4).
+ * After a streamed call the handle holds no analysis tables: sla_hip_get_trace / sla_hip_pack / sla_hip_final_residual answer
+ * SLA_APIRESULT_PARAMETER_NOT_SET (NULL).
  * Returns SLA_APIRESULT_INVALID_ARGUMENT for an unknown name or a value out of range. */
 int sla_hip_encoder_set_option(struct SLAEncoder* encoder, const char* name, double value);
 

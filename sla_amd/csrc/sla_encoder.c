@@ -59,7 +59,7 @@ struct SLAEncoder {
   hipStream_t stream_up, stream_down;            /* descriptor uploads / result downloads: kept off the kernel streams */
   hipEvent_t  ev[2 + 8 * 20];       /* prepass pair + MAX_CHUNKS x EV_PER_CHUNK (checked below) */
   uint32_t chunks;
-  uint32_t split[8], split_count, chunk_cut[9];   /* relative chunk sizes (SLA_HIP_CHUNK_SPLIT="1,3,1"), boundaries of this run */
+  uint32_t split[8], split_count, chunk_cut[9];   /* relative chunk sizes (none set: the built-in shares), boundaries of this run */
   int      fuse_lattice;            /* 1: the lattice runs inside k_lpc_blocks (SLA_HIP_LATTICE=fused), 0: separate k_lattice launch */
   int      device_plan;             /* 1: code lengths + Dijkstra on the device where certified (default), 0: host only */
   int      search_exact;            /* 1: tile-sum search where it is provably bit-exact (default), 0: chains only */
@@ -233,7 +233,7 @@ struct slai_pool {
   uint32_t busy;                     /* atomic: workers that have not finished the current generation */
 };
 
-static uint32_t g_pool_spins = 8000u;       /* pause instructions before an idle worker sleeps (SLA_HIP_POOL_SPINS, read in SLAEncoder_Create) */
+static const uint32_t g_pool_spins = 8000u; /* pause instructions before an idle worker sleeps */
 #define POOL_SPINS g_pool_spins
 
 static void pool_drain(struct slai_pool* p)
@@ -350,98 +350,37 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   if (hipGetDeviceProperties(&prop, e->device) == hipSuccess) {
     snprintf(g_device_name, sizeof(g_device_name), "%.160s (%.80s)", prop.name, prop.gcnArchName);
   }
-  /* (SLA_HIP_STREAM_ORDER=1 creates them in the opposite order: an experiment behind option "one_stream") */
-  if ((getenv("SLA_HIP_STREAM_ORDER") != NULL && hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess)
-      || (getenv("SLA_HIP_STREAM_ORDER") != NULL && hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess)
-      || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess
-      || (e->stream2 == NULL && hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess)
-      || (e->stream3 == NULL && hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess)) { goto fail; }
-  if (getenv("SLA_HIP_COPY_STREAMS") != NULL && atoi(getenv("SLA_HIP_COPY_STREAMS")) == 0) {   /* debugging: copies back on the kernel stream */
-    e->stream_up = e->stream2; e->stream_down = e->stream2; e->own_copy_streams = 0;
-  } else {
-    if (hipStreamCreateWithFlags(&e->stream_up, hipStreamNonBlocking) != hipSuccess
-        || hipStreamCreateWithFlags(&e->stream_down, hipStreamNonBlocking) != hipSuccess) { goto fail; }
-    e->own_copy_streams = 1;
-  }
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess
+      || hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess
+      || hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess
+      || hipStreamCreateWithFlags(&e->stream_up, hipStreamNonBlocking) != hipSuccess
+      || hipStreamCreateWithFlags(&e->stream_down, hipStreamNonBlocking) != hipSuccess) { goto fail; }
+  e->own_copy_streams = 1;
   for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { if (hipEventCreate(&e->ev[i]) != hipSuccess) { goto fail; } }
   if (hipEventCreate(&e->ev_stage[0]) != hipSuccess || hipEventCreate(&e->ev_stage[1]) != hipSuccess
       || hipEventCreate(&e->ev_prep) != hipSuccess) { goto fail; }
   for (i = 0; i < 4; i++) { if (hipEventCreate(&e->ev_pack[i]) != hipSuccess) { goto fail; } }
-  /* every knob is read here, once; sla_hip_encoder_set_option changes them afterwards */
-  /* two chunks of 25 % / 75 % that share one k_tail (the figures are at the chunk cuts in run_pipeline) */
+  /* the defaults of every knob; sla_hip_encoder_set_option changes them afterwards.  Nothing but SLA_HIP_TRACE comes from the
+   * environment (rounds 1 - 3 read some thirty variables here) */
+  /* two chunks of 25 % / 75 % that share one tail launch (the figures are at the chunk cuts in run_pipeline) */
   e->chunks = 2;
   e->alt_streams = 2;
   e->single_tail = 1;
   e->device_ltm = 1;
-  env = getenv("SLA_HIP_LTM");
-  if (env != NULL) { e->device_ltm = (strcmp(env, "host") != 0); }
-  env = getenv("SLA_HIP_ALT_STREAMS");
-  if (env != NULL && atoi(env) >= 0 && atoi(env) <= 2) { e->alt_streams = atoi(env); }
-  env = getenv("SLA_HIP_SINGLE_TAIL");
-  if (env != NULL) { e->single_tail = (atoi(env) != 0); }
-  env = getenv("SLA_HIP_CHUNKS");
-  if (env != NULL && atoi(env) > 0) { e->chunks = (uint32_t)atoi(env); e->chunks_forced = 1; }
-  env = getenv("SLA_HIP_CHUNK_SPLIT");
-  if (env != NULL) {
-    const char* q = env;
-    while (*q != '\0' && e->split_count < 8) {
-      const long v = strtol(q, (char**)&q, 10);
-      if (v <= 0) { e->split_count = 0; break; }
-      e->split[e->split_count++] = (uint32_t)v;
-      if (*q == ',') { q++; }
-    }
-    if (e->split_count > 0) { e->chunks = e->split_count; }
-  }
   e->search_exact = 1; e->exact_bits = 53; e->device_plan = 1; e->cert_safety = 64.0;
   e->block_cert = 1; e->block_cert_safety = 16.0;
   e->table_cache = 1;
-  env = getenv("SLA_HIP_TABLE_CACHE");
-  if (env != NULL) { e->table_cache = (atoi(env) != 0); }
   e->prelaunch = 1;
   e->device_expand = 1;
-  env = getenv("SLA_HIP_EXPAND");
-  if (env != NULL) { e->device_expand = (atoi(env) != 0); }
   e->upload24 = 1;      /* profiles/r3_pack24_ab_*.json: plain path +13 % (C3) / +15 % (C5) from pageable memory, streamed path +1..3 % */
-  env = getenv("SLA_HIP_BLOCK_CERT");
-  if (env != NULL && atof(env) >= 0.0) { e->block_cert = (atof(env) != 0.0); if (atof(env) >= 16.0) { e->block_cert_safety = atof(env); } }
   e->stream_mode = 1; e->stream_piece = 32u << 20; e->stream_lanes = 4;
-  env = getenv("SLA_HIP_STREAM");
-  if (env != NULL) { e->stream_mode = (atoi(env) != 0); }
   /* measured on C2: the lattice inside k_lpc_blocks costs 0.6 ms per step (9 wave-chunks on the 8 waves of a workgroup
    * that has nothing else left to overlap them with), its own launch 0.27 ms: separate by default */
   e->fuse_lattice = 0;
-  env = getenv("SLA_HIP_LATTICE");
-  if (env != NULL && strcmp(env, "fused") == 0) { e->fuse_lattice = 1; }
-  env = getenv("SLA_HIP_LPC_BLOCKS");
-  if (env != NULL && strcmp(env, "chains") == 0) { e->fuse_lattice = 0; e->tune.lpc_blocks_chains = 1; }
-  env = getenv("SLA_HIP_PLAN");
-  if (env != NULL && strcmp(env, "host") == 0) { e->device_plan = 0; }
-  env = getenv("SLA_HIP_SEARCH");
-  if (env != NULL && strcmp(env, "chain") == 0) { e->search_exact = 0; }
-  env = getenv("SLA_HIP_CERT");
-  if (env != NULL && (atof(env) == 0.0 || atof(env) >= 64.0)) { e->cert_safety = atof(env); }
-  env = getenv("SLA_HIP_EXACT_BITS");
-  if (env != NULL && atoi(env) > 0 && atoi(env) <= 53) { e->exact_bits = atoi(env); }
-  env = getenv("SLA_HIP_PLAN_COPY");
-  e->plan_copy_down = (env != NULL && strcmp(env, "down") == 0);
-  e->trace = (getenv("SLA_HIP_TRACE") != NULL);
-  env = getenv("SLA_HIP_POOL_SPINS");
-  if (env != NULL && atoi(env) >= 0) { g_pool_spins = (uint32_t)atoi(env); }
+  e->plan_copy_down = 0;
+  env = getenv("SLA_HIP_TRACE");
+  e->trace = (env != NULL);
   g_trace_on = e->trace;
-  env = getenv("SLA_HIP_LPC_PACK");
-  if (env != NULL && atoi(env) >= 1) { e->tune.lpc_pack = (uint32_t)atoi(env); }
-  env = getenv("SLA_HIP_UPLOAD24");
-  if (env != NULL) { e->upload24 = (atoi(env) != 0); }
-  env = getenv("SLA_HIP_TAIL_LANES");
-  if (env != NULL && atoi(env) >= 0 && atoi(env) <= 6) { e->tune.tail_lanes = (uint32_t)atoi(env); }
-  env = getenv("SLA_HIP_ACF");
-  if (env != NULL && strcmp(env, "classic") == 0) { e->tune.acf_classic = 1; }
-  env = getenv("SLA_HIP_LPC_THREADS");
-  if (env != NULL && (atoi(env) == 256 || atoi(env) == 512)) { e->tune.lpc_threads = (uint32_t)atoi(env); }
-  env = getenv("SLA_HIP_TAIL_WAVES");
-  if (env != NULL && atoi(env) >= 1 && atoi(env) <= 4) { e->tune.tail_waves = (uint32_t)atoi(env); }
-  env = getenv("SLA_HIP_PLAN_MARGIN");
-  if (env != NULL && atof(env) >= 1e-4) { e->tune.plan_margin = atof(env); }
   if (hipHostMalloc((void**)&e->h_or, 4096, hipHostMallocDefault) != hipSuccess) { e->h_or = NULL; goto fail; }   /* [0,1] prepass words, [2] rerun counter, +64 B: kernel spans */
   {
     uint32_t fft = 1;
@@ -451,14 +390,10 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
     if (e->fft == NULL) { goto fail; }
   }
   {
-    /* host pool: the CPUs this process may use, shared with the other ranks of a one-process-per-GPU launch */
+    /* host pool: the CPUs this process may use (a launcher of several ranks on few cores sets option "threads") */
     cpu_set_t set;
-    uint32_t ranks = 1;
     e->threads = (uint32_t)sysconf(_SC_NPROCESSORS_ONLN);
     if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0 && (uint32_t)CPU_COUNT(&set) < e->threads) { e->threads = (uint32_t)CPU_COUNT(&set); }
-    env = getenv("LOCAL_WORLD_SIZE");
-    if (env != NULL && atoi(env) > 1) { ranks = (uint32_t)atoi(env); }
-    e->threads /= ranks;
   }
   if (e->threads < 1) { e->threads = 1; }
   /* The loops are short: more workers only add wake-up and join time.  Six, and a short spin before an idle worker sleeps:
@@ -467,8 +402,6 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
    * whole process is throttled for the rest of the period -- 4 - 10 ms stalls in 1.3 ms steps (tests/tools/step_jitter.py).
    * The steps themselves do not notice: C2 1.32 ms, C3-600 s 2.48, C5-120 s 4.77 with 4, 6 or 10 workers. */
   if (e->threads > 6) { e->threads = 6; }
-  env = getenv("SLA_HIP_THREADS");
-  if (env != NULL && atoi(env) > 0) { e->threads = (uint32_t)atoi(env); }
   e->pool = pool_create(e->threads);
   if (e->pool == NULL) { goto fail; }
   e->win_type = (SLAWindowFunctionType)-1;
@@ -657,6 +590,7 @@ typedef struct {
   int spec;                                       /* the searches are in flight on a guess of the prepass result */
   int prelaunched;                                /* chunk 0's certified block kernels were queued with the searches (device-side count) */
   int clear_in_kernel;                            /* spans, rerun counter and k_expand's numbers are cleared by the first search kernel */
+  uint32_t* clear_ptr[3]; uint32_t clear_words[3]; /* ... these words: handed to the first search launch (sla_hip_launch_extra), then NULL */
   int one_stream;                                 /* one chunk on device tables: search, block stage and tail on ONE stream (no
                                                    * cross-queue event waits between them: 10 - 20 us each on the critical path) */
   hipStream_t tail_stream;                        /* the stream the last tail kernel was put on */
@@ -1308,9 +1242,15 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
        * flags the rest, which plan_chunk reruns as serial chains.  Without the device plan (or with the certificate
        * switched off) they are flagged at once and take the chains here, without a host round trip. */
       const double cert = e->device_plan ? e->cert_safety : 0.0;
-      RCCHK(sla_hip_launch_search_exact(e->pcm_dev, e->stride, ms, order, dx, nx, a->max_window, a->max_xcands, (const sla_hip_lpc_cand*)e->d_cands.ptr,
-                                        (double*)e->d_tile_sums.ptr + (size_t)k->xg_lo * SLA_HIP_XTILES * 2 * sla_hip_search_exact_lags(order),
-                                        (double*)e->d_lpc_out.ptr, limit, cert, (uint32_t*)e->d_or.ptr + 8 + c, e->stream));
+      sla_hip_launch_extra xs;
+      memset(&xs, 0, sizeof(xs));
+      if (a->clear_in_kernel && a->clear_ptr[0] != NULL) {      /* words this analysis wants zeroed before its kernels use them: once */
+        int q;
+        for (q = 0; q < 3; q++) { xs.clear_ptr[q] = a->clear_ptr[q]; xs.clear_words[q] = a->clear_words[q]; a->clear_ptr[q] = NULL; }
+      }
+      RCCHK(sla_hip_launch_search_exact_x(e->pcm_dev, e->stride, ms, order, dx, nx, a->max_window, a->max_xcands, (const sla_hip_lpc_cand*)e->d_cands.ptr,
+                                          (double*)e->d_tile_sums.ptr + (size_t)k->xg_lo * SLA_HIP_XTILES * 2 * sla_hip_search_exact_lags(order),
+                                          (double*)e->d_lpc_out.ptr, limit, cert, (uint32_t*)e->d_or.ptr + 8 + c, e->stream, &xs));
       if (!(cert > 0.0))
       RCCHK(sla_hip_launch_lpc_rerun(e->pcm_dev, e->stride, ms, order, (const sla_hip_lpc_group*)e->d_groups.ptr + k->grp_lo, ng,
                                      a->max_window, a->max_cpg, (const sla_hip_lpc_cand*)e->d_cands.ptr, (double*)e->d_lpc_out.ptr,
@@ -1344,7 +1284,7 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
                                     e->expand_seq, e->stream));
         HIPCHK(hipEventRecord(ev[EV_EXPANDED], e->stream));
         /* Short files: the first two kernels of the block stage go out right here, sized for the most groups the chunk can
-         * have and reading the number from the device (slai_next_launch_count) -- the device starts on them the moment the
+         * have and reading the number from the device (sla_hip_launch_extra.d_group_count) -- the device starts on them the moment the
          * tables are written instead of 40 - 50 us later, when the host has seen the counts and made its first launches;
          * by then it only has to queue the lattice behind them.  (Long files: their idle workgroups would cost more.) */
         a->prelaunched = 0;
@@ -1354,14 +1294,15 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
           const hipStream_t ps = a->one_stream ? e->stream : e->stream2;      /* the stream blocks_launch will continue on */
           HIPCHK(hipStreamWaitEvent(ps, ev[EV_EXPANDED], 0));
           HIPCHK(hipEventRecord(ev[EV_LPCB_S], ps));
-          slai_next_launch_span(SPAN_SLOT(e, c, 0));
-          slai_next_launch_count((const uint32_t*)e->d_run.ptr);
-          RCCHK(sla_hip_launch_lpc_blocks_cert(e->pcm_dev, e->stride, ms2, order, (const sla_hip_lpc_group*)e->d_bgroups.ptr, a->blocks_bound * C,
-                                               a->max_window, (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
-                                               (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
-                                               (uint32_t*)e->d_rshift.ptr, (uint32_t*)e->d_cert_flag.ptr,
-                                               (uint32_t*)e->d_fb_list.ptr, (uint32_t*)e->d_fb_count.ptr + c,
-                                               e->block_cert_safety, bps, ps));
+          sla_hip_launch_extra xt;
+          memset(&xt, 0, sizeof(xt));
+          xt.d_span = SPAN_SLOT(e, c, 0); xt.d_group_count = (const uint32_t*)e->d_run.ptr;
+          RCCHK(sla_hip_launch_lpc_blocks_cert_x(e->pcm_dev, e->stride, ms2, order, (const sla_hip_lpc_group*)e->d_bgroups.ptr, a->blocks_bound * C,
+                                                 a->max_window, (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
+                                                 (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
+                                                 (uint32_t*)e->d_rshift.ptr, (uint32_t*)e->d_cert_flag.ptr,
+                                                 (uint32_t*)e->d_fb_list.ptr, (uint32_t*)e->d_fb_count.ptr + c,
+                                                 e->block_cert_safety, bps, ps, &xt));
           HIPCHK(hipEventRecord(ev[EV_LPCB_E], ps));
           a->prelaunched = 1;
         }
@@ -1475,8 +1416,10 @@ static int tail_enqueue(struct SLAEncoder* e, actx_t* a, uint32_t c, uint32_t lo
   HIPCHK(hipEventRecord(ev[EV_TAIL_S], ts));
   if (hi > lo) {
     sla_hip_tail_job* dj = (sla_hip_tail_job*)e->d_jobs.ptr + lo;
-    slai_next_launch_span(SPAN_SLOT(e, c, 3));
-    RCCHK(sla_hip_launch_tail(RES1(e), RES2(e), e->stride, dj, hi - lo, ntaps, lms, (uint64_t*)e->d_fold.ptr + lo, ts));
+    sla_hip_launch_extra xt;
+    memset(&xt, 0, sizeof(xt));
+    xt.d_span = SPAN_SLOT(e, c, 3);
+    RCCHK(sla_hip_launch_tail_x(RES1(e), RES2(e), e->stride, dj, hi - lo, ntaps, lms, (uint64_t*)e->d_fold.ptr + lo, ts, &xt));
   }
   HIPCHK(hipEventRecord(ev[EV_TAIL_E], ts));
   if (hi > lo) {
@@ -1575,30 +1518,30 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c, int mode)
     } else {
       HIPCHK(hipStreamWaitEvent(bs, ev[EV_EXPANDED], 0));      /* the tables were written on the search stream */
     }
-    if (!pre) {
-      HIPCHK(hipEventRecord(ev[EV_LPCB_S], bs));
-      slai_next_launch_span(SPAN_SLOT(e, c, 0));
-    }
+    sla_hip_launch_extra xb;                     /* the block stage's launch records its execution span in slot 0 */
+    memset(&xb, 0, sizeof(xb));
+    xb.d_span = SPAN_SLOT(e, c, 0);
+    if (!pre) { HIPCHK(hipEventRecord(ev[EV_LPCB_S], bs)); }
     if (fused) {
-      RCCHK(sla_hip_launch_lpc_blocks(e->pcm_dev, e->stride, ms, order, dg, ng, max_window,
-                                      (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
-                                      (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
-                                      (uint32_t*)e->d_rshift.ptr, RES1(e), bs));
+      RCCHK(sla_hip_launch_lpc_blocks_x(e->pcm_dev, e->stride, ms, order, dg, ng, max_window,
+                                        (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
+                                        (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
+                                        (uint32_t*)e->d_rshift.ptr, RES1(e), bs, &xb));
     } else if (pre) {
       /* queued with the searches (search_launch), events and span slot included */
     } else if (use_cert) {
       /* any-order autocorrelation + certified quantiser; what does not certify goes through the exact kernels behind it */
-      RCCHK(sla_hip_launch_lpc_blocks_cert(e->pcm_dev, e->stride, ms, order, dg, ng, max_window,
-                                           (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
-                                           (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
-                                           (uint32_t*)e->d_rshift.ptr, (uint32_t*)e->d_cert_flag.ptr,
-                                           (uint32_t*)e->d_fb_list.ptr + k->bg_lo, (uint32_t*)e->d_fb_count.ptr + c,
-                                           e->block_cert_safety, bps, bs));
+      RCCHK(sla_hip_launch_lpc_blocks_cert_x(e->pcm_dev, e->stride, ms, order, dg, ng, max_window,
+                                             (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
+                                             (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
+                                             (uint32_t*)e->d_rshift.ptr, (uint32_t*)e->d_cert_flag.ptr,
+                                             (uint32_t*)e->d_fb_list.ptr + k->bg_lo, (uint32_t*)e->d_fb_count.ptr + c,
+                                             e->block_cert_safety, bps, bs, &xb));
     } else {
-      RCCHK(sla_hip_launch_lpc(e->pcm_dev, e->stride, ms, order, dg, ng, max_window, 1,
-                               (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
-                               (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
-                               (uint32_t*)e->d_rshift.ptr, bs));
+      RCCHK(sla_hip_launch_lpc_x(e->pcm_dev, e->stride, ms, order, dg, ng, max_window, 1,
+                                 (const sla_hip_lpc_cand*)e->d_bcands.ptr, (const double*)e->d_winpool.ptr,
+                                 (double*)e->d_blk_out.ptr, (int32_t*)e->d_code.ptr, (int32_t*)e->d_kint.ptr,
+                                 (uint32_t*)e->d_rshift.ptr, bs, &xb));
     }
     if (!pre) { HIPCHK(hipEventRecord(ev[EV_LPCB_E], bs)); }
     /* pass 2 (k_lpc_blocks is running): lattice chunks and FFT jobs */
@@ -1621,16 +1564,16 @@ static int blocks_launch(struct SLAEncoder* e, actx_t* a, uint32_t c, int mode)
       HIPCHK(hipStreamWaitEvent(bs, ev[EV_UPLOADED2], 0));
     }
     if (!fused) {
-      slai_next_launch_span(SPAN_SLOT(e, c, 1));
-      RCCHK(sla_hip_launch_lattice_groups(e->pcm_dev, e->stride, ms, order, dg, ng, max_window, (const int32_t*)e->d_kint.ptr, RES1(e), bs));
+      xb.d_span = SPAN_SLOT(e, c, 1);
+      RCCHK(sla_hip_launch_lattice_groups_x(e->pcm_dev, e->stride, ms, order, dg, ng, max_window, (const int32_t*)e->d_kint.ptr, RES1(e), bs, &xb));
     }
     HIPCHK(hipEventRecord(ev[EV_LAT_E], bs));
     if (sizeof(double) * (size_t)fft_size > SLA_HIP_LDS_BUDGET) { slots = (ng < 512) ? ng : 512; }
     HIPCHK(hipEventRecord(ev[EV_ACF_S], bs));
-    slai_next_launch_span(SPAN_SLOT(e, c, 2));
-    RCCHK(sla_hip_launch_ltm_acf(RES1(e), e->stride, da, ng, fft_size, (const double*)e->d_twiddle.ptr,
-                                 (double*)e->d_acf_scratch.ptr, slots,
-                                 (double*)e->d_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD, SLAI_LTM_ACF_HEAD, bs));
+    xb.d_span = SPAN_SLOT(e, c, 2);
+    RCCHK(sla_hip_launch_ltm_acf_x(RES1(e), e->stride, da, ng, fft_size, (const double*)e->d_twiddle.ptr,
+                                   (double*)e->d_acf_scratch.ptr, slots,
+                                   (double*)e->d_acf.ptr + (size_t)k->bg_lo * SLAI_LTM_ACF_HEAD, SLAI_LTM_ACF_HEAD, bs, &xb));
     HIPCHK(hipEventRecord(ev[EV_ACF_E], bs));
     if (e->device_ltm) {
       /* pitch + taps into the job table k_tail reads; the tail follows on the same stream, no host in between */
@@ -1769,8 +1712,12 @@ static int tail_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
     PTRACE("tail: jobs built");
     HIPCHK(hipMemcpyAsync(dj, jobs + k->job_lo, sizeof(sla_hip_tail_job) * nj, hipMemcpyHostToDevice, e->stream3));
     HIPCHK(hipEventRecord(ev[EV_TAIL_S], e->stream3));
-    slai_next_launch_span(SPAN_SLOT(e, c, 3));
-    RCCHK(sla_hip_launch_tail(RES1(e), RES2(e), e->stride, dj, nj, ntaps, lms, (uint64_t*)e->d_fold.ptr + k->job_lo, e->stream3));
+    {
+      sla_hip_launch_extra xt;
+      memset(&xt, 0, sizeof(xt));
+      xt.d_span = SPAN_SLOT(e, c, 3);
+      RCCHK(sla_hip_launch_tail_x(RES1(e), RES2(e), e->stride, dj, nj, ntaps, lms, (uint64_t*)e->d_fold.ptr + k->job_lo, e->stream3, &xt));
+    }
     HIPCHK(hipEventRecord(ev[EV_TAIL_E], e->stream3));
     HIPCHK(hipMemcpyAsync((uint64_t*)e->h_fold.ptr + k->job_lo, (uint64_t*)e->d_fold.ptr + k->job_lo, sizeof(uint64_t) * nj, hipMemcpyDeviceToHost, e->stream3));
   } else {
@@ -1840,7 +1787,7 @@ static int launch_searches(struct SLAEncoder* e, actx_t* a, int preset_blocks, i
   /* the span slots are cleared on the search stream: every kernel that writes one is launched after the host has seen a
    * search of this run complete, i.e. behind this memset */
   /* (with the tile-sum search those words, the rerun counter and k_expand's running numbers are cleared by the first search
-   * kernel itself -- slai_next_launch_clear -- instead of by three fill kernels in front of it) */
+   * kernel itself -- sla_hip_launch_extra.clear_ptr -- instead of by three fill kernels in front of it) */
   a->clear_in_kernel = (!preset_blocks && a->exact);
   if (dev_reserve(&e->d_spans, sizeof(unsigned long long) * MAX_CHUNKS * 4 * 2) != 0
       || (!a->clear_in_kernel && hipMemsetAsync(e->d_spans.ptr, 0, sizeof(unsigned long long) * MAX_CHUNKS * 4 * 2, e->stream) != hipSuccess)
@@ -1906,8 +1853,10 @@ static int launch_searches(struct SLAEncoder* e, actx_t* a, int preset_blocks, i
 
   if (!preset_blocks) {
     if (a->clear_in_kernel) {
-      slai_next_launch_clear((uint32_t*)e->d_spans.ptr, MAX_CHUNKS * 4 * 2 * 2, (uint32_t*)e->d_or.ptr + 2, 1,
-                             a->expand ? (uint32_t*)e->d_run.ptr : NULL, 4);
+      /* (the first search launch of this analysis takes them along: search_launch, chunk 0) */
+      a->clear_ptr[0] = (uint32_t*)e->d_spans.ptr; a->clear_words[0] = MAX_CHUNKS * 4 * 2 * 2;
+      a->clear_ptr[1] = (uint32_t*)e->d_or.ptr + 2; a->clear_words[1] = 1;
+      a->clear_ptr[2] = a->expand ? (uint32_t*)e->d_run.ptr : NULL; a->clear_words[2] = 4;
     } else if (hipMemsetAsync((uint32_t*)e->d_or.ptr + 2, 0, sizeof(uint32_t), e->stream) != hipSuccess) { rc = SLA_APIRESULT_NG; }      /* groups rerun as serial chains */
     for (c = 0; c < a->nchunks && rc == 0; c++) { rc = search_launch(e, a, c); }
     TRACE("search launched", a->nchunks);
@@ -2128,11 +2077,10 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   else if (strcmp(name, "lpc_threads") == 0)       { if (iv != 0 && iv != 256 && iv != 512) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.lpc_threads = (uint32_t)iv; }
   else if (strcmp(name, "tail_waves") == 0)        { OPT_RANGE(0, 4); e->tune.tail_waves = (uint32_t)iv; }
   else if (strcmp(name, "lpc_tile") == 0)          { if (iv != 0 && iv != 24 && iv != 48) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.lpc_tile = (uint32_t)iv; }
-  else if (strcmp(name, "acf_classic") == 0)       { OPT_RANGE(0, 1); e->tune.acf_classic = (uint32_t)iv; }
   else if (strcmp(name, "rice_lanes") == 0)        { OPT_RANGE(0, 2); e->tune.rice_lanes = (uint32_t)iv; }
   else if (strcmp(name, "lattice_plain") == 0)     { OPT_RANGE(0, 1); e->tune.lattice_plain = (uint32_t)iv; }
   else if (strcmp(name, "cert_audit") == 0)        { OPT_RANGE(0, 1 << 30); e->tune.cert_audit = (uint32_t)iv; }
-  else if (strcmp(name, "tail_lanes") == 0)        { OPT_RANGE(0, 6); e->tune.tail_lanes = (uint32_t)iv; }
+  else if (strcmp(name, "tail_taps") == 0)         { if (iv != 0 && iv != 1 && iv != 2 && iv != 4) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.tail_taps = (uint32_t)iv; }
   else if (strcmp(name, "lpc_blocks_chains") == 0) { OPT_RANGE(0, 1); e->tune.lpc_blocks_chains = (uint32_t)iv; if (iv) { e->fuse_lattice = 0; } }
   /* the certification margins may only be widened: below the built-in values byte-identity is no longer guaranteed */
   else if (strcmp(name, "plan_margin") == 0)       { if (value != 0.0 && !(value >= 1e-4)) { return SLA_APIRESULT_INVALID_ARGUMENT; } e->tune.plan_margin = value; }

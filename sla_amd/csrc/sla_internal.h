@@ -45,12 +45,6 @@ int      slai_make_window(SLAWindowFunctionType type, double* w, uint32_t n);
 double   slai_code_length(double sumsq, uint32_t n, uint32_t bps, const double* parcor, uint32_t order);
 int      slai_shortest_path(const double* adj, uint32_t nodes, uint32_t* path);
 int      slai_host_check(void);       /* 0: long double / double arithmetic of this host is the reference build's */
-/* sla_kernels.hip: the next k_lpc_blocks / k_lattice / k_ltm_acf / k_tail launch of this thread records its
- * execution span (2 x u64, zero-initialised device memory: ~min start, max end in 100 MHz ticks) */
-void slai_next_launch_span(unsigned long long* d_span);
-void slai_next_launch_count(const uint32_t* d_run);
-void slai_next_launch_clear(uint32_t* a, uint32_t na, uint32_t* b, uint32_t nb, uint32_t* c, uint32_t nc);
-
 uint32_t slai_zero_run(const uint64_t* nz_mask, uint64_t from, uint64_t limit);
 int      slai_range_is_zero(const uint64_t* nz_mask, uint64_t from, uint64_t count);
 

@@ -2327,15 +2327,13 @@ void k_emphasis_f64(const double* __restrict__ in, double* __restrict__ out, uin
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_tail: long-term filter -> sign-log LMS -> folded sum.  The LMS is serial in time (every sample
-// updates all 2*ORDER coefficients from the error it just produced), so parallelism inside one
-// (block, channel) exists only ACROSS THE TAPS: a group of G = 2*ORDER lanes owns one job, lane t holds
-// one coefficient and one history value (t < ORDER: input history, else prediction history).  Per
-// sample: one 32-bit product per lane, a log2(G)-step DPP sum (wrapping int adds are associative, so
-// the tree equals the reference's serial sum), the error/step computed redundantly by every lane, one
-// multiply-add coefficient update per lane and a one-lane DPP shift of the history.  Samples are
-// fetched G at a time (lane t loads and long-term-filters sample s0+t: coalesced), handed to the
-// group through ds_bpermute, and the G errors are stored back coalesced.
+// Tail stage: long-term filter -> sign-log LMS -> folded sum (src/SLAPredictor.c:1031-1119, 1202-1331; src/SLACoder.c:361-385).
+// The LMS is serial in time (every sample updates all 2 * ORDER coefficients from the error it just produced), so the
+// parallelism inside one (block, channel) job exists only ACROSS THE TAPS: a few lanes own one job, each K taps of the input
+// history and K of the prediction history; per sample the lanes' products meet in a DPP sum (wrapping int adds are
+// associative, so the tree equals the reference's serial sum), the error and the step are computed redundantly by every
+// lane of the job, and the histories move on by one DPP shift.  (Rounds 1 - 3 kept three earlier layouts -- 2 * ORDER
+// lanes, ORDER lanes, ONE lane per job -- behind an option; k_tailk beat all of them at every job count)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int32_t sgn(int32_t v)          // clamp to [-1, 1] = sign, one v_med3_i32
 {
@@ -2356,246 +2354,6 @@ template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t x)
 {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, true);
-}
-
-template <int G>
-__device__ __forceinline__ uint32_t group_sum(uint32_t x)
-{
-  x += dpp_u32<0xB1>(x);                       // quad_perm [1,0,3,2]   lane ^ 1
-  x += dpp_u32<0x4E>(x);                       // quad_perm [2,3,0,1]   lane ^ 2
-  if (G >= 8) { x += dpp_u32<0x141>(x); }      // row_half_mirror       other quad of the 8
-  if (G >= 16) { x += dpp_u32<0x140>(x); }     // row_mirror            other half of the 16
-  if (G >= 32) { x += (uint32_t)__shfl_xor((int)x, 16); }
-  if (G >= 64) { x += (uint32_t)__shfl_xor((int)x, 32); }
-  return x;
-}
-
-// G consecutive samples of one job group.  FIRST: this is the block that starts at sample 0, whose first
-// ORDER samples only prime both histories (src/SLAPredictor.c:1233-1255); u is a compile-time constant
-// after unrolling, so the priming steps cost nothing in the steady-state instantiation.
-template <int ORDER, bool FIRST>
-__device__ __forceinline__ int32_t tail_block(int32_t v_mine, uint32_t grp_base, bool is_fir_head, bool is_iir_head,
-                                              uint32_t t, int32_t& coef, int32_t& h)
-{
-  constexpr int G = 2 * ORDER;
-  int32_t e_mine = 0;
-  // the G inputs of the block: all requested up front, so no step of the serial chain waits for the LDS crossbar
-  int32_t vs[G];
-#pragma unroll
-  for (int u = 0; u < G; u++) { vs[u] = __shfl(v_mine, (int)(grp_base + u)); }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int u = 0; u < G; u++) {
-    const int32_t v = vs[u];
-    int32_t e, ph;
-    if (FIRST && u < ORDER) {
-      e = v; ph = v;
-    } else {
-      // The chain coef -> sum -> p -> e -> |e| -> log -> coef is what bounds the kernel (one wave per SIMD): e and
-      // -e are formed side by side, the sign product does not wait for the logarithm, and step * sign goes
-      // through the full-rate 24-bit multiply-add (|step| <= 16).
-      const int32_t sh = sgn(h);
-      const uint32_t sum = group_sum<G>((uint32_t)coef * (uint32_t)h) + (1u << 9);
-      const int32_t p = (int32_t)sum >> 10;
-      e = (int32_t)((uint32_t)v - (uint32_t)p);
-      const int32_t ne = (int32_t)((uint32_t)p - (uint32_t)v);
-      const uint32_t mag = (uint32_t)max(e, ne);
-      const int32_t lg = 32 - (int32_t)__clz((int)mag);                    // ceil(log2(|e|+1)); __clz(0) = 32
-      const int32_t sign2 = __mul24(sgn(e), sh);                            // sign(e) * sign(h)
-      coef = mad24(sign2, lg >> 1, coef);                                   // step table src/SLAPredictor.c:123-144
-      ph = p;
-    }
-    // history: lane t takes lane t-1; the group's first FIR / IIR lane takes the new input / prediction
-    if (G == 16) {
-      // a group is exactly one DPP row: row_shr:1 leaves lane 0 of the row with `old`, which is the new input
-      h = (int32_t)__builtin_amdgcn_update_dpp(v, h, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
-      h = is_iir_head ? ph : h;
-    } else {
-      h = (int32_t)__builtin_amdgcn_update_dpp(h, h, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-      h = is_fir_head ? v : (is_iir_head ? ph : h);
-    }
-    e_mine = (t == (uint32_t)u) ? e : e_mine;
-  }
-  return e_mine;
-}
-
-template <int ORDER>
-__global__ __launch_bounds__(256)
-void k_tail(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, uint64_t stride,
-            const sla_hip_tail_job* __restrict__ jobs, uint32_t num_jobs, uint32_t ntaps,
-            uint64_t* __restrict__ fold_sum, unsigned long long* span, uint32_t stage_flags)
-{
-  span_begin(span);
-  constexpr int G = 2 * ORDER;                 // lanes per job
-  constexpr int JPW = 64 / G;                  // jobs per wave
-  const uint32_t lane = threadIdx.x & 63;
-  const uint32_t t = lane & (G - 1);
-  const uint32_t grp_base = lane - t;
-  const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const uint32_t j = wave * JPW + (lane / G);
-  const bool have = (j < num_jobs);
-  const sla_hip_tail_job job = jobs[have ? j : 0];
-  const uint32_t n = have ? job.blk_len : 0;
-  const int32_t* in = res_in + (uint64_t)job.channel * stride + job.blk_off;
-  int32_t* out = res_out + (uint64_t)job.channel * stride + job.blk_off;
-  const uint32_t delay = job.pitch + (ntaps >> 1);
-  const bool use_ltm = (job.pitch >= 3);
-  const bool short_job = (n < (uint32_t)ORDER);      // fewer samples than taps: everything passes through
-  const bool is_fir_head = (t == 0), is_iir_head = (t == (uint32_t)ORDER);
-  const uint32_t nmax = umax_wave(n);
-
-  // lane t fetches sample s0+t and applies the long-term stage to it   src/SLAPredictor.c:1063-1099
-  auto fetch = [&](uint32_t s) -> int32_t {
-    int32_t v = 0;
-    if (s < n) {
-      v = in[s];
-      if (use_ltm && s >= delay) {
-        int64_t acc = (int64_t)1 << 30;
-        for (uint32_t k = 0; k < ntaps; k++) { acc += (int64_t)job.ltm_coef[k] * (int64_t)in[s - delay + k]; }
-        v = (int32_t)((uint32_t)v - (uint32_t)(int32_t)(acc >> 31));
-      }
-    }
-    return v;
-  };
-
-  int32_t coef = 0, h = 0;
-  uint64_t fsum = 0;
-  int32_t v_next = fetch(t);
-  for (uint32_t s0 = 0; s0 < nmax; s0 += G) {
-    const int32_t v_mine = v_next;
-    v_next = fetch(s0 + G + t);                      // next block's samples travel while this one computes
-    int32_t e_mine = (s0 == 0) ? tail_block<ORDER, true>(v_mine, grp_base, is_fir_head, is_iir_head, t, coef, h)
-                               : tail_block<ORDER, false>(v_mine, grp_base, is_fir_head, is_iir_head, t, coef, h);
-    e_mine = (short_job || (stage_flags & 1u)) ? v_mine : e_mine;      // stage_flags bit 0: no LMS stage (per-call API)
-    const uint32_t s = s0 + t;
-    if (s < n) {
-      out[s] = e_mine;
-      fsum += (e_mine < 0) ? ~((uint32_t)e_mine << 1) : ((uint32_t)e_mine << 1);   // zig-zag fold, src/SLAUtility.h:37
-    }
-  }
-  // sum of the lanes' partial folded sums
-#pragma unroll
-  for (int off = 1; off < G; off <<= 1) {
-    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)fsum, off);
-    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(fsum >> 32), off);
-    fsum += ((uint64_t)hi << 32) | lo;
-  }
-  if (have && t == 0) { fold_sum[j] = fsum; }
-  span_end(span);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_tail2: the same stage with TWO coefficients per lane.  The cascade is 2*ORDER taps -- ORDER on the input history,
-// ORDER on the prediction history -- that differ only in what is shifted into their history; a lane owns tap t of both
-// halves, so a job takes ORDER lanes and a wave carries twice as many jobs.  The kernel is bound by instruction issue
-// (k_tail: ~25 instructions per sample and wave, 1.7 - 7 waves per SIMD on the bench configurations), and the second
-// tap costs a lane 5 instructions more (product, two sign products, update, history shift) while it saves the other
-// wave's 25 -- and one step of the DPP sum.
-// ---------------------------------------------------------------------------------------------
-template <int ORDER, bool FIRST>
-__device__ __forceinline__ int32_t tail_block2(int32_t v_mine, uint32_t grp_base, bool is_head, uint32_t t,
-                                               int32_t& ca, int32_t& cb, int32_t& ha, int32_t& hb)
-{
-  constexpr int G = ORDER;
-  int32_t e_mine = 0;
-  int32_t vs[G];
-#pragma unroll
-  for (int u = 0; u < G; u++) { vs[u] = __shfl(v_mine, (int)(grp_base + u)); }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int u = 0; u < G; u++) {
-    const int32_t v = vs[u];
-    int32_t e, ph;
-    if (FIRST) {
-      e = v; ph = v;                                   // the first ORDER samples only prime both histories
-    } else {
-      const int32_t sa = sgn(ha), sb = sgn(hb);
-      const uint32_t sum = group_sum<G>((uint32_t)ca * (uint32_t)ha + (uint32_t)cb * (uint32_t)hb) + (1u << 9);
-      const int32_t p = (int32_t)sum >> 10;
-      e = (int32_t)((uint32_t)v - (uint32_t)p);
-      const int32_t ne = (int32_t)((uint32_t)p - (uint32_t)v);
-      const uint32_t mag = (uint32_t)max(e, ne);
-      const int32_t lg = 32 - (int32_t)__clz((int)mag);
-      const int32_t se = sgn(e);
-      ca = mad24(__mul24(se, sa), lg >> 1, ca);
-      cb = mad24(__mul24(se, sb), lg >> 1, cb);
-      ph = p;
-    }
-    // histories: lane t takes lane t-1; the job's first lane takes the new input / the new prediction
-    if (G <= 16) {
-      ha = (int32_t)__builtin_amdgcn_update_dpp(v, ha, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
-      hb = (int32_t)__builtin_amdgcn_update_dpp(ph, hb, 0x111, 0xF, 0xF, false);
-    } else {
-      ha = (int32_t)__builtin_amdgcn_update_dpp(v, ha, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-      hb = (int32_t)__builtin_amdgcn_update_dpp(ph, hb, 0x138, 0xF, 0xF, false);
-    }
-    if (G != 16) { ha = is_head ? v : ha; hb = is_head ? ph : hb; }      // (a 16-lane job is one DPP row: its lane 0 got `old`)
-    e_mine = (t == (uint32_t)u) ? e : e_mine;
-  }
-  return e_mine;
-}
-
-template <int ORDER>
-__global__ __launch_bounds__(256)
-void k_tail2(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, uint64_t stride,
-             const sla_hip_tail_job* __restrict__ jobs, uint32_t num_jobs, uint32_t ntaps,
-             uint64_t* __restrict__ fold_sum, unsigned long long* span, uint32_t stage_flags)
-{
-  span_begin(span);
-  constexpr int G = ORDER;                     // lanes per job
-  constexpr int JPW = 64 / G;                  // jobs per wave
-  const uint32_t lane = threadIdx.x & 63;
-  const uint32_t t = lane & (G - 1);
-  const uint32_t grp_base = lane - t;
-  const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const uint32_t j = wave * JPW + (lane / G);
-  const bool have = (j < num_jobs);
-  const sla_hip_tail_job job = jobs[have ? j : 0];
-  const uint32_t n = have ? job.blk_len : 0;
-  const int32_t* in = res_in + (uint64_t)job.channel * stride + job.blk_off;
-  int32_t* out = res_out + (uint64_t)job.channel * stride + job.blk_off;
-  const uint32_t delay = job.pitch + (ntaps >> 1);
-  const bool use_ltm = (job.pitch >= 3);
-  const bool short_job = (n < (uint32_t)ORDER);      // fewer samples than taps: everything passes through
-  const bool is_head = (t == 0);
-  const uint32_t nmax = umax_wave(n);
-
-  auto fetch = [&](uint32_t s) -> int32_t {          // src/SLAPredictor.c:1063-1099
-    int32_t v = 0;
-    if (s < n) {
-      v = in[s];
-      if (use_ltm && s >= delay) {
-        int64_t acc = (int64_t)1 << 30;
-        for (uint32_t k = 0; k < ntaps; k++) { acc += (int64_t)job.ltm_coef[k] * (int64_t)in[s - delay + k]; }
-        v = (int32_t)((uint32_t)v - (uint32_t)(int32_t)(acc >> 31));
-      }
-    }
-    return v;
-  };
-
-  int32_t ca = 0, cb = 0, ha = 0, hb = 0;
-  uint64_t fsum = 0;
-  int32_t v_next = fetch(t);
-  for (uint32_t s0 = 0; s0 < nmax; s0 += G) {
-    const int32_t v_mine = v_next;
-    v_next = fetch(s0 + G + t);
-    int32_t e_mine = (s0 == 0) ? tail_block2<ORDER, true>(v_mine, grp_base, is_head, t, ca, cb, ha, hb)
-                               : tail_block2<ORDER, false>(v_mine, grp_base, is_head, t, ca, cb, ha, hb);
-    e_mine = (short_job || (stage_flags & 1u)) ? v_mine : e_mine;
-    const uint32_t s = s0 + t;
-    if (s < n) {
-      out[s] = e_mine;
-      fsum += (e_mine < 0) ? ~((uint32_t)e_mine << 1) : ((uint32_t)e_mine << 1);
-    }
-  }
-#pragma unroll
-  for (int off = 1; off < G; off <<= 1) {
-    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)fsum, off);
-    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(fsum >> 32), off);
-    fsum += ((uint64_t)hi << 32) | lo;
-  }
-  if (have && t == 0) { fold_sum[j] = fsum; }
-  span_end(span);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2831,137 +2589,6 @@ void k_tailk(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, 
   span_end(span);
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_tail1: the same stage with ONE LANE per job -- for files with tens of thousands of (block, channel) jobs.  k_tail
-// and k_tail2 spread a job's taps over 8 - 16 lanes to shorten the serial chain per sample, which is what a short file
-// needs (its duration is one block's chain); a long file has more jobs than the chip has lanes, and then what counts is
-// instructions per job and sample: ~25 per 4 - 8 jobs there, ~70 per 64 jobs here (2*ORDER products and as many
-// sign-step updates, all in registers: ORDER samples are unrolled so that the histories' ring positions are static
-// register indices).  A lane walks its own block: it fetches ORDER consecutive samples (and the long-term window
-// behind them) per step, one step ahead of the arithmetic.
-// ---------------------------------------------------------------------------------------------
-template <int ORDER, bool FIRST>
-__device__ __forceinline__ void tail1_block(const int32_t (&vs)[ORDER], int32_t (&es)[ORDER], int32_t (&cf)[ORDER], int32_t (&ci)[ORDER],
-                                            int32_t (&hf)[ORDER], int32_t (&hi)[ORDER], int32_t (&sf)[ORDER], int32_t (&si)[ORDER])
-{
-#pragma unroll
-  for (int u = 0; u < ORDER; u++) {
-    const int32_t v = vs[u];
-    int32_t e, ph;
-    if (FIRST) {
-      e = v; ph = v;                                   // the first ORDER samples only prime both histories  src/SLAPredictor.c:1233-1255
-    } else {
-      // the element of age i sits in slot (i - u) mod ORDER at step u of the unrolled block
-      uint32_t sum = 1u << 9;
-#pragma unroll
-      for (int i = 0; i < ORDER; i++) {
-        const int slot = (i - u + ORDER) % ORDER;
-        sum += (uint32_t)cf[i] * (uint32_t)hf[slot];
-        sum += (uint32_t)ci[i] * (uint32_t)hi[slot];
-      }
-      const int32_t p = (int32_t)sum >> 10;
-      e = (int32_t)((uint32_t)v - (uint32_t)p);
-      const int32_t ne = (int32_t)((uint32_t)p - (uint32_t)v);
-      const uint32_t mag = (uint32_t)max(e, ne);
-      const int32_t lg = 32 - (int32_t)__clz((int)mag);                    // ceil(log2(|e|+1)); __clz(0) = 32
-      const int32_t step = __mul24(sgn(e), lg >> 1);                       // step table src/SLAPredictor.c:123-144 times sign(e)
-#pragma unroll
-      for (int i = 0; i < ORDER; i++) {
-        const int slot = (i - u + ORDER) % ORDER;
-        cf[i] = mad24(step, sf[slot], cf[i]);
-        ci[i] = mad24(step, si[slot], ci[i]);
-      }
-      ph = p;
-    }
-    const int put = (ORDER - 1 - u + ORDER) % ORDER;   // the oldest element's slot takes the new one
-    hf[put] = v; sf[put] = sgn(v);
-    hi[put] = ph; si[put] = sgn(ph);
-    es[u] = e;
-  }
-}
-
-// A lane that walked its own block through global memory touched 64 different cache lines per load or store instruction
-// (measured: twice as slow as k_tail2).  So the wave moves the samples as tiles: T1_TILE samples of each of its 64 jobs
-// per step, fetched row by row with all lanes on consecutive samples of one job (two jobs per instruction; the
-// long-term stage is applied on the way in, src/SLAPredictor.c:1063-1099), transposed through LDS -- row stride
-// T1_TILE + 1 words, so that both the row-wise fill and the lane-per-row walk are conflict-free -- and written back the
-// same way.
-#define T1_TILE 32
-#define T1_ROW (T1_TILE + 1)
-
-template <int ORDER>
-__global__ __launch_bounds__(64)
-void k_tail1(const int32_t* __restrict__ res_in, int32_t* __restrict__ res_out, uint64_t stride,
-             const sla_hip_tail_job* __restrict__ jobs, uint32_t num_jobs, uint32_t ntaps,
-             uint64_t* __restrict__ fold_sum, unsigned long long* span, uint32_t stage_flags)
-{
-  __shared__ int32_t t_in[64 * T1_ROW], t_out[64 * T1_ROW];
-  __shared__ sla_hip_tail_job s_job[64];
-  span_begin(span);
-  const uint32_t lane = threadIdx.x;
-  const uint32_t j = blockIdx.x * 64 + lane;
-  const bool have = (j < num_jobs);
-  s_job[lane] = jobs[have ? j : 0];
-  if (!have) { s_job[lane].blk_len = 0; }
-  const uint32_t n = s_job[lane].blk_len;
-  const bool pass = (n < (uint32_t)ORDER) || (stage_flags & 1u);      // fewer samples than taps, or no LMS stage wanted: everything passes through
-  const uint32_t nmax = umax_wave(n);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-  int32_t cf[ORDER], ci[ORDER], hf[ORDER], hi[ORDER], sf[ORDER], si[ORDER];
-#pragma unroll
-  for (int i = 0; i < ORDER; i++) { cf[i] = 0; ci[i] = 0; hf[i] = 0; hi[i] = 0; sf[i] = 0; si[i] = 0; }
-  uint64_t fsum = 0;
-  const uint32_t half = lane >> 5, t = lane & 31u;
-  for (uint32_t s0 = 0; s0 < nmax; s0 += T1_TILE) {
-    // ---- tile in: row q = samples [s0, s0 + T1_TILE) of job q, behind the long-term stage ----
-#pragma unroll 4
-    for (uint32_t r = 0; r < 32; r++) {
-      const uint32_t q = 2 * r + half;
-      const sla_hip_tail_job* jq = &s_job[q];        // (fields straight from LDS: a private copy with its tap array would live in scratch)
-      const uint32_t s = s0 + t;
-      int32_t x = 0;
-      if (s < jq->blk_len) {
-        const int32_t* in = res_in + (uint64_t)jq->channel * stride + jq->blk_off;
-        const uint32_t pitch = jq->pitch, delay = pitch + (ntaps >> 1);
-        x = in[s];
-        if (pitch >= 3 && s >= delay) {
-          int64_t acc = (int64_t)1 << 30;
-          for (uint32_t k = 0; k < ntaps; k++) { acc += (int64_t)jq->ltm_coef[k] * (int64_t)in[s - delay + k]; }
-          x = (int32_t)((uint32_t)x - (uint32_t)(int32_t)(acc >> 31));
-        }
-      }
-      t_in[q * T1_ROW + t] = x;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- the serial cascade: lane = job, ORDER samples per unrolled block ----
-#pragma unroll 1
-    for (uint32_t b0 = 0; b0 < T1_TILE; b0 += ORDER) {
-      int32_t cur[ORDER], es[ORDER];
-#pragma unroll
-      for (int u = 0; u < ORDER; u++) { cur[u] = t_in[lane * T1_ROW + b0 + u]; }
-      if (s0 + b0 == 0) { tail1_block<ORDER, true>(cur, es, cf, ci, hf, hi, sf, si); }
-      else { tail1_block<ORDER, false>(cur, es, cf, ci, hf, hi, sf, si); }
-#pragma unroll
-      for (int u = 0; u < ORDER; u++) {
-        const int32_t e = pass ? cur[u] : es[u];
-        t_out[lane * T1_ROW + b0 + u] = e;
-        if (s0 + b0 + (uint32_t)u < n) { fsum += (e < 0) ? ~((uint32_t)e << 1) : ((uint32_t)e << 1); }   // zig-zag fold, src/SLAUtility.h:37
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- tile out ----
-#pragma unroll 4
-    for (uint32_t r = 0; r < 32; r++) {
-      const uint32_t q = 2 * r + half;
-      const sla_hip_tail_job* jq = &s_job[q];
-      const uint32_t s = s0 + t;
-      if (s < jq->blk_len) { res_out[(uint64_t)jq->channel * stride + jq->blk_off + s] = t_out[q * T1_ROW + t]; }
-    }
-  }
-  if (have) { fold_sum[j] = fsum; }
-  span_end(span);
-}
 
 // ---------------------------------------------------------------------------------------------
 // k_ltm_acf: autocorrelation of the lattice residual by the reference's real FFT
@@ -3779,22 +3406,10 @@ void k_ltm_solve(const double* __restrict__ acf, const sla_hip_lpc_group* __rest
 // ---------------------------------------------------------------------------------------------
 // launchers (C-ABI, see include/sla_hip.h)
 // ---------------------------------------------------------------------------------------------
-// The driver may ask for the on-device execution span of its next launch of k_lpc_blocks / k_lattice / k_ltm_acf /
-// k_tail (see span_begin): it names the two-word slot right before the launcher call, on the same host thread.
-static thread_local unsigned long long* t_next_span = nullptr;
-extern "C" void slai_next_launch_span(unsigned long long* d_span) { t_next_span = d_span; }
-static inline unsigned long long* take_span() { unsigned long long* p = t_next_span; t_next_span = nullptr; return p; }
-// the next sla_hip_launch_lpc_blocks_cert takes its group count from k_expand_scan's running numbers on the device (its
-// num_groups argument is then the most there can be): the launch can be queued before the host has seen the count
-static thread_local const uint32_t* t_next_count = nullptr;
-extern "C" void slai_next_launch_count(const uint32_t* d_run) { t_next_count = d_run; }
-// words the next sla_hip_launch_search_exact clears on the way (see clear_list): up to three regions, same host thread
-static thread_local clear_list t_next_clear = {{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}};
-extern "C" void slai_next_launch_clear(uint32_t* a, uint32_t na, uint32_t* b, uint32_t nb, uint32_t* c, uint32_t nc)
-{
-  t_next_clear.ptr[0] = a; t_next_clear.words[0] = na; t_next_clear.ptr[1] = b; t_next_clear.words[1] = nb;
-  t_next_clear.ptr[2] = c; t_next_clear.words[2] = nc;
-}
+// Optional extras of a launch travel in sla_hip_launch_extra (include/sla_hip.h): the two-word slot for its on-device execution
+// span (see span_begin), a device-side group count, words to clear on the way.  (Rounds 2 - 3 passed them through thread-local
+// one-shot requests that a later commit had to drop at every API entry; now they are arguments.)
+static inline unsigned long long* span_of(const sla_hip_launch_extra* x) { return (x != nullptr) ? x->d_span : nullptr; }
 
 // Tuning knobs of the launchers (include/sla_hip.h: sla_hip_tuning).  They belong to an encoder handle, which reads
 // them ONCE (environment at SLAEncoder_Create, sla_hip_encoder_set_option afterwards) and names its copy to the
@@ -3806,10 +3421,6 @@ static thread_local bool t_tuning_set = false;
 extern "C" void sla_hip_use_tuning(const sla_hip_tuning* tuning)
 {
   if (tuning != nullptr) { t_tuning_val = *tuning; t_tuning_set = true; } else { t_tuning_set = false; }
-  // every API entry of a handle comes through here: a one-shot request (span slot, words to clear, device-side count) that
-  // an earlier call set and -- leaving on an error -- never used must not reach the next launch of this thread
-  t_next_span = nullptr; t_next_count = nullptr;
-  t_next_clear.ptr[0] = t_next_clear.ptr[1] = t_next_clear.ptr[2] = nullptr;
 }
 static inline sla_hip_tuning tuning()
 {
@@ -3936,7 +3547,18 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
                            double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
                            sla_hip_stream_t stream, uint32_t mode_flags, uint32_t* d_rerun_counter, int32_t* d_lat_residual,
                            const uint32_t* list = nullptr, const uint32_t* list_count = nullptr, uint32_t* d_cert_flag = nullptr,
-                           uint32_t audit_bps = 0u);
+                           uint32_t audit_bps = 0u, unsigned long long* span = nullptr);
+
+extern "C" int sla_hip_launch_lpc_x(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                                  const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                                  uint32_t max_cands_per_group,
+                                  const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
+                                  double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
+                                  sla_hip_stream_t stream, const sla_hip_launch_extra* extra)
+{
+  return launch_lpc_impl(d_pcm, plane_stride, mid_side, order, d_groups, num_groups, max_window, max_cands_per_group, d_cands,
+                         d_window_pool, d_out, d_code, d_kint, d_rshift, stream, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, span_of(extra));
+}
 
 extern "C" int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
                                   const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
@@ -3945,8 +3567,18 @@ extern "C" int sla_hip_launch_lpc(const int32_t* d_pcm, uint64_t plane_stride, u
                                   double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
                                   sla_hip_stream_t stream)
 {
-  return launch_lpc_impl(d_pcm, plane_stride, mid_side, order, d_groups, num_groups, max_window, max_cands_per_group, d_cands,
-                         d_window_pool, d_out, d_code, d_kint, d_rshift, stream, 0u, nullptr, nullptr);
+  return sla_hip_launch_lpc_x(d_pcm, plane_stride, mid_side, order, d_groups, num_groups, max_window, max_cands_per_group, d_cands, d_window_pool, d_out, d_code, d_kint, d_rshift, stream, nullptr);
+}
+
+extern "C" int sla_hip_launch_lpc_blocks_x(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                                         const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                                         const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
+                                         double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
+                                         int32_t* d_lattice_residual, sla_hip_stream_t stream, const sla_hip_launch_extra* extra)
+{
+  if (d_code == nullptr || d_lattice_residual == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
+  return launch_lpc_impl(d_pcm, plane_stride, mid_side, order, d_groups, num_groups, max_window, 1, d_cands,
+                         d_window_pool, d_out, d_code, d_kint, d_rshift, stream, 0u, nullptr, d_lattice_residual, nullptr, nullptr, nullptr, 0u, span_of(extra));
 }
 
 extern "C" int sla_hip_launch_lpc_blocks(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
@@ -3955,17 +3587,16 @@ extern "C" int sla_hip_launch_lpc_blocks(const int32_t* d_pcm, uint64_t plane_st
                                          double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
                                          int32_t* d_lattice_residual, sla_hip_stream_t stream)
 {
-  if (d_code == nullptr || d_lattice_residual == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
-  return launch_lpc_impl(d_pcm, plane_stride, mid_side, order, d_groups, num_groups, max_window, 1, d_cands,
-                         d_window_pool, d_out, d_code, d_kint, d_rshift, stream, 0u, nullptr, d_lattice_residual);
+  return sla_hip_launch_lpc_blocks_x(d_pcm, plane_stride, mid_side, order, d_groups, num_groups, max_window, d_cands, d_window_pool, d_out, d_code, d_kint, d_rshift, d_lattice_residual, stream, nullptr);
 }
 
-extern "C" int sla_hip_launch_lpc_blocks_cert(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+extern "C" int sla_hip_launch_lpc_blocks_cert_x(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
                                               const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
                                               const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
                                               double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
                                               uint32_t* d_cert_flag, uint32_t* d_fallback_list, uint32_t* d_fallback_count,
-                                              double safety, uint32_t bits_per_sample, sla_hip_stream_t stream)
+                                              double safety, uint32_t bits_per_sample, sla_hip_stream_t stream,
+                                                const sla_hip_launch_extra* extra)
 {
   if (d_pcm == nullptr || d_groups == nullptr || d_cands == nullptr || d_window_pool == nullptr || d_out == nullptr || d_code == nullptr
       || d_kint == nullptr || d_rshift == nullptr || d_cert_flag == nullptr || d_fallback_list == nullptr || d_fallback_count == nullptr) {
@@ -3977,8 +3608,8 @@ extern "C" int sla_hip_launch_lpc_blocks_cert(const int32_t* d_pcm, uint64_t pla
   if (num_groups == 0) { return 0; }
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipSuccess;
-  unsigned long long* span = take_span();
-  const uint32_t* dyn = t_next_count; t_next_count = nullptr;      // slai_next_launch_count: num_groups is an upper bound, the kernels read the number
+  unsigned long long* span = span_of(extra);
+  const uint32_t* dyn = (extra != nullptr) ? extra->d_group_count : nullptr;      // num_groups is then an upper bound, the kernels read the number
   const dim3 grid((num_groups + 3) / 4), block(256);
 #define SLA_ACFB(NBB) do { \
     if (mid_side) { hipLaunchKernelGGL((k_acf_blocks<NBB, true>), grid, block, 0, st, d_pcm, plane_stride, order, d_groups, num_groups, d_window_pool, d_out, d_rshift, span, d_fallback_count, dyn); } \
@@ -4006,6 +3637,17 @@ extern "C" int sla_hip_launch_lpc_blocks_cert(const int32_t* d_pcm, uint64_t pla
                          d_fallback_list, d_fallback_count, d_cert_flag, bits_per_sample);
 }
 
+extern "C" int sla_hip_launch_lpc_blocks_cert(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                                              const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                                              const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
+                                              double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
+                                              uint32_t* d_cert_flag, uint32_t* d_fallback_list, uint32_t* d_fallback_count,
+                                              double safety, uint32_t bits_per_sample, sla_hip_stream_t stream)
+{
+  return sla_hip_launch_lpc_blocks_cert_x(d_pcm, plane_stride, mid_side, order, d_groups, num_groups, max_window, d_cands, d_window_pool, d_out, d_code,
+                                          d_kint, d_rshift, d_cert_flag, d_fallback_list, d_fallback_count, safety, bits_per_sample, stream, nullptr);
+}
+
 extern "C" int sla_hip_launch_lpc_rerun(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
                                         const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
                                         uint32_t max_cands_per_group, const sla_hip_lpc_cand* d_cands,
@@ -4021,7 +3663,8 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
                            const sla_hip_lpc_cand* d_cands, const double* d_window_pool,
                            double* d_out, int32_t* d_code, int32_t* d_kint, uint32_t* d_rshift,
                            sla_hip_stream_t stream, uint32_t mode_flags, uint32_t* d_rerun_counter, int32_t* d_lat_residual,
-                           const uint32_t* list, const uint32_t* list_count, uint32_t* d_cert_flag, uint32_t audit_bps)
+                           const uint32_t* list, const uint32_t* list_count, uint32_t* d_cert_flag, uint32_t audit_bps,
+                           unsigned long long* span)
 {
   if (d_pcm == nullptr || d_groups == nullptr || d_cands == nullptr || d_out == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (order < 1 || order > 255 || max_window == 0 || max_cands_per_group == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
@@ -4057,7 +3700,6 @@ static int launch_lpc_impl(const int32_t* d_pcm, uint64_t plane_stride, uint32_t
       if (e != hipSuccess) { return hip_rc(e); }
       // list mode: a fixed grid walks the list (two workgroups per CU hold what the device can run at once)
       const dim3 grid((list != nullptr) ? LIST_LPC_GRID : (num_groups + p - 1) / p), block(LB_THREADS);
-      unsigned long long* span = take_span();
 #ifdef SLA_HIP_DEBUG
       const uint32_t clk = (uint32_t)(getenv("SLA_HIP_LPC_CLK") != nullptr);
 #else
@@ -4256,11 +3898,11 @@ extern "C" uint32_t sla_hip_search_exact_lags(uint32_t order)
   return (nb <= 3) ? 12 : (nb <= 5) ? 20 : (nb <= 9) ? 36 : (nb <= 13) ? 52 : 0;
 }
 
-extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+extern "C" int sla_hip_launch_search_exact_x(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
                                            const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
                                            uint32_t max_cands_per_group,
                                            const sla_hip_lpc_cand* d_cands, double* d_tile_sums, double* d_out,
-                                           double exact_limit, double cert_safety, uint32_t* d_any_exact, sla_hip_stream_t stream)
+                                           double exact_limit, double cert_safety, uint32_t* d_any_exact, sla_hip_stream_t stream, const sla_hip_launch_extra* extra)
 {
   if (d_pcm == nullptr || d_groups == nullptr || d_cands == nullptr || d_tile_sums == nullptr || d_out == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   const uint32_t lags = sla_hip_search_exact_lags(order);
@@ -4268,26 +3910,17 @@ extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_
   if (max_window == 0 || max_cands_per_group == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (num_groups == 0) { return 0; }
   hipStream_t st = (hipStream_t)stream;
-  clear_list cl = t_next_clear;                                       // what the caller asked to have cleared on the way
-  t_next_clear.ptr[0] = t_next_clear.ptr[1] = t_next_clear.ptr[2] = nullptr;
+  clear_list cl = {{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}};      // what the caller asked to have cleared on the way
+  if (extra != nullptr) { for (int i = 0; i < 3; i++) { cl.ptr[i] = extra->clear_ptr[i]; cl.words[i] = extra->clear_words[i]; } }
   cl.ptr[3] = d_any_exact; cl.words[3] = (d_any_exact != nullptr) ? 1u : 0u;      // the flag k_search_finish raises
   const uint32_t tiles = (max_window + SLA_HIP_XTILE - 1) / SLA_HIP_XTILE;       // waves per group
   const uint32_t waves = num_groups * tiles;
   const dim3 grid((waves + 3) / 4), block(256);
   switch (lags) {
     case 12: hipLaunchKernelGGL(k_acf_tiles<3>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); break;
-    case 20:
-      if (tuning().acf_classic) { hipLaunchKernelGGL(k_acf_tiles<5>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); }
-      else { hipLaunchKernelGGL(k_acf_tiles_lds<5>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); }
-      break;
-    case 36:
-      if (tuning().acf_classic) { hipLaunchKernelGGL(k_acf_tiles<9>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); }
-      else { hipLaunchKernelGGL(k_acf_tiles_lds<9>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); }
-      break;
-    default:
-      if (tuning().acf_classic) { hipLaunchKernelGGL(k_acf_tiles<13>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); }
-      else { hipLaunchKernelGGL(k_acf_tiles_lds<13>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); }
-      break;
+    case 20: hipLaunchKernelGGL(k_acf_tiles_lds<5>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); break;
+    case 36: hipLaunchKernelGGL(k_acf_tiles_lds<9>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); break;
+    default: hipLaunchKernelGGL(k_acf_tiles_lds<13>, grid, block, 0, st, d_pcm, plane_stride, mid_side, d_groups, num_groups, tiles, d_tile_sums, cl); break;
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { return hip_rc(e); }
@@ -4315,7 +3948,7 @@ extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_
       if (e != hipSuccess) { return hip_rc(e); } \
       e = ensure_dynamic_lds((const void*)k_search_finish<PP, 2>, lds_r); \
       if (e != hipSuccess) { return hip_rc(e); } \
-      if (cert_safety > 0.0 && !tuning().acf_classic) { \
+      if (cert_safety > 0.0) { \
         const uint64_t slots_bound = (uint64_t)num_groups * max_cands_per_group; \
         hipLaunchKernelGGL((k_search_cert<PP>), dim3((uint32_t)((slots_bound + XC_CANDS - 1) / XC_CANDS)), dim3(64), sizeof(double) * XC_CANDS * (order + 1), st, \
                            order, lags, max_cands_per_group, d_groups, num_groups, d_cands, d_tile_sums, d_out, exact_limit, cert_safety, d_any_exact); \
@@ -4334,6 +3967,15 @@ extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_
   }
 #undef SLA_FINISH
   return hip_rc(hipGetLastError());
+}
+
+extern "C" int sla_hip_launch_search_exact(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                                           const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                                           uint32_t max_cands_per_group,
+                                           const sla_hip_lpc_cand* d_cands, double* d_tile_sums, double* d_out,
+                                           double exact_limit, double cert_safety, uint32_t* d_any_exact, sla_hip_stream_t stream)
+{
+  return sla_hip_launch_search_exact_x(d_pcm, plane_stride, mid_side, order, d_groups, num_groups, max_window, max_cands_per_group, d_cands, d_tile_sums, d_out, exact_limit, cert_safety, d_any_exact, stream, nullptr);
 }
 
 extern "C" int sla_hip_launch_plan(const sla_hip_lpc_group* d_groups, uint32_t num_superframes, uint32_t num_channels,
@@ -4382,13 +4024,13 @@ extern "C" int sla_hip_launch_lattice(const int32_t* d_pcm, uint64_t plane_strid
   if (order < 1 || order > 255 || (order + LAT_T - 1) / LAT_T >= 32) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (num_chunks == 0) { return 0; }
   hipLaunchKernelGGL(k_lattice, dim3((num_chunks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_pcm, plane_stride,
-                     mid_side, order, d_chunks, num_chunks, d_kint, d_residual, take_span(), tuning().lattice_plain ? 2u : 0u);
+                     mid_side, order, d_chunks, num_chunks, d_kint, d_residual, (unsigned long long*)nullptr, tuning().lattice_plain ? 2u : 0u);
   return hip_rc(hipGetLastError());
 }
 
-extern "C" int sla_hip_launch_lattice_groups(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+extern "C" int sla_hip_launch_lattice_groups_x(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
                                              const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
-                                             const int32_t* d_kint, int32_t* d_residual, sla_hip_stream_t stream)
+                                             const int32_t* d_kint, int32_t* d_residual, sla_hip_stream_t stream, const sla_hip_launch_extra* extra)
 {
   if (d_pcm == nullptr || d_groups == nullptr || d_kint == nullptr || d_residual == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (order < 1 || order > 255 || (order + LAT_T - 1) / LAT_T >= 32 || max_window == 0) { return SLA_APIRESULT_INVALID_ARGUMENT; }
@@ -4398,8 +4040,15 @@ extern "C" int sla_hip_launch_lattice_groups(const int32_t* d_pcm, uint64_t plan
   const uint64_t waves = (uint64_t)num_groups * cpg;
   if (waves > 0x7FFFFFFFull) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
   hipLaunchKernelGGL(k_lattice_groups, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_pcm, plane_stride,
-                     mid_side, order, d_groups, num_groups, cpg, d_kint, d_residual, take_span(), tuning().lattice_plain ? 2u : 0u);
+                     mid_side, order, d_groups, num_groups, cpg, d_kint, d_residual, span_of(extra), tuning().lattice_plain ? 2u : 0u);
   return hip_rc(hipGetLastError());
+}
+
+extern "C" int sla_hip_launch_lattice_groups(const int32_t* d_pcm, uint64_t plane_stride, uint32_t mid_side, uint32_t order,
+                                             const sla_hip_lpc_group* d_groups, uint32_t num_groups, uint32_t max_window,
+                                             const int32_t* d_kint, int32_t* d_residual, sla_hip_stream_t stream)
+{
+  return sla_hip_launch_lattice_groups_x(d_pcm, plane_stride, mid_side, order, d_groups, num_groups, max_window, d_kint, d_residual, stream, nullptr);
 }
 
 extern "C" uint32_t sla_hip_lattice_chunk_samples(uint32_t order)
@@ -4415,7 +4064,7 @@ extern "C" int sla_hip_launch_lattice_raw(const int32_t* d_samples, uint64_t pla
   if (order < 1 || order > 255 || (order + LAT_T - 1) / LAT_T >= 32) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (num_chunks == 0) { return 0; }
   hipLaunchKernelGGL(k_lattice, dim3((num_chunks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_samples, plane_stride,
-                     0u, order, d_chunks, num_chunks, d_kint, d_residual, take_span(), 1u | (tuning().lattice_plain ? 2u : 0u));
+                     0u, order, d_chunks, num_chunks, d_kint, d_residual, (unsigned long long*)nullptr, 1u | (tuning().lattice_plain ? 2u : 0u));
   return hip_rc(hipGetLastError());
 }
 
@@ -4448,7 +4097,15 @@ extern "C" int sla_hip_launch_emphasis_f64(const double* d_in, double* d_out, ui
 
 static int launch_tail_impl(const int32_t* d_res_in, int32_t* d_res_out, uint64_t plane_stride,
                             const sla_hip_tail_job* d_jobs, uint32_t num_jobs, uint32_t longterm_order,
-                            uint32_t lms_order, uint64_t* d_fold_sum, sla_hip_stream_t stream, uint32_t stage_flags);
+                            uint32_t lms_order, uint64_t* d_fold_sum, sla_hip_stream_t stream, uint32_t stage_flags,
+                            unsigned long long* span = nullptr);
+
+extern "C" int sla_hip_launch_tail_x(const int32_t* d_res_in, int32_t* d_res_out, uint64_t plane_stride,
+                                     const sla_hip_tail_job* d_jobs, uint32_t num_jobs, uint32_t longterm_order,
+                                     uint32_t lms_order, uint64_t* d_fold_sum, sla_hip_stream_t stream, const sla_hip_launch_extra* extra)
+{
+  return launch_tail_impl(d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, lms_order, d_fold_sum, stream, 0u, span_of(extra));
+}
 
 extern "C" int sla_hip_launch_tail(const int32_t* d_res_in, int32_t* d_res_out, uint64_t plane_stride,
                                    const sla_hip_tail_job* d_jobs, uint32_t num_jobs, uint32_t longterm_order,
@@ -4469,35 +4126,17 @@ extern "C" int sla_hip_launch_tail_stages(const int32_t* d_res_in, int32_t* d_re
 #define TAILK2_WAVES 2048u
 static int launch_tail_impl(const int32_t* d_res_in, int32_t* d_res_out, uint64_t plane_stride,
                             const sla_hip_tail_job* d_jobs, uint32_t num_jobs, uint32_t longterm_order,
-                            uint32_t lms_order, uint64_t* d_fold_sum, sla_hip_stream_t stream, uint32_t stage_flags)
+                            uint32_t lms_order, uint64_t* d_fold_sum, sla_hip_stream_t stream, uint32_t stage_flags,
+                            unsigned long long* span)
 {
   if (d_res_in == nullptr || d_res_out == nullptr || d_jobs == nullptr || d_fold_sum == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (longterm_order > 5 || !(longterm_order & 1)) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (!(lms_order == 4 || lms_order == 8 || lms_order == 16 || lms_order == 32)) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
   if (num_jobs == 0) { return 0; }
   const uint32_t tw = tuning().tail_waves;
-  const uint32_t tail_waves = (tw >= 1 && tw <= 4) ? tw : 1u;     /* one wave per workgroup: the dispatcher spreads the (few, long-running) waves over all CUs */
   hipStream_t st = (hipStream_t)stream;
-  unsigned long long* span = take_span();
-  /* Round 2's kernels, now behind the knob only (tail_lanes 2 / 1): one coefficient per lane (k_tail, 2 * order lanes per
-   * job) and two (k_tail2, order lanes per job), both fetching one sample per lane and step. */
-  const uint32_t one_tap_waves = (num_jobs + (64 / (2 * lms_order)) - 1) / (64 / (2 * lms_order));
-  const uint32_t lanes_knob = tuning().tail_lanes;
-  /* One lane per job (k_tail1; LMS orders 4 - 16, the histories live in registers): only on request.  Measured against
-   * k_tail2 on the full-length files -- C3 (90 k jobs) 4.05 against 3.61 ms, C5-600 s (56 k jobs of 8192 samples) 7.6
-   * against 5.2 ms, the C4 batch 3.1 against 1.34 ms: 16 quarter-rate 32-bit products per sample in ONE lane's chain and
-   * the tile transposes cost more than the 64 jobs per wave save. */
-  if (lms_order <= 16 && lanes_knob == 3) {
-    dim3 grid1((num_jobs + 63) / 64), block1(64);
-    switch (lms_order) {
-      case 4:  hipLaunchKernelGGL(k_tail1<4>,  grid1, block1, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
-      case 8:  hipLaunchKernelGGL(k_tail1<8>,  grid1, block1, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
-      default: hipLaunchKernelGGL(k_tail1<16>, grid1, block1, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
-    }
-    return hip_rc(hipGetLastError());
-  }
-  /* K taps of each history per lane (k_tailk), the automatic choice.  Measured (tests/tools/chunk_sweep.py, LMS order 8,
-   * ms per launch; k_tail / k_tail2 are the round-2 kernels, still behind the knob):
+  /* K taps of each history per lane (k_tailk).  Measured (tests/tools/chunk_sweep.py, LMS order 8, ms per launch; k_tail /
+   * k_tail2 = the 2 * order- and order-lanes-per-job kernels of rounds 1 - 2, deleted in round 4):
    *   jobs     blocks          k_tail  k_tail2   K = 1   K = 2   K = 4
    *    3.5 k   4096 (C2 300 s)   0.42    0.49     0.35    0.43    0.62
    *    7 k     4096 (C2)         0.44    0.57     0.37    0.43    0.62
@@ -4507,68 +4146,44 @@ static int launch_tail_impl(const int32_t* d_res_in, int32_t* d_res_out, uint64_
    *  169 k     8192 (C5)        16.5    13.2      7.45    5.45    6.70
    * One tap per lane has the shortest chain per sample (0.35 ms per 4096 samples) and holds up to about two waves per SIMD;
    * beyond that two taps per lane halve the work per job.  Four never won: its 16-sample runs per lane cost more in the
-   * long-term stage and registers than the shared per-sample work saves. */
+   * long-term stage and registers than the shared per-sample work saves.  (One LANE per job -- histories in registers,
+   * tiles transposed through LDS, round 3 -- lost to all of them: 16 half-rate 32-bit products per sample in one lane's
+   * chain.) */
+  uint32_t k = tuning().tail_taps;                                     /* 0 = by the number of jobs */
+  const uint32_t k1_waves = (num_jobs * lms_order + 63u) / 64u;        /* waves of K = 1 */
+  if (k != 1 && k != 2 && k != 4) { k = (lms_order > 16 || (k1_waves > TAILK2_WAVES && lms_order >= 4)) ? 2u : 1u; }
+  if (k == 1 && lms_order > 16) { k = 2; }                /* at most sixteen lanes per job */
+  if (k > lms_order / 2) { k = lms_order / 2; }          /* at least two */
   {
-    uint32_t k = 0;
-    const uint32_t k1_waves = (num_jobs * lms_order + 63u) / 64u;        /* waves of K = 1 */
-    if (lanes_knob == 4 || lanes_knob == 5) { k = (lanes_knob == 4) ? 2u : 4u; }
-    else if (lanes_knob == 6 && lms_order <= 16) { k = 1; }
-    else if (lanes_knob == 0) { k = (lms_order > 16 || (k1_waves > TAILK2_WAVES && lms_order >= 4)) ? 2u : 1u; }
-    if (k > lms_order / 2) { k = lms_order / 2; }          /* at least two lanes per job */
-    if (k >= 1) {
-      /* four waves per workgroup: one workgroup fills a CU's four SIMDs with one wave each (one-wave workgroups landed two
-       * on a SIMD while other CUs stood empty: C2 0.44 against 0.37 ms, C3 1.83 against 1.46) */
-      const uint32_t twk = (tw >= 1 && tw <= 4) ? tw : 4u;
-      const uint32_t jpw = 64 / (lms_order / k);
-      const uint32_t jpb = twk * jpw;
-      dim3 gridk((num_jobs + jpb - 1) / jpb), blockk(64 * twk);
+    /* four waves per workgroup: one workgroup fills a CU's four SIMDs with one wave each (one-wave workgroups landed two
+     * on a SIMD while other CUs stood empty: C2 0.44 against 0.37 ms, C3 1.83 against 1.46) */
+    const uint32_t twk = (tw >= 1 && tw <= 4) ? tw : 4u;
+    const uint32_t jpw = 64 / (lms_order / k);
+    const uint32_t jpb = twk * jpw;
+    dim3 gridk((num_jobs + jpb - 1) / jpb), blockk(64 * twk);
 #define LAUNCH_TAILK(O, KK) hipLaunchKernelGGL((k_tailk<O, KK>), gridk, blockk, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags)
-      switch (lms_order * 16 + k) {
-        case 4 * 16 + 1:  LAUNCH_TAILK(4, 1); break;
-        case 8 * 16 + 1:  LAUNCH_TAILK(8, 1); break;
-        case 16 * 16 + 1: LAUNCH_TAILK(16, 1); break;
-        case 4 * 16 + 2:  LAUNCH_TAILK(4, 2); break;
-        case 8 * 16 + 2:  LAUNCH_TAILK(8, 2); break;
-        case 8 * 16 + 4:  LAUNCH_TAILK(8, 4); break;
-        case 16 * 16 + 2: LAUNCH_TAILK(16, 2); break;
-        case 16 * 16 + 4: LAUNCH_TAILK(16, 4); break;
-        case 32 * 16 + 2: LAUNCH_TAILK(32, 2); break;
-        case 32 * 16 + 4: LAUNCH_TAILK(32, 4); break;
-        default: return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY;
-      }
-#undef LAUNCH_TAILK
-      return hip_rc(hipGetLastError());
-    }
-  }
-  (void)one_tap_waves;
-  if (lanes_knob == 1) {      /* two taps per lane: `order` lanes per job */
-    const uint32_t jpb = tail_waves * (64 / lms_order);
-    dim3 grid2((num_jobs + jpb - 1) / jpb), block2(64 * tail_waves);
-    switch (lms_order) {
-      case 4:  hipLaunchKernelGGL(k_tail2<4>,  grid2, block2, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
-      case 8:  hipLaunchKernelGGL(k_tail2<8>,  grid2, block2, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
-      case 16: hipLaunchKernelGGL(k_tail2<16>, grid2, block2, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
-      case 32: hipLaunchKernelGGL(k_tail2<32>, grid2, block2, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
+    switch (lms_order * 16 + k) {
+      case 4 * 16 + 1:  LAUNCH_TAILK(4, 1); break;
+      case 8 * 16 + 1:  LAUNCH_TAILK(8, 1); break;
+      case 16 * 16 + 1: LAUNCH_TAILK(16, 1); break;
+      case 4 * 16 + 2:  LAUNCH_TAILK(4, 2); break;
+      case 8 * 16 + 2:  LAUNCH_TAILK(8, 2); break;
+      case 8 * 16 + 4:  LAUNCH_TAILK(8, 4); break;
+      case 16 * 16 + 2: LAUNCH_TAILK(16, 2); break;
+      case 16 * 16 + 4: LAUNCH_TAILK(16, 4); break;
+      case 32 * 16 + 2: LAUNCH_TAILK(32, 2); break;
+      case 32 * 16 + 4: LAUNCH_TAILK(32, 4); break;
       default: return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY;
     }
-    return hip_rc(hipGetLastError());
-  }
-  const uint32_t jobs_per_block = tail_waves * (64 / (2 * lms_order));     // 64/(2*order) jobs per wave
-  dim3 grid((num_jobs + jobs_per_block - 1) / (jobs_per_block ? jobs_per_block : 1)), block(64 * tail_waves);
-  switch (lms_order) {
-    case 4:  hipLaunchKernelGGL(k_tail<4>,  grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
-    case 8:  hipLaunchKernelGGL(k_tail<8>,  grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
-    case 16: hipLaunchKernelGGL(k_tail<16>, grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
-    case 32: hipLaunchKernelGGL(k_tail<32>, grid, block, 0, st, d_res_in, d_res_out, plane_stride, d_jobs, num_jobs, longterm_order, d_fold_sum, span, stage_flags); break;
-    default: return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY;
+#undef LAUNCH_TAILK
   }
   return hip_rc(hipGetLastError());
 }
 
-extern "C" int sla_hip_launch_ltm_acf(const int32_t* d_residual, uint64_t plane_stride,
+extern "C" int sla_hip_launch_ltm_acf_x(const int32_t* d_residual, uint64_t plane_stride,
                                       const sla_hip_acf_job* d_jobs, uint32_t num_jobs, uint32_t fft_size,
                                       const double* d_twiddles, double* d_scratch, uint32_t scratch_slots,
-                                      double* d_acf_head, uint32_t head, sla_hip_stream_t stream)
+                                      double* d_acf_head, uint32_t head, sla_hip_stream_t stream, const sla_hip_launch_extra* extra)
 {
   if (d_residual == nullptr || d_jobs == nullptr || d_twiddles == nullptr || d_acf_head == nullptr) { return SLA_APIRESULT_INVALID_ARGUMENT; }
   if (fft_size < 1024 || fft_size > 65536 * 2 || (fft_size & (fft_size - 1)) || head == 0 || head > fft_size) { return SLA_APIRESULT_INVALID_ARGUMENT; }
@@ -4577,8 +4192,8 @@ extern "C" int sla_hip_launch_ltm_acf(const int32_t* d_residual, uint64_t plane_
   while ((1u << log2F) < fft_size) { log2F++; }
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = sizeof(double) * (size_t)fft_size;
-  unsigned long long* span = take_span();
-  if (lds <= SLA_HIP_LDS_BUDGET && log2F >= 12 && log2F <= 14 && !tuning().acf_classic) {
+  unsigned long long* span = span_of(extra);
+  if (lds <= SLA_HIP_LDS_BUDGET && log2F >= 12 && log2F <= 14) {
     // the capacities the encoder is created with (2048 .. 8192 samples per block): fewer LDS passes, same bits
     hipError_t e = hipSuccess;
 #define SLA_ACF2(LL, TT, REC) do { \
@@ -4604,6 +4219,14 @@ extern "C" int sla_hip_launch_ltm_acf(const int32_t* d_residual, uint64_t plane_
                        log2F, d_twiddles, d_scratch, d_acf_head, head, span);
   }
   return hip_rc(hipGetLastError());
+}
+
+extern "C" int sla_hip_launch_ltm_acf(const int32_t* d_residual, uint64_t plane_stride,
+                                      const sla_hip_acf_job* d_jobs, uint32_t num_jobs, uint32_t fft_size,
+                                      const double* d_twiddles, double* d_scratch, uint32_t scratch_slots,
+                                      double* d_acf_head, uint32_t head, sla_hip_stream_t stream)
+{
+  return sla_hip_launch_ltm_acf_x(d_residual, plane_stride, d_jobs, num_jobs, fft_size, d_twiddles, d_scratch, scratch_slots, d_acf_head, head, stream, nullptr);
 }
 
 extern "C" int sla_hip_launch_ltm_solve(const double* d_acf_records, const sla_hip_lpc_group* d_groups, uint32_t num_jobs,

@@ -43,8 +43,8 @@ class Chunk(C.Structure):
 
 class Tuning(C.Structure):
     _fields_ = [("lpc_pack", C.c_uint32), ("lpc_threads", C.c_uint32), ("lpc_blocks_chains", C.c_uint32), ("tail_waves", C.c_uint32),
-                ("lpc_tile", C.c_uint32), ("tail_lanes", C.c_uint32), ("plan_margin", C.c_double), ("acf_classic", C.c_uint32),
-                ("rice_lanes", C.c_uint32), ("lattice_plain", C.c_uint32)]
+                ("lpc_tile", C.c_uint32), ("tail_taps", C.c_uint32), ("plan_margin", C.c_double), ("rice_lanes", C.c_uint32),
+                ("lattice_plain", C.c_uint32), ("cert_audit", C.c_uint32)]
 
 
 def forms_of(y, kint, order, per):

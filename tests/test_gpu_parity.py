@@ -45,7 +45,7 @@ def hip_encode(hip, p, pcm, want_residuals=True):
             enc.set_option("stream", 1)
             enc.set_option("stream_piece", 1024)
             enc.set_option("stream_lanes", 1 + (n // 7) % 4)
-            enc.set_option("tail_lanes", 1 + (n // 5) % 3)               # the three layouts of the tail kernel take turns
+            enc.set_option("tail_taps", (1, 2, 4)[(n // 5) % 3])         # the three layouts of the tail kernel take turns
             again = enc.encode_whole(pcm)
             assert again == data, "streamed EncodeWhole differs from the plain path"
         return data, tr
@@ -155,31 +155,27 @@ def test_window_types(oracle, hip, wtype):
 def test_tail_orders(oracle, hip, lms, ltm):
     pcm = W.music_like(2, 20000, 24, seed=lms + ltm)
     p = S.make_params(2, 24, 48000, 16, ltm, lms, 1, 1, 4096)
-    want = assert_same_as_oracle(oracle, hip, p, pcm)             # one tap per lane (k_tail: the choice for few jobs)
-    got, _ = _encode_with_options(hip, p, pcm, tail_lanes=1)      # two taps per lane (k_tail2)
+    want = assert_same_as_oracle(oracle, hip, p, pcm)             # the automatic choice (few jobs: one tap per lane; order 32: two)
+    got, _ = _encode_with_options(hip, p, pcm, tail_taps=1)       # one tap of each history per lane (k_tailk<., 1>; order 32 takes two)
     assert got == want
-    got, _ = _encode_with_options(hip, p, pcm, tail_lanes=1, tail_waves=2, chunks=1)
+    got, _ = _encode_with_options(hip, p, pcm, tail_taps=1, tail_waves=2, chunks=1)
     assert got == want
-    got, _ = _encode_with_options(hip, p, pcm, tail_lanes=3)      # one lane per job (k_tail1; order 32 falls back)
+    got, _ = _encode_with_options(hip, p, pcm, tail_taps=2)       # two (k_tailk<., 2>)
     assert got == want
-    got, _ = _encode_with_options(hip, p, pcm, tail_lanes=4)      # two taps of each history per lane (k_tailk<., 2>)
-    assert got == want
-    got, _ = _encode_with_options(hip, p, pcm, tail_lanes=5, tail_waves=4)      # four (k_tailk<., 4>; LMS order 4: two)
-    assert got == want
-    got, _ = _encode_with_options(hip, p, pcm, tail_lanes=6)      # one (k_tailk<., 1>: k_tail2's layout; order 32 takes the automatic choice)
+    got, _ = _encode_with_options(hip, p, pcm, tail_taps=4, tail_waves=4)      # four (k_tailk<., 4>; LMS order 4: two)
     assert got == want
 
 
-@pytest.mark.parametrize("lanes", [4, 5, 6])
+@pytest.mark.parametrize("taps", [1, 2, 4])
 @pytest.mark.parametrize("n", [1, 7, 9, 31, 33, 63, 65, 4095, 4097, 20011])
-def test_tail_k_taps_per_lane_ragged_blocks(oracle, hip, lanes, n):
+def test_tail_k_taps_per_lane_ragged_blocks(oracle, hip, taps, n):
     """k_tailk on blocks shorter than the LMS order, one sample over a multiple of it, and with the last job of a wave
     missing (3 channels: the job count is not a multiple of the jobs per wave)"""
     pcm = W.music_like(3, n, 16, seed=n)
     p = S.make_params(3, 16, 48000, 8, 3, 8, 0, 1, 2048)
     ret, want = oracle.encode_whole(p, pcm)
     assert ret == 0
-    got, _ = _encode_with_options(hip, p, pcm, tail_lanes=lanes)
+    got, _ = _encode_with_options(hip, p, pcm, tail_taps=taps)
     assert got == want
 
 
@@ -850,8 +846,8 @@ def test_random_parameter_walk_chunked(oracle, hip, seed):
     assert_same_as_oracle(oracle, hip, p, pcm, roundtrip=False)
     want = oracle.encode_trace(p, pcm)[1]
     for opts in ({"chunks": 3}, {"chunks": 2, "single_tail": 0}, {"chunks": 3, "device_ltm": 0}, {"chunks": 2, "alt_streams": 1},
-                 {"chunks": 3, "alt_streams": 1}, {"chunks": 2, "device_expand": 0}, {"chunks": 1, "tail_lanes": 4},
-                 {"chunks": 2, "tail_lanes": 5, "tail_waves": 2}):
+                 {"chunks": 3, "alt_streams": 1}, {"chunks": 2, "device_expand": 0}, {"chunks": 1, "tail_taps": 2},
+                 {"chunks": 2, "tail_taps": 4, "tail_waves": 2}):
         got, t = _encode_with_options(hip, p, pcm, **opts)
         assert got == want and t[9] == opts["chunks"], opts
 
@@ -1142,15 +1138,14 @@ def test_rice_walk_kernels_agree(oracle, hip, n, kind):
 
 
 @pytest.mark.parametrize("n,bits,ms", [(8192 * 6 + 333, 24, 0), (8192 * 3 + 40, 16, 0), (4096 * 9 + 1999, 24, 1), (1500, 24, 0)])
-def test_tile_sums_at_52_lags_both_kernels(oracle, hip, n, bits, ms):
-    """orders 33 .. 52 take the tile sums from k_acf_tiles_lds (partners from LDS, tile walked backwards); option
-    acf_classic keeps k_acf_tiles<13> (DPP moves): the oracle's bytes from both, on windows with a short last tile (fewer
-    samples than lags in it), a window shorter than a tile, loud 24-bit material (certified sums) and 16-bit (exact sums)"""
+def test_tile_sums_at_52_lags(oracle, hip, n, bits, ms):
+    """orders 33 .. 52 take the tile sums from k_acf_tiles_lds<13> (partners from LDS, tile walked backwards): the oracle's bytes
+    on windows with a short last tile (fewer samples than lags in it), a window shorter than a tile, loud 24-bit material
+    (certified sums) and 16-bit (exact sums)"""
     nch = 2 if ms else 1
     pcm = W.music_like(nch, n, bits, seed=n % 71, level=1.0)
     p = S.make_params(nch, bits, 96000, 48, 3, 8, ms, 1, 8192)
     ret, want = oracle.encode_whole(p, pcm)
     assert ret == 0
-    for classic in (0, 1):
-        got, _ = _encode_with_options(hip, p, pcm, acf_classic=classic, stream=0)
-        assert got == want, classic
+    got, _ = _encode_with_options(hip, p, pcm, stream=0)
+    assert got == want

@@ -16,16 +16,14 @@ import sla_amd        # noqa: E402
 
 SETTINGS = [
     {},
-    {"tail_lanes": 1},
-    {"tail_lanes": 2},
-    {"tail_lanes": 6},
-    {"tail_lanes": 4},
-    {"tail_lanes": 5},
-    {"tail_lanes": 6, "tail_waves": 4},
-    {"tail_lanes": 4, "tail_waves": 4},
-    {"tail_lanes": 5, "tail_waves": 4},
+    {"tail_taps": 1},
+    {"tail_taps": 2},
+    {"tail_taps": 4},
+    {"tail_taps": 1, "tail_waves": 4},
+    {"tail_taps": 2, "tail_waves": 4},
+    {"tail_taps": 4, "tail_waves": 4},
 ]
-DEFAULTS = {"chunks": 1, "first_chunk": 0, "single_tail": 1, "device_ltm": 1, "tail_lanes": 0, "tail_waves": 0, "alt_streams": 2, "lpc_pack": 0, "lpc_blocks_chains": 0, "lpc_threads": 0, "lpc_tile": 0}
+DEFAULTS = {"chunks": 1, "first_chunk": 0, "single_tail": 1, "device_ltm": 1, "tail_taps": 0, "tail_waves": 0, "alt_streams": 2, "lpc_pack": 0, "lpc_blocks_chains": 0, "lpc_threads": 0, "lpc_tile": 0}
 
 
 def main():
