@@ -82,16 +82,35 @@ int main(int argc, char** argv)
     const char* path = getenv("SLA_RCCL_ID_FILE");
     FILE* f;
     if (path == NULL) { fprintf(stderr, "world > 1 needs SLA_RCCL_ID_FILE\n"); return 2; }
+    /* The file carries the launch's own nonce (SLA_RCCL_LAUNCH_ID: the launcher hands every rank of ONE launch the same
+     * value, e.g. its pid or a timestamp) in front of the id: a file left behind by an earlier launch -- or by rank 0 of
+     * this one before it renamed the new id into place -- is not ours and is not read (a stale file gave
+     * the ranks different ids and ncclCommInitRank hung).  Rank 0 removes what is there first; the others give up after
+     * a minute instead of polling for ever. */
+    const char* nonce_s = getenv("SLA_RCCL_LAUNCH_ID");
+    const unsigned long long nonce = nonce_s ? strtoull(nonce_s, NULL, 10) : 0ull;
+    if (nonce_s == NULL) { fprintf(stderr, "world > 1 needs SLA_RCCL_LAUNCH_ID (one value per launch, the same on every rank)\n"); return 2; }
     if (rank == 0) {
       char tmp[4096];
+      (void)remove(path);
       CHECK_NCCL(ncclGetUniqueId(&id));
       snprintf(tmp, sizeof(tmp), "%s.tmp", path);
-      f = fopen(tmp, "wb"); if (!f || fwrite(&id, sizeof(id), 1, f) != 1) { return 2; } fclose(f);
+      f = fopen(tmp, "wb");
+      if (!f || fwrite(&nonce, sizeof(nonce), 1, f) != 1 || fwrite(&id, sizeof(id), 1, f) != 1) { return 2; }
+      fclose(f);
       if (rename(tmp, path) != 0) { return 2; }
     } else {
-      while ((f = fopen(path, "rb")) == NULL) { usleep(10000); }
-      if (fread(&id, sizeof(id), 1, f) != 1) { return 2; }
-      fclose(f);
+      int tries = 0, got = 0;
+      while (!got && tries++ < 6000) {
+        unsigned long long seen = 0;
+        f = fopen(path, "rb");
+        if (f != NULL) {
+          got = (fread(&seen, sizeof(seen), 1, f) == 1 && seen == nonce && fread(&id, sizeof(id), 1, f) == 1);
+          fclose(f);
+        }
+        if (!got) { usleep(10000); }
+      }
+      if (!got) { fprintf(stderr, "rank %u: no id of launch %llu in %s after 60 s\n", rank, nonce, path); return 2; }
     }
   } else {
     CHECK_NCCL(ncclGetUniqueId(&id));

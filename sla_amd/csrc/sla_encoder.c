@@ -1118,7 +1118,20 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
   }
   {
     const int silence = (rebuild || e->h_or[1] != 0);
-    if (a->spec && (silence || e->h_or[0] != a->or_word)) { a->spec = 0; e->spec_misses++; }      /* guessed wrong: the searches go out again */
+    if (a->spec && (silence || e->h_or[0] != a->or_word)) {
+      /* guessed wrong: the searches go out again.  Whatever the first run queued on the block stream behind its tables (the
+       * prelaunched block kernels: they still read the descriptors, counters and candidate slots the second run rewrites) must
+       * have drained first: the search stream waits for that stream's tail (the two runs were unordered) */
+      if (a->prelaunched) {
+        const hipStream_t ps = a->one_stream ? e->stream : e->stream2;
+        if (ps != e->stream) {
+          HIPCHK(hipEventRecord(e->ev_prep, ps));
+          HIPCHK(hipStreamWaitEvent(e->stream, e->ev_prep, 0));
+        }
+        a->prelaunched = 0;
+      }
+      a->spec = 0; e->spec_misses++;
+    }
     decide_routes(e, a, e->h_or[0], silence);
     e->spec_valid = !silence; e->spec_or = e->h_or[0];
   }
