@@ -4,13 +4,13 @@ cd "$(dirname "$0")/../.."
 for c in c2 c3 c5; do
   case $c in c2) tag=c2;; c3) tag=c3_600s;; c5) tag=c5_120s;; esac
   f=$(ls -t $(find gpurun_out/kt_$c -name "*kernel_stats.csv" 2>/dev/null) 2>/dev/null | head -1)
-  [ -n "$f" ] && cp "$f" profiles/r3_kernel_stats_$tag.csv
+  [ -n "$f" ] && cp "$f" profiles/r4_kernel_stats_$tag.csv
   [ -f gpurun_out/pmc_$c/pmc_traffic_$c.json ] && cp gpurun_out/pmc_$c/pmc_traffic_$c.json profiles/pmc_traffic_$c.json
   for ctr in FETCH_SIZE WRITE_SIZE; do
     f=$(ls -t $(find gpurun_out/pmc_$c/$ctr -name "*counter_collection.csv" 2>/dev/null) 2>/dev/null | head -1)
     lower=$(echo $ctr | tr A-Z a-z)
     # per kernel: launches and mean counter value (the raw per-dispatch rows are megabytes)
-    [ -n "$f" ] && python3 - "$f" "$ctr" > profiles/r3_pmc_${lower}_$c.csv <<'PY'
+    [ -n "$f" ] && python3 - "$f" "$ctr" > profiles/r4_pmc_${lower}_$c.csv <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(lambda: [0, 0.0])
 for row in csv.DictReader(open(sys.argv[1])):
@@ -22,6 +22,6 @@ for k, (n, v) in sorted(agg.items()):
     print('"%s",%d,%s,%.3f' % (k, n, sys.argv[2], v / n))
 PY
   done
-  [ -f gpurun_out/sq_$c.txt ] && cp gpurun_out/sq_$c.txt profiles/r3_sq_counters_$tag.csv
+  [ -f gpurun_out/sq_$c.txt ] && cp gpurun_out/sq_$c.txt profiles/r4_sq_counters_$tag.csv
 done
 ls -la profiles | tail -20
