@@ -19,7 +19,7 @@ import slalibs as S
 
 pytestmark = pytest.mark.gpu
 
-LAT_T = 16
+LAT_T = 17          # samples per lane of the lattice wave (kernels/lattice_wave.inc)
 
 
 @pytest.fixture(scope="module")
@@ -168,12 +168,12 @@ def test_lattice_forms_at_the_edges(oracle, hip):
 
 
 def test_lattice_ragged_blocks_and_shift(oracle, hip):
-    """block lengths around the wave's 976 / 960 / 944-sample chunks, left-justified input with a shift (the pipeline's staging)"""
+    """block lengths around the wave's (64 - halo lanes) * 17-sample chunks, left-justified input with a shift (the pipeline's staging)"""
     rng = np.random.default_rng(5)
     for order in (8, 16, 32, 48):
         per = (64 - (order + LAT_T - 1) // LAT_T) * LAT_T
         kint = np.concatenate([[0], rng.integers(-120, 121, order)]).astype(np.int32)
-        for n in (1, 15, 16, 17, per - 1, per, per + 1, 2 * per, 2 * per + 5, 4096, 4097):
+        for n in (1, 15, 16, 17, 18, 33, 34, 35, per - 1, per, per + 1, 2 * per, 2 * per + 5, 2048, 4096, 4097, 8192):
             x24 = rng.integers(-(1 << 23), 1 << 23, n, dtype=np.int64).astype(np.int32)
             x = (x24.astype(np.int64) << 8).astype(np.int32)                  # left-justified 24-bit, as the API hands it over
             want = oracle.lattice_predict(oracle.preemph_i32(x24), kint)
