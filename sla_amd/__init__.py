@@ -317,7 +317,7 @@ class Encoder:
             cap = capacity if capacity is not None else 8 * pcm.shape[0] * n + 65536
             buf = np.zeros(cap, np.uint8)
         else:
-            buf, cap = out, len(out)
+            buf, cap = out, min(len(out), 0xFFFFFFF0)        # the API's sizes are 32-bit
         size = C.c_uint32(0)
         self._check(self._lib.SLAEncoder_EncodeWhole(self._h, ptrs, n, buf.ctypes.data_as(u8p), cap, C.byref(size)),
                     "SLAEncoder_EncodeWhole")

@@ -151,8 +151,8 @@ struct SLAEncoder {
    * their own on the same device, one host thread each), so upload, kernels and download of different pieces overlap */
   int      stream_mode;             /* 1 (default): on for files of at least two pieces */
   uint32_t stream_piece;            /* samples (all channels together) per piece */
-  uint32_t stream_lanes;            /* worker lanes (1..4) */
-  struct SLAEncoder* lane[4];
+  uint32_t stream_lanes;            /* worker lanes (1..SLAI_STREAM_LANES) */
+  struct SLAEncoder* lane[SLAI_STREAM_LANES];
   int      is_lane;
   struct slai_pool* upload_pool;    /* a lane's staging copies of its upload run on the parent's (otherwise idle, larger) pool: uploads take turns */
   int      streamed;                /* the last EncodeWhole ran on the lanes: this handle holds no analysis tables */
@@ -373,7 +373,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   e->prelaunch = 1;
   e->device_expand = 1;
   e->upload24 = 1;      /* profiles/r3_pack24_ab_*.json: plain path +13 % (C3) / +15 % (C5) from pageable memory, streamed path +1..3 % */
-  e->stream_mode = 1; e->stream_piece = 32u << 20; e->stream_lanes = 4;
+  e->stream_mode = 1; e->stream_piece = 32u << 20; e->stream_lanes = 6;
   /* measured on C2: the lattice inside k_lpc_blocks costs 0.6 ms per step (9 wave-chunks on the 8 waves of a workgroup
    * that has nothing else left to overlap them with), its own launch 0.27 ms: separate by default */
   e->fuse_lattice = 0;
@@ -417,7 +417,7 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   pinbuf_t* h[29];
   int i;
   if (e == NULL) { return; }
-  for (i = 0; i < 4; i++) { SLAEncoder_Destroy(e->lane[i]); e->lane[i] = NULL; }
+  for (i = 0; i < SLAI_STREAM_LANES; i++) { SLAEncoder_Destroy(e->lane[i]); e->lane[i] = NULL; }
   (void)hipSetDevice(e->device);
   if (e->stream != NULL) { (void)hipStreamSynchronize(e->stream); }
   if (e->stream2 != NULL) { (void)hipStreamSynchronize(e->stream2); }
@@ -2108,7 +2108,7 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   else if (strcmp(name, "single_tail") == 0)       { OPT_RANGE(0, 1); e->single_tail = (int)iv; }
   else if (strcmp(name, "stream") == 0)            { OPT_RANGE(0, 1); e->stream_mode = (int)iv; }
   else if (strcmp(name, "stream_piece") == 0)      { OPT_RANGE(1024, 1 << 30); e->stream_piece = (uint32_t)iv; }
-  else if (strcmp(name, "stream_lanes") == 0)      { OPT_RANGE(1, 4); e->stream_lanes = (uint32_t)iv; }
+  else if (strcmp(name, "stream_lanes") == 0)      { OPT_RANGE(1, SLAI_STREAM_LANES); e->stream_lanes = (uint32_t)iv; }
   else if (strcmp(name, "first_chunk") == 0)       { OPT_RANGE(0, 999); e->first_chunk = (uint32_t)iv; }
   else if (strcmp(name, "alt_streams") == 0)       { OPT_RANGE(0, 2); e->alt_streams = (int)iv; }
   else if (strcmp(name, "device_expand") == 0)     { OPT_RANGE(0, 1); e->device_expand = (int)iv; }
@@ -2925,8 +2925,8 @@ static int download_bytes(struct SLAEncoder* e, uint8_t* dst, const uint8_t* d_s
  * One file = upload (PCIe in), analysis (kernels), pack (kernels), download (PCIe out): four resources that the plain
  * path uses one after the other.  Blocks are independent and the only sequential thing in the format is
  * the super-frame hop, so the file is cut into pieces exactly as "one file, several GPUs" cuts it (sla_hip.h) -- only
- * that the "ranks" are worker lanes on ONE device: handles of their own (own streams, buffers, host threads), piece r
- * on lane r mod L.  A lane uploads its piece (+ one block of halo), scans it, takes over the hop where the piece
+ * that the "ranks" are worker lanes on ONE device: handles of their own (own streams, buffers, host threads); a lane that
+ * has delivered its piece takes the next piece nobody has taken.  A lane uploads its piece (+ one block of halo), scans it, takes over the hop where the piece
  * before it ended, analyses [bounds[r], bounds[r+1]), sizes its blocks, learns where they go in the caller's buffer
  * from the piece before it, and writes them there.  Uploads take turns in piece order (piece 0 should be analysed
  * while piece 1 is still on the bus, not share the bus with it).
@@ -2941,6 +2941,9 @@ typedef struct {
   uint32_t nominal[65];              /* piece r scans [nominal[r], nominal[r+1]) (multiples of 64) */
   pthread_mutex_t mu; pthread_cond_t cv;
   uint32_t upload_turn;              /* the piece whose upload may start */
+  uint32_t next_piece;               /* the next piece nobody has taken: a lane that has delivered its piece takes this one (round 3 dealt
+                                        piece r to lane r mod L: an upload then waited for ITS lane while another stood idle) */
+  uint8_t  lane_of[65];              /* (for the trace) */
   int      have_ntz; uint32_t ntz;   /* trailing zeros of piece 0's OR word */
   uint32_t bounds[65]; uint32_t bounds_known;      /* bounds[0..bounds_known) are final */
   uint64_t off[65]; uint32_t off_known;            /* byte offset of piece r's first block in the file */
@@ -2991,7 +2994,12 @@ static void* stream_lane_main(void* varg)
   const int32_t* planes[SLAI_MAX_CHANNELS];
   uint64_t* mask = NULL; size_t mask_cap = 0;
   uint32_t r, ch;
-  for (r = sa->lane; r < sc->K; r += sc->L) {
+  for (;;) {
+    pthread_mutex_lock(&sc->mu);
+    r = sc->next_piece++;
+    if (r < sc->K) { sc->lane_of[r] = (uint8_t)sa->lane; }
+    pthread_mutex_unlock(&sc->mu);
+    if (r >= sc->K) { break; }
     const uint32_t lo = sc->nominal[r], nominal_hi = sc->nominal[r + 1];
     const uint32_t hi = (sc->n - nominal_hi > sc->maxb) ? nominal_hi + sc->maxb : sc->n;      /* + the halo the hop may run into */
     const uint32_t cnt = hi - lo;
@@ -3120,8 +3128,8 @@ static int encode_whole_streamed(struct SLAEncoder* e, const int32_t* const* inp
 {
   const uint32_t C = e->wave_format.num_channels;
   stream_ctx_t* sc;
-  stream_arg_t args[4];
-  pthread_t th[4];
+  stream_arg_t args[SLAI_STREAM_LANES];
+  pthread_t th[SLAI_STREAM_LANES];
   uint32_t piece, K, L, r, t, started = 0;
   int rc = 0;
   struct SLAHeaderInfo hinfo;
@@ -3153,7 +3161,7 @@ static int encode_whole_streamed(struct SLAEncoder* e, const int32_t* const* inp
   rc = sc->failed;
   if (e->trace) {
     for (r = 0; r < K; r++) {
-      fprintf(stderr, "[sla_hip] piece %2u lane %u: upload %7.3f..%7.3f scanned %7.3f hop %7.3f analysed %7.3f sized %7.3f delivered %7.3f ms\n", r, r % L,
+      fprintf(stderr, "[sla_hip] piece %2u lane %u: upload %7.3f..%7.3f scanned %7.3f hop %7.3f analysed %7.3f sized %7.3f delivered %7.3f ms\n", r, (uint32_t)sc->lane_of[r],
               sc->stamp[r][0], sc->stamp[r][1], sc->stamp[r][2], sc->stamp[r][3], sc->stamp[r][4], sc->stamp[r][5], sc->stamp[r][6]);
     }
   }

@@ -37,6 +37,7 @@
 #define SLAI_BLK_CRC_START        8
 #define SLAI_MAX_ORDER            255
 #define SLAI_MAX_TAPS             5
+#define SLAI_STREAM_LANES         6       /* worker lanes of a streamed SLAEncoder_EncodeWhole, at most */
 #define SLAI_MAX_NODES            66      /* 65535 / 1024 + 2 */
 enum { SLAI_BLK_COMPRESS = 0, SLAI_BLK_SILENT = 1, SLAI_BLK_RAW = 2 };
 
