@@ -294,9 +294,13 @@ int sla_hip_launch_plan(const sla_hip_lpc_group* d_groups, uint32_t num_superfra
  * block-stage kernels can follow the partition search without the host building and uploading their descriptors
  * (the host part of src/SLAEncoder.c:846-869: the walk over the super-frames that numbers the blocks).
  * d_superframes: the run, in file order.  A live super-frame names its row of d_parts / d_num_parts / d_status; one
- * that is a single SILENT block (live == SLA_HIP_NOT_LIVE) takes one block index and produces no group.  No block of
- * a live super-frame is treated as silent: the caller uses this only for input whose non-zero mask has no all-zero
+ * that is a single SILENT block (live == SLA_HIP_NOT_LIVE) takes one block index and produces no group.
+ * sla_hip_launch_expand treats no block of a live super-frame as silent: for input whose non-zero mask has no all-zero
  * word (sla_hip_launch_prepass: d_or_mask[1] == 0), where a block of SLA's minimum length cannot be.
+ * sla_hip_launch_expand_masked (round 4) also takes the prepass mask (d_nonzero_mask, bit s of word s / 64 = some
+ * channel's sample s is not zero; NULL = the plain call): a block of a live super-frame whose samples are all zero is
+ * a SILENT block (src/SLAEncoder.c:392-408) -- it takes a block index and produces no group, exactly as the host's walk
+ * numbers it -- so that files WITH silence get device-written tables too.
  * d_run: 4 words, zeroed by the caller before the first run of a file; d_prefix: 2 * num_superframes words of scratch (the
  * numbering is done by one workgroup, k_expand_scan, the descriptors are written by the whole device, k_expand_write).
  * Per (block, channel), numbered on from d_run[0] blocks / d_run[1] groups: d_groups[g] (windowed form: win_off looked
@@ -319,6 +323,13 @@ int sla_hip_launch_expand(const sla_hip_superframe* d_superframes, uint32_t num_
                           uint32_t* d_run, uint32_t* d_prefix, sla_hip_lpc_group* d_groups, sla_hip_lpc_cand* d_cands,
                           sla_hip_acf_job* d_acf_jobs, uint32_t group_capacity,
                           uint32_t* counts, uint32_t sequence, sla_hip_stream_t stream);
+int sla_hip_launch_expand_masked(const sla_hip_superframe* d_superframes, uint32_t num_superframes,
+                          const uint32_t* d_parts, const uint32_t* d_num_parts, const uint32_t* d_status,
+                          uint32_t num_channels, uint32_t int_shift,
+                          const uint32_t* d_win_len, const uint32_t* d_win_off, uint32_t num_windows,
+                          uint32_t* d_run, uint32_t* d_prefix, sla_hip_lpc_group* d_groups, sla_hip_lpc_cand* d_cands,
+                          sla_hip_acf_job* d_acf_jobs, uint32_t group_capacity,
+                          uint32_t* counts, uint32_t sequence, const uint64_t* d_nonzero_mask, sla_hip_stream_t stream);
 
 /* Building blocks of the per-call predictor API (include/SLAPredictor.h), also usable on their own:
  *   sla_hip_launch_lpc_f64      sla_hip_launch_lpc in its search form on samples that already are doubles
@@ -609,7 +620,8 @@ int sla_hip_get_trace(struct SLAEncoder* encoder, sla_hip_trace* trace);
  * for the file), "first_chunk" (1/1000 of the super-frames in pipeline chunk 0; 0: built-in shares), "alt_streams" (block
  * stages of odd and even pipeline chunks on two streams: 0 never, 1 / 2 = default: whenever the file is cut into chunks),
  * "device_expand" (1 = default: block tables of certified partitions written on the device, sla_hip_launch_expand, the
- * host's copy following under the kernels; 0: host tables first), "table_cache" (1 = default: the search tables of a file --
+ * host's copy following under the kernels; 0: host tables first), "expand_silence" (1 = default: input with silence takes
+ * the device tables too, sla_hip_launch_expand_masked; 0: host tables for such input), "table_cache" (1 = default: the search tables of a file --
  * or batch -- without silence are kept for the next one of the same layout and parameters), "prelaunch" (1 = default: short
  * files queue the certified block kernels together with the searches, sized for the most groups there can be, the kernels
  * reading the number from the device), "one_stream" (1: a one-chunk file keeps search, block stage and tail on one stream;

@@ -182,7 +182,7 @@ EXPORTED_SYMBOLS = [
     "sla_hip_analyze_device", "sla_hip_pack", "sla_hip_final_residual", "sla_hip_lattice_residual",
     "sla_hip_get_trace", "sla_hip_device_name", "sla_hip_last_timing", "sla_hip_launch_search_exact",
     "sla_hip_search_exact_lags", "sla_hip_launch_plan", "sla_hip_last_counters", "sla_hip_launch_lpc_rerun", "sla_hip_last_kernel_ms", "sla_hip_launch_lpc_blocks", "sla_hip_launch_lpc_blocks_cert", "sla_hip_last_block_cert", "sla_hip_last_cert_audit", "sla_hip_launch_batch_scan", "sla_hip_launch_lattice_groups_x", "sla_hip_launch_lpc_blocks_cert_x", "sla_hip_launch_lpc_blocks_x",
-    "sla_hip_launch_lpc_x", "sla_hip_launch_ltm_acf_x", "sla_hip_launch_search_exact_x", "sla_hip_launch_tail_x", "sla_hip_last_expand", "sla_hip_launch_expand",
+    "sla_hip_launch_lpc_x", "sla_hip_launch_ltm_acf_x", "sla_hip_launch_search_exact_x", "sla_hip_launch_tail_x", "sla_hip_last_expand", "sla_hip_launch_expand", "sla_hip_launch_expand_masked",
     "sla_hip_launch_lpc_f64", "sla_hip_launch_lattice_raw", "sla_hip_launch_tail_stages", "sla_hip_launch_emphasis_i32",
     "sla_hip_launch_emphasis_f64", "sla_hip_use_tuning", "sla_hip_launch_lattice_groups", "sla_hip_launch_ltm_solve",
     "sla_hip_encoder_set_option", "sla_hip_shard_scan", "sla_hip_shard_scan_counts", "sla_hip_shard_bounds", "sla_hip_shard_analyze", "sla_hip_shard_analyze_no_silence", "sla_hip_shard_header",

@@ -86,6 +86,8 @@ struct SLAEncoder {
                                      * slower; default 0) */
   int      device_expand;           /* 1 (default): the block table of certified partitions is written on the device (k_expand) and the block
                                      * stage launched from two counts, the host's own tables following under the kernels; 0: host tables first */
+  int      expand_silence;          /* 1 (default): files / batches WITH silence take device-written block tables too (k_expand reads the
+                                     * prepass mask: all-zero blocks of searched super-frames get no group); 0: host tables for them (rounds 2-3) */
   uint32_t expand_seq;              /* sequence number of the last k_expand launch (what the host polls for) */
   uint32_t expanded_chunks;         /* last analysis: pipeline chunks whose block stage was launched from device tables */
   /* Search tables (super-frames, candidate shapes, groups) of the last file WITHOUT silence, host and device copies, kept for
@@ -371,7 +373,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   e->block_cert = 1; e->block_cert_safety = 16.0;
   e->table_cache = 1;
   e->prelaunch = 1;
-  e->device_expand = 1;
+  e->device_expand = 1; e->expand_silence = 1;
   e->upload24 = 1;      /* profiles/r3_pack24_ab_*.json: plain path +13 % (C3) / +15 % (C5) from pageable memory, streamed path +1..3 % */
   e->stream_mode = 1; e->stream_piece = 32u << 20; e->stream_lanes = 6;
   /* measured on C2: the lattice inside k_lpc_blocks costs 0.6 ms per step (9 wave-chunks on the 8 waves of a workgroup
@@ -585,6 +587,7 @@ typedef struct {
   hipEvent_t* ev;                                 /* [nchunks][EV_PER_CHUNK]             */
   /* device-written block tables (k_expand) */
   int expand;                                     /* this run asks for them                       */
+  int silence;                                    /* the file (batch) has silence: k_expand reads the mask */
   int borrowed;                                   /* sf / shapes belong to the encoder's table cache */
   int tab_hit;                                    /* ... and were found there                         */
   int spec;                                       /* the searches are in flight on a guess of the prepass result */
@@ -987,11 +990,14 @@ static void decide_routes(struct SLAEncoder* e, actx_t* a, uint32_t or_word, int
   a->or_word = or_word;
   a->exact = (e->search_exact && SLAI_SEARCH_DELTA == SLA_HIP_XTILE && maxb <= SLA_HIP_XTILE * SLA_HIP_XTILES
               && sla_hip_search_exact_lags(order) != 0 && or_word != 0);
-  /* Block tables on the device (k_expand) where no block inside a searched super-frame can be SILENT: the mask has no
-   * all-zero word (or the caller vouched for that), so no run of zeros reaches SLA's minimum block length; whole SILENT
-   * super-frames (only the file's last one can be, then) are in the table the kernel reads.  A batch of files is one
-   * super-frame table like any other (the hop restarts at every file): same route when k_batch_scan found no silence. */
-  a->expand = (e->device_expand && e->device_plan && !silence && a->nsf > 0
+  /* Block tables on the device (k_expand).  Where the mask has no all-zero word (or the caller vouched for that) no run of
+   * zeros reaches SLA's minimum block length and no block inside a searched super-frame can be SILENT; whole SILENT
+   * super-frames are in the table the kernel reads.  With silence (round 4) the kernel reads the device's copy of the mask
+   * and leaves the all-zero blocks of searched super-frames without groups, as the host's walk does (plan_chunk, which
+   * still runs -- later, under the block kernels -- and must arrive at the same numbers: blocks_launch mode 2).  A batch of
+   * files is one super-frame table like any other (the hop restarts at every file). */
+  a->silence = silence;
+  a->expand = (e->device_expand && e->device_plan && (!silence || (e->expand_silence && e->d_nz.ptr != NULL)) && a->nsf > 0
                && e->winmap_entries > 0 && e->winmap_entries <= 256 && a->max_window <= MAX_ANALYSIS_WINDOW
                && e->d_sframes.ptr != NULL && e->h_counts.ptr != NULL);
 }
@@ -1289,12 +1295,12 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
         const uint32_t bps = e->wave_format.bit_per_sample;
         hc[0] = hc[1] = hc[2] = hc[3] = 0;
         if (c == 0 && !a->clear_in_kernel) { HIPCHK(hipMemsetAsync(e->d_run.ptr, 0, 16, e->stream)); }      /* the running block / group numbers restart */
-        RCCHK(sla_hip_launch_expand((const sla_hip_superframe*)e->d_sframes.ptr + k->sf_lo, k->sf_hi - k->sf_lo,
+        RCCHK(sla_hip_launch_expand_masked((const sla_hip_superframe*)e->d_sframes.ptr + k->sf_lo, k->sf_hi - k->sf_lo,
                                     (const uint32_t*)e->d_parts.ptr, (const uint32_t*)e->d_nparts.ptr, (const uint32_t*)e->d_pstatus.ptr,
                                     C, 32 - bps + e->lshift, (const uint32_t*)e->d_winmap.ptr, (const uint32_t*)e->d_winmap.ptr + e->winmap_entries,
                                     e->winmap_entries, (uint32_t*)e->d_run.ptr, (uint32_t*)e->d_expref.ptr, (sla_hip_lpc_group*)e->d_bgroups.ptr, (sla_hip_lpc_cand*)e->d_bcands.ptr,
                                     (sla_hip_acf_job*)e->d_acf_jobs.ptr, a->blocks_bound * C, (uint32_t*)e->h_counts.ptr + 4 * (size_t)c,
-                                    e->expand_seq, e->stream));
+                                    e->expand_seq, a->silence ? (const uint64_t*)e->d_nz.ptr : NULL, e->stream));
         HIPCHK(hipEventRecord(ev[EV_EXPANDED], e->stream));
         /* Short files: the first two kernels of the block stage go out right here, sized for the most groups the chunk can
          * have and reading the number from the device (sla_hip_launch_extra.d_group_count) -- the device starts on them the moment the
@@ -2112,6 +2118,7 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   else if (strcmp(name, "first_chunk") == 0)       { OPT_RANGE(0, 999); e->first_chunk = (uint32_t)iv; }
   else if (strcmp(name, "alt_streams") == 0)       { OPT_RANGE(0, 2); e->alt_streams = (int)iv; }
   else if (strcmp(name, "device_expand") == 0)     { OPT_RANGE(0, 1); e->device_expand = (int)iv; }
+  else if (strcmp(name, "expand_silence") == 0)    { OPT_RANGE(0, 1); e->expand_silence = (int)iv; }
   else if (strcmp(name, "one_stream") == 0)        { OPT_RANGE(0, 1); e->one_stream = (int)iv; }
   else if (strcmp(name, "prelaunch") == 0)         { OPT_RANGE(0, 1); e->prelaunch = (int)iv; }
   else if (strcmp(name, "table_cache") == 0)       { OPT_RANGE(0, 1); e->table_cache = (int)iv; e->tab_valid = 0; e->spec_valid = 0; }
@@ -3115,7 +3122,7 @@ static struct SLAEncoder* stream_lane(struct SLAEncoder* e, uint32_t t)
   l->chunks = e->chunks; l->chunks_forced = e->chunks_forced; l->first_chunk = e->first_chunk; l->split_count = 0;
   l->fuse_lattice = e->fuse_lattice; l->device_plan = e->device_plan; l->search_exact = e->search_exact; l->exact_bits = e->exact_bits;
   l->cert_safety = e->cert_safety; l->single_tail = e->single_tail; l->device_ltm = e->device_ltm; l->tune = e->tune;
-  l->block_cert = e->block_cert; l->block_cert_safety = e->block_cert_safety; l->alt_streams = e->alt_streams; l->device_expand = e->device_expand;
+  l->block_cert = e->block_cert; l->block_cert_safety = e->block_cert_safety; l->alt_streams = e->alt_streams; l->device_expand = e->device_expand; l->expand_silence = e->expand_silence;
   l->table_cache = e->table_cache; l->prelaunch = e->prelaunch; l->one_stream = e->one_stream;
   l->trace = 0;
   return l;

@@ -282,8 +282,9 @@ def test_batch_without_silence_takes_device_tables(oracle, hip):
 
 def test_batch_with_a_silent_tail_or_a_zero_word_takes_the_mask(oracle, hip):
     """the two things k_batch_scan looks for: a file whose last super-frame (< 127 samples) is all zero -- a SILENT block no
-    all-zero mask word betrays -- and an all-zero 64-sample word inside one file; either sends the batch through the host's
-    mask and tables, bytes as the oracle's"""
+    all-zero mask word betrays -- and an all-zero 64-sample word inside one file; either brings the batch's mask to the host
+    (the super-frame hop needs it) and makes k_expand read the device's copy; option expand_silence = 0: host tables; bytes as
+    the oracle's"""
     p = S.make_params(1, 16, 48000, 8, 1, 4, 0, 1, 4096)
     a = W.music_like(1, 4096 * 2 + 100, 16, seed=5)
     a[:, 4096 * 2:] = 0                                     # 100 zero samples = the whole last super-frame
@@ -300,11 +301,15 @@ def test_batch_with_a_silent_tail_or_a_zero_word_takes_the_mask(oracle, hip):
     try:
         enc.num_channels, enc.order, enc.ltm_order = 1, 8, 1
         enc.analyze_batch_device(d_pcm.data_ptr(), span, span, starts, [x.shape[1] for x in (b, e, d)])
-        assert enc.last_expand()[0] == 0                     # host tables
+        assert enc.last_expand()[0] >= 1                     # round 4: device tables, k_expand reads the mask
+        _check_trace(oracle, p, enc.trace(), starts, [b, e, d])
+        enc.set_option("expand_silence", 0)
+        enc.analyze_batch_device(d_pcm.data_ptr(), span, span, starts, [x.shape[1] for x in (b, e, d)])
+        assert enc.last_expand()[0] == 0                     # host tables (rounds 2-3)
         _check_trace(oracle, p, enc.trace(), starts, [b, e, d])
     finally:
         enc.close()
-    # (d's 125 zeros hold an aligned all-zero word: host tables too.)  A tail of 100 samples that is NOT silent, no zero word:
+    # (d's 125 zeros hold an aligned all-zero word: the mask route too.)  A tail of 100 samples that is NOT silent, no zero word:
     f = W.music_like(1, 4096 * 2 + 100, 16, seed=11)
     f[0, f[0] == 0] = 1 << 16
     g = b.copy()

@@ -1,7 +1,7 @@
 """Block tables written on the device (k_expand, option "device_expand"): the block stage is launched from two counts,
 the host's own tables follow under the kernels.  Same bytes as the host-table route and as the oracle; the route falls
-back to host tables chunk-wise when the device cannot certify a partition, and is not taken at all for input with
-all-zero mask words (where a block inside a super-frame could be SILENT).
+back to host tables chunk-wise when the device cannot certify a partition.  Input with all-zero mask words (where a block
+inside a super-frame can be SILENT) takes it too since round 4: k_expand reads the prepass mask (option "expand_silence").
 
 Reference: the walk over the super-frames that numbers the blocks, src/SLAEncoder.c:846-869."""
 import numpy as np
@@ -97,17 +97,83 @@ def test_uncertified_partitions_take_the_host_tables(oracle, hip):
     assert ed[0] == 0 and cnt[1] > 0
 
 
-def test_silence_keeps_the_host_tables(oracle, hip):
-    """all-zero mask words: a block inside a super-frame can be SILENT, the device tables are not used"""
+def test_silence_takes_device_tables_too(oracle, hip):
+    """all-zero mask words: a block inside a super-frame can be SILENT.  Round 4: k_expand reads the mask and gives such a
+    block a number but no group; option expand_silence = 0 keeps the host tables of rounds 2-3"""
     pcm = W.music_like(2, 400000, 16, seed=5)
     pcm[:, 100000:140000] = 0
     pcm[:, 390000:] = 0
     p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096)
     ret, want = oracle.encode_whole(p, pcm)
     assert ret == 0
-    got, ed, _ = _encode(hip, p, pcm, device_expand=1, stream=0)
+    got, ed, cnt = _encode(hip, p, pcm, device_expand=1, stream=0)
+    assert got == want
+    if cnt[1] == 0:
+        assert ed[0] == ed[1] >= 1, ed
+    got, ed, _ = _encode(hip, p, pcm, device_expand=1, expand_silence=0, stream=0)
     assert got == want
     assert ed[0] == 0
+
+
+SILENCE_CASES = [
+    # nch, bits, order, ms, maxb, super-frames
+    (1, 16, 16, 0, 4096, 40),
+    (2, 24, 32, 1, 16384, 24),
+    (3, 20, 48, 0, 8192, 20),
+    (2, 16, 8, 1, 2048, 60),
+]
+
+
+@pytest.mark.parametrize("nch,bits,order,ms,maxb,nsf", SILENCE_CASES)
+def test_silent_blocks_inside_searched_superframes(oracle, hip, nch, bits, order, ms, maxb, nsf):
+    """zero runs that do NOT begin where a super-frame begins: the super-frame is searched like any other and the blocks of
+    its partition that are all zero become SILENT blocks (src/SLAEncoder.c:392-408) -- a block number, no group -- between
+    compressed ones; zero runs that do begin there move the grid.  Device tables (k_expand with the mask), host tables and the
+    oracle agree on bytes and on the block table"""
+    rng = np.random.default_rng(nch * 1000 + maxb)
+    n = maxb * nsf + int(rng.integers(1, maxb))
+    pcm = W.music_like(nch, n, bits, seed=order + maxb)
+    nz = (pcm != 0).any(axis=0)
+    pcm[0, ~nz] = 1 << (32 - bits)                         # no accidental zero sample
+    at = 0
+    for k in range(nsf):
+        lo = k * maxb
+        kind = k % 6
+        if kind == 1:                                      # the second half of the window
+            pcm[:, lo + maxb // 2:lo + maxb] = 0
+        elif kind == 2 and maxb >= 4096:                   # a middle piece on the search grid
+            pcm[:, lo + 1024:lo + 1024 + 2048] = 0
+        elif kind == 3:                                    # everything but the first sample
+            pcm[:, lo + 1:lo + maxb] = 0
+        elif kind == 4:                                    # off the grid: from somewhere to the end of the window and beyond
+            s0 = lo + int(rng.integers(1, maxb // 2))
+            pcm[:, s0:lo + maxb + int(rng.integers(0, 3000))] = 0
+    p = S.make_params(nch, bits, 48000, order, 1, 8, ms, 1, maxb)
+    ret, want = oracle.encode_whole(p, pcm)
+    assert ret == 0
+    enc = hip.Encoder(p.cap_channels, p.cap_block_samples, p.cap_parcor_order, p.cap_longterm_order, p.cap_lms_order)
+    try:
+        enc.set_option("stream", 0)
+        enc.set_wave_format(nch, bits, 48000)
+        enc.set_encode_parameter(order, 1, 8, ms, 1, maxb)
+        got = enc.encode_whole(pcm)
+        ed, cnt = enc.last_expand()[:2], enc.last_counters()
+        tr = enc.trace(want_residuals=False)
+    finally:
+        enc.close()
+    assert got == want
+    if cnt[1] == 0:
+        assert ed[0] == ed[1] >= 1, ed
+    nb = tr.num_blocks
+    typ, start, ln = tr.blk_type[:nb], tr.blk_start[:nb], tr.blk_nsmpl[:nb]
+    # SILENT blocks that follow a compressed block of fewer than maxb samples: inside a searched super-frame (or right behind
+    # a ragged one -- both kinds are wanted)
+    inner = [(int(start[b]), int(ln[b])) for b in range(1, nb) if typ[b] == 1 and typ[b - 1] != 1 and ln[b - 1] < maxb]
+    assert len(inner) >= 2 or maxb == 2048, (inner, nb)          # (maxb = the minimum block length: a super-frame is one block)
+    assert _encode(hip, p, pcm, device_expand=0, stream=0)[0] == want
+    assert _encode(hip, p, pcm, expand_silence=0, stream=0)[0] == want
+    assert _encode(hip, p, pcm, chunks=3, stream=0)[0] == want
+    assert _encode(hip, p, pcm, stream=0, prelaunch=0, one_stream=1)[0] == want
 
 
 def test_silent_last_superframe(oracle, hip):
@@ -125,6 +191,7 @@ def test_silent_last_superframe(oracle, hip):
 def test_expand_launcher_rejects_bad_arguments(hip):
     L = hip.lib()
     assert L.sla_hip_launch_expand(None, 0, None, None, None, 1, 0, None, None, 0, None, None, None, None, None, 0, None, 1, None) != 0
+    assert L.sla_hip_launch_expand_masked(None, 0, None, None, None, 1, 0, None, None, 0, None, None, None, None, None, 0, None, 1, None, None) != 0
 
 
 def test_handle_reuse_across_routes(oracle, hip):
@@ -142,7 +209,7 @@ def test_handle_reuse_across_routes(oracle, hip):
             ret, want = oracle.encode_whole(p, pcm)
             assert ret == 0
             assert enc.encode_whole(pcm) == want
-            assert (enc.last_expand()[0] == 0) == (i == 2)
+            assert enc.last_expand()[0] >= 1                # (i == 2, silence: device tables through the mask since round 4)
     finally:
         enc.close()
 

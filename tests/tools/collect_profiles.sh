@@ -3,11 +3,12 @@ set -e
 cd "$(dirname "$0")/../.."
 for c in c2 c3 c5; do
   case $c in c2) tag=c2;; c3) tag=c3_600s;; c5) tag=c5_120s;; esac
+  U=$(echo $c | tr a-z A-Z)                              # prof_pmc.sh writes gpurun_out/pmc_<CFG>
   f=$(ls -t $(find gpurun_out/kt_$c -name "*kernel_stats.csv" 2>/dev/null) 2>/dev/null | head -1)
   [ -n "$f" ] && cp "$f" profiles/r4_kernel_stats_$tag.csv
-  [ -f gpurun_out/pmc_$c/pmc_traffic_$c.json ] && cp gpurun_out/pmc_$c/pmc_traffic_$c.json profiles/pmc_traffic_$c.json
+  [ -f gpurun_out/pmc_$U/pmc_traffic_$c.json ] && cp gpurun_out/pmc_$U/pmc_traffic_$c.json profiles/pmc_traffic_$c.json
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    f=$(ls -t $(find gpurun_out/pmc_$c/$ctr -name "*counter_collection.csv" 2>/dev/null) 2>/dev/null | head -1)
+    f=$(ls -t $(find gpurun_out/pmc_$U/$ctr -name "*counter_collection.csv" 2>/dev/null) 2>/dev/null | head -1)
     lower=$(echo $ctr | tr A-Z a-z)
     # per kernel: launches and mean counter value (the raw per-dispatch rows are megabytes)
     [ -n "$f" ] && python3 - "$f" "$ctr" > profiles/r4_pmc_${lower}_$c.csv <<'PY'
