@@ -27,6 +27,10 @@ DEFAULTS = {"chunks": 1, "first_chunk": 0, "single_tail": 1, "device_ltm": 1, "t
 
 
 def main():
+    global SETTINGS
+    if os.environ.get("SWEEP_SETTINGS"):                  # a JSON list of option dicts instead of the built-in list
+        import json
+        SETTINGS = json.loads(os.environ["SWEEP_SETTINGS"])
     cfg = sys.argv[1]
     nch, bits, rate, seconds, order, ltm, lms, ms, win, maxb, cap = bench.CONFIGS[cfg]
     if len(sys.argv) > 2 and sys.argv[2]:
