@@ -854,7 +854,7 @@ def test_random_parameter_walk_chunked(oracle, hip, seed):
 
 # ------------------------------------------------------------------ streamed SLAEncoder_EncodeWhole
 
-def _streamed(hip, p, pcm, piece, lanes, capacity=None):
+def _streamed(hip, p, pcm, piece, lanes, capacity=None, **options):
     enc = hip.Encoder(p.cap_channels, p.cap_block_samples, p.cap_parcor_order, p.cap_longterm_order, p.cap_lms_order)
     try:
         enc.set_wave_format(p.num_channels, p.bits_per_sample, p.sampling_rate)
@@ -862,6 +862,8 @@ def _streamed(hip, p, pcm, piece, lanes, capacity=None):
                                  p.window_type, p.max_block_samples)
         enc.set_option("stream_piece", piece)
         enc.set_option("stream_lanes", lanes)
+        for k, v in options.items():
+            enc.set_option(k, v)
         first = enc.encode_whole(pcm, capacity=capacity)
         second = enc.encode_whole(pcm, capacity=capacity)         # the lanes are reused
         assert first == second
@@ -893,6 +895,7 @@ def test_streamed_encode_whole(oracle, hip, nch, bits, ms, maxb, piece, lanes):
     ret, want, _ = oracle.encode_trace(p, pcm)
     assert ret == 0
     assert _streamed(hip, p, pcm, piece, lanes) == want
+    assert _streamed(hip, p, pcm, piece, 6) == want               # six lanes, pieces to whichever is free
 
 
 def test_streamed_pieces_disagree_on_offset_lshift(oracle, hip):
