@@ -123,6 +123,8 @@ struct SLAEncoder {
   size_t nz_ones_cap; uint64_t nz_ones_words;    /* h_nz words [0, nz_ones_words) are known to be all ones (h_nz.cap == nz_ones_cap) */
   pinbuf_t h_stage[2]; devbuf_t d_stage[2]; hipEvent_t ev_stage[2];
   hipEvent_t ev_prep;               /* the prepass result has reached the host */
+  hipEvent_t ev_tables;             /* the search tables have reached the device (upload stream) */
+  int      groups_valid;            /* d_groups holds the sliced search groups of the current tables (search_groups_ready) */
   hipEvent_t ev_pack[4];            /* device pack: the blocks of a quarter of the image are written and checksummed */
 
   /* window pool: tables for every block length seen so far */
@@ -360,7 +362,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   e->own_copy_streams = 1;
   for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { if (hipEventCreate(&e->ev[i]) != hipSuccess) { goto fail; } }
   if (hipEventCreate(&e->ev_stage[0]) != hipSuccess || hipEventCreate(&e->ev_stage[1]) != hipSuccess
-      || hipEventCreate(&e->ev_prep) != hipSuccess) { goto fail; }
+      || hipEventCreate(&e->ev_prep) != hipSuccess || hipEventCreateWithFlags(&e->ev_tables, hipEventDisableTiming) != hipSuccess) { goto fail; }
   for (i = 0; i < 4; i++) { if (hipEventCreate(&e->ev_pack[i]) != hipSuccess) { goto fail; } }
   /* the defaults of every knob; sla_hip_encoder_set_option changes them afterwards.  Nothing but SLA_HIP_TRACE comes from the
    * environment (rounds 1 - 3 read some thirty variables here) */
@@ -457,6 +459,7 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   }
   for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { if (e->ev[i] != NULL) { (void)hipEventDestroy(e->ev[i]); } }
   if (e->ev_prep != NULL) { (void)hipEventDestroy(e->ev_prep); }
+  if (e->ev_tables != NULL) { (void)hipEventDestroy(e->ev_tables); }
   for (i = 0; i < 4; i++) { if (e->ev_pack[i] != NULL) { (void)hipEventDestroy(e->ev_pack[i]); } }
   if (e->own_copy_streams) {
     if (e->stream_up != NULL) { (void)hipStreamDestroy(e->stream_up); }
@@ -716,7 +719,7 @@ static int build_tables(struct SLAEncoder* e, actx_t* a, const uint64_t* nz)
   const uint32_t n = e->num_samples, maxb = e->encode_param.max_num_block_samples;
   extern uint32_t sla_hip_lattice_chunk_samples(uint32_t order);
   const uint32_t chunk_samples = sla_hip_lattice_chunk_samples(order);
-  sla_hip_lpc_cand* cands; sla_hip_lpc_group* groups;
+  sla_hip_lpc_cand* cands;
   uint32_t sf_cap = 0, shapes_cap = 8, pos, i, sg;
   const uint32_t nsegs = e->nsegs ? e->nsegs : 1u;
 
@@ -811,7 +814,10 @@ static int build_tables(struct SLAEncoder* e, actx_t* a, const uint64_t* nz)
     RCCHK(pin_reserve(&e->h_groups, sizeof(sla_hip_lpc_group) * total_groups));
     RCCHK(pin_reserve(&e->h_xgroups, sizeof(sla_hip_lpc_group) * ((size_t)a->nsf * C + 1)));
   }
-  groups = (sla_hip_lpc_group*)e->h_groups.ptr;
+  /* The sliced groups are what the serial-chain kernels read: the search without tile sums, and the rerun of what the tile sums
+   * could not certify -- the exception.  Here they are only counted; search_groups_ready() writes and uploads them for whoever
+   * needs them (an hour of stereo: 84 k descriptors, 3.4 MB, built and sent for nothing on every file whose tables are new). */
+  e->groups_valid = 0;
   a->max_window = 1; a->max_cpg = 1; a->max_xcands = 1;
   /* candidates start on multiples of SLAI_SEARCH_DELTA and end on one or with the window: tile aligned */
   a->exact = (e->search_exact && SLAI_SEARCH_DELTA == SLA_HIP_XTILE && maxb <= SLA_HIP_XTILE * SLA_HIP_XTILES
@@ -828,13 +834,9 @@ static int build_tables(struct SLAEncoder* e, actx_t* a, const uint64_t* nz)
     f->slot_base = a->nslots;
     for (ch = 0; ch < C; ch++) {
       for (first = 0; first < sh->ncand; first += cpg) {
-        sla_hip_lpc_group* g = &groups[a->nsgroups++];
-        g->pcm_off = f->start; g->num_samples = sh->window; g->channel = ch;
-        g->win_off = SLA_HIP_NO_WINDOW; g->int_shift = 32 - bps;
-        g->cand_first = sh->cand_first + first;
-        g->cand_count = (sh->ncand - first < cpg) ? (sh->ncand - first) : cpg;
-        g->slot_first = a->nslots + ch * sh->ncand + first; g->pad_ = 0;
-        if (g->cand_count > a->max_cpg) { a->max_cpg = g->cand_count; }
+        const uint32_t count = (sh->ncand - first < cpg) ? (sh->ncand - first) : cpg;
+        a->nsgroups++;
+        if (count > a->max_cpg) { a->max_cpg = count; }
       }
     }
     f->grp_hi = a->nsgroups;
@@ -855,17 +857,56 @@ static int build_tables(struct SLAEncoder* e, actx_t* a, const uint64_t* nz)
 
 static int pipeline_reserve(struct SLAEncoder* e, const actx_t* a);
 
-/* candidate and group tables of the partition search -> device (in order on the search stream) */
-static int upload_search_tables(struct SLAEncoder* e, const actx_t* a)
+/* the sliced search groups of the current tables (counted by build_tables), written and sent to the device the first time a
+ * serial-chain kernel is about to read them; in order on the search stream */
+static int search_groups_ready(struct SLAEncoder* e, const actx_t* a)
 {
+  const uint32_t C = e->wave_format.num_channels, bps = e->wave_format.bit_per_sample;
+  const uint32_t O1 = e->encode_param.parcor_order + 1;
+  sla_hip_lpc_group* groups = (sla_hip_lpc_group*)e->h_groups.ptr;
+  uint32_t i;
+  if (e->groups_valid || a->nsgroups == 0) { return 0; }
+  if (groups == NULL || e->d_groups.ptr == NULL) { return SLA_APIRESULT_NG; }
+  for (i = 0; i < a->nsf; i++) {
+    const sframe_t* f = &a->sf[i];
+    const shape_t* sh;
+    uint32_t cpg, ch, first, g = f->grp_lo;
+    if (f->shape == 0xFFFFFFFFu) { continue; }
+    sh = &a->shapes[f->shape];
+    cpg = (uint32_t)((SLA_HIP_LDS_BUDGET / 8 - sh->window) / O1);
+    if (cpg > sh->ncand) { cpg = sh->ncand; }
+    for (ch = 0; ch < C; ch++) {
+      for (first = 0; first < sh->ncand; first += cpg) {
+        sla_hip_lpc_group* gr = &groups[g++];
+        gr->pcm_off = f->start; gr->num_samples = sh->window; gr->channel = ch;
+        gr->win_off = SLA_HIP_NO_WINDOW; gr->int_shift = 32 - bps;
+        gr->cand_first = sh->cand_first + first;
+        gr->cand_count = (sh->ncand - first < cpg) ? (sh->ncand - first) : cpg;
+        gr->slot_first = f->slot_base + ch * sh->ncand + first; gr->pad_ = 0;
+      }
+    }
+    if (g != f->grp_hi) { return SLA_APIRESULT_NG; }
+  }
+  HIPCHK(hipMemcpyAsync(e->d_groups.ptr, groups, sizeof(sla_hip_lpc_group) * a->nsgroups, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));            /* (h_groups may be rewritten by the next file's tables) */
+  e->groups_valid = 1;
+  return 0;
+}
+
+/* candidate and group tables of the partition search -> device (in order on the search stream) */
+/* beside: 0 = in order on the search stream, behind the prepass (every caller today); 1 = on the block-stage stream beside it,
+ * the search stream waiting for an event.  The second form was measured (round 4, tests/tools/nocache_ab.sh): the typical C3
+ * step without kept tables got another 0.15 ms shorter, but in one step of three a later launch call of the same analysis
+ * then blocked for milliseconds (the block stage went out 7 ms late, the step took 12.6 instead of 9.5 ms) -- on the upload
+ * stream and on the block-stage stream alike; not understood, not used. */
+static int upload_search_tables(struct SLAEncoder* e, const actx_t* a, int beside)
+{
+  const hipStream_t us = beside ? e->stream2 : e->stream;
   if (a->ncands > 0) {
-    HIPCHK(hipMemcpyAsync(e->d_cands.ptr, e->h_cands.ptr, sizeof(sla_hip_lpc_cand) * a->ncands, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_cands.ptr, e->h_cands.ptr, sizeof(sla_hip_lpc_cand) * a->ncands, hipMemcpyHostToDevice, us));
   }
   if (a->nxg > 0) {
-    HIPCHK(hipMemcpyAsync(e->d_xgroups.ptr, e->h_xgroups.ptr, sizeof(sla_hip_lpc_group) * a->nxg, hipMemcpyHostToDevice, e->stream));
-  }
-  if (a->nsgroups > 0) {
-    HIPCHK(hipMemcpyAsync(e->d_groups.ptr, e->h_groups.ptr, sizeof(sla_hip_lpc_group) * a->nsgroups, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_xgroups.ptr, e->h_xgroups.ptr, sizeof(sla_hip_lpc_group) * a->nxg, hipMemcpyHostToDevice, us));
   }
   if (e->device_expand && e->device_plan && a->nsf > 0 && e->win_entries > 0) {
     /* what k_expand reads: the super-frames in file order and the window offset of every block length */
@@ -884,9 +925,13 @@ static int upload_search_tables(struct SLAEncoder* e, const actx_t* a)
       hs[i].live = (a->sf[i].shape == 0xFFFFFFFFu) ? SLA_HIP_NOT_LIVE : a->sf[i].xg / C;
     }
     for (i = 0; i < e->win_entries; i++) { hw[i] = e->win_len[i]; hw[e->win_entries + i] = e->win_off[i]; }
-    HIPCHK(hipMemcpyAsync(e->d_sframes.ptr, hs, sizeof(sla_hip_superframe) * a->nsf, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->d_winmap.ptr, hw, sizeof(uint32_t) * 2 * e->win_entries, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_sframes.ptr, hs, sizeof(sla_hip_superframe) * a->nsf, hipMemcpyHostToDevice, us));
+    HIPCHK(hipMemcpyAsync(e->d_winmap.ptr, hw, sizeof(uint32_t) * 2 * e->win_entries, hipMemcpyHostToDevice, us));
     e->winmap_entries = e->win_entries;
+  }
+  if (beside) {
+    HIPCHK(hipEventRecord(e->ev_tables, us));
+    HIPCHK(hipStreamWaitEvent(e->stream, e->ev_tables, 0));
   }
   return 0;
 }
@@ -911,7 +956,7 @@ static int tables_no_silence(struct SLAEncoder* e, actx_t* a)
   free(e->tab_sf); free(e->tab_shapes); e->tab_sf = NULL; e->tab_shapes = NULL;
   RCCHK(build_tables(e, a, NULL));
   RCCHK(pipeline_reserve(e, a));
-  RCCHK(upload_search_tables(e, a));
+  RCCHK(upload_search_tables(e, a, 0));
   if (e->table_cache) {
     uint32_t* c = e->tab_cnt;
     /* (the window list may have grown while the tables were built: the key holds what it is now) */
@@ -949,7 +994,7 @@ static int tables_batch_no_silence(struct SLAEncoder* e, actx_t* a)
   free(e->tab_sf); free(e->tab_shapes); e->tab_sf = NULL; e->tab_shapes = NULL;
   RCCHK(build_tables(e, a, NULL));                         /* no mask: nothing is silent */
   RCCHK(pipeline_reserve(e, a));
-  RCCHK(upload_search_tables(e, a));
+  RCCHK(upload_search_tables(e, a, 0));
   if (e->table_cache) {
     uint32_t* c = e->tab_cnt;
     uint32_t* segs = (uint32_t*)realloc(e->tab_segs, seg_bytes ? seg_bytes : 4);
@@ -1028,7 +1073,7 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
     e->tab_valid = 0;                                     /* the batch's tables take the place of the kept ones */
     RCCHK(build_tables(e, a, (const uint64_t*)e->h_nz.ptr));
     RCCHK(pipeline_reserve(e, a));
-    RCCHK(upload_search_tables(e, a));
+    RCCHK(upload_search_tables(e, a, 0));
     decide_routes(e, a, e->h_or[0], 1);
     return 0;
   }
@@ -1120,7 +1165,7 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
     a->blocks_bound = 0; a->lchunks_bound = 0;
     RCCHK(build_tables(e, a, nz));
     RCCHK(pipeline_reserve(e, a));
-    RCCHK(upload_search_tables(e, a));
+    RCCHK(upload_search_tables(e, a, 0));
   }
   {
     const int silence = (rebuild || e->h_or[1] != 0);
@@ -1270,12 +1315,14 @@ static int search_launch(struct SLAEncoder* e, actx_t* a, uint32_t c)
       RCCHK(sla_hip_launch_search_exact_x(e->pcm_dev, e->stride, ms, order, dx, nx, a->max_window, a->max_xcands, (const sla_hip_lpc_cand*)e->d_cands.ptr,
                                           (double*)e->d_tile_sums.ptr + (size_t)k->xg_lo * SLA_HIP_XTILES * 2 * sla_hip_search_exact_lags(order),
                                           (double*)e->d_lpc_out.ptr, limit, cert, (uint32_t*)e->d_or.ptr + 8 + c, e->stream, &xs));
+      if (!(cert > 0.0)) { RCCHK(search_groups_ready(e, a)); }
       if (!(cert > 0.0))
       RCCHK(sla_hip_launch_lpc_rerun(e->pcm_dev, e->stride, ms, order, (const sla_hip_lpc_group*)e->d_groups.ptr + k->grp_lo, ng,
                                      a->max_window, a->max_cpg, (const sla_hip_lpc_cand*)e->d_cands.ptr, (double*)e->d_lpc_out.ptr,
                                      (uint32_t*)e->d_or.ptr + 2, e->stream));
     } else {
       sla_hip_lpc_group* dg = (sla_hip_lpc_group*)e->d_groups.ptr + k->grp_lo;
+      RCCHK(search_groups_ready(e, a));
       HIPCHK(hipEventRecord(ev[EV_SEARCH_S], e->stream));
       RCCHK(sla_hip_launch_lpc(e->pcm_dev, e->stride, ms, order, dg, ng, a->max_window, a->max_cpg,
                                (const sla_hip_lpc_cand*)e->d_cands.ptr, NULL, (double*)e->d_lpc_out.ptr, NULL, NULL, NULL, e->stream));
@@ -1377,6 +1424,7 @@ static int plan_chunk(struct SLAEncoder* e, actx_t* a, uint32_t c)
        * groups in the reference's order (the others return at once) before the doubles come home */
       const uint32_t order = e->encode_param.parcor_order;
       const uint32_t ms = (e->encode_param.ch_process_method == SLA_CHPROCESSMETHOD_STEREO_MS);
+      RCCHK(search_groups_ready(e, a));
       RCCHK(sla_hip_launch_lpc_rerun(e->pcm_dev, e->stride, ms, order, (const sla_hip_lpc_group*)e->d_groups.ptr + k->grp_lo, k->grp_hi - k->grp_lo,
                                      a->max_window, a->max_cpg, (const sla_hip_lpc_cand*)e->d_cands.ptr, (double*)e->d_lpc_out.ptr,
                                      (uint32_t*)e->d_or.ptr + 2, e->stream));
