@@ -671,7 +671,22 @@ def run_config(torch, sla_amd, S, cfg, args, rank, world, primary, cpu_results=N
         e2e = (time.perf_counter() - t1) / reps
         sla_bytes = int(sum(len(d) for _, d in got))
         h2d = n_own * nch * upload_bytes_per_sample(bits)
+        # the same batch in one piece (option batch_lanes = 1: upload, analysis, pack, download one after the other): the bytes
+        # must be the same, file by file
+        lanes_bytes = [bytes(d) for _, d in got]
+        enc2.set_option("batch_lanes", 1)
+        plain = enc2.encode_batch(batch["clips"], outs=outs)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            plain = enc2.encode_batch(batch["clips"], outs=outs)
+        e2e_plain = (time.perf_counter() - t1) / reps
+        lanes_equal = (lanes_bytes == [bytes(d) for _, d in plain])
+        enc2.set_option("batch_lanes", 4)
+        if not lanes_equal:
+            print(json.dumps({"error": "sla_hip_encode_batch on worker lanes and in one piece differ"}), flush=True)
+            sys.exit(3)
         out["end_to_end"] = {"msamples_s": round(n_own * nch / e2e / 1e6, 3), "samples": n_own * nch,
+                             "one_piece_msamples_s": round(n_own * nch / e2e_plain / 1e6, 3), "lanes_equal_one_piece": lanes_equal,
                              "sla_bytes": sla_bytes, "files_ok": int(sum(1 for rc, _ in got if rc == 0)),
                              "pcie_bytes_up": h2d, "pcie_bytes_down": sla_bytes,
                              "pcie_frac_up": round(h2d / e2e / 1e9 / PCIE_PEAK_GBS, 4), "pcie_frac_down": round(sla_bytes / e2e / 1e9 / PCIE_PEAK_GBS, 4),

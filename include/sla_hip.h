@@ -628,7 +628,9 @@ int sla_hip_get_trace(struct SLAEncoder* encoder, sla_hip_trace* trace);
  * measured slower, default 0), "upload24" (1 = default: pageable input of 17..24 significant bits crosses the bus as three
  * bytes per sample; DESIGN section 7 has the A/B).
  * SLAEncoder_EncodeWhole of long files: "stream" (0: never streamed), "stream_piece" (samples per piece, all channels
- * together; default 32 Mi; a file of fewer than two pieces is not streamed), "stream_lanes" (worker lanes, 1..6, default 6; pieces are handed to whichever lane is free).
+ * together; default 32 Mi; a file of fewer than two pieces is not streamed), "stream_lanes" (worker lanes, 1..6, default 6; pieces are handed to whichever lane is free),
+ * "batch_lanes" (sla_hip_encode_batch: a batch of at least 8 files and 16 Mi samples is dealt out in groups of consecutive files to
+ * that many worker lanes, uploads taking turns, everything behind them overlapping; 1..6, default 4; 1 = the batch in one piece).
  * After a streamed call the handle holds no analysis tables: sla_hip_get_trace / sla_hip_pack / sla_hip_final_residual answer
  * SLA_APIRESULT_PARAMETER_NOT_SET (NULL).
  * Returns SLA_APIRESULT_INVALID_ARGUMENT for an unknown name or a value out of range. */

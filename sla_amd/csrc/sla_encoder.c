@@ -156,6 +156,9 @@ struct SLAEncoder {
   int      stream_mode;             /* 1 (default): on for files of at least two pieces */
   uint32_t stream_piece;            /* samples (all channels together) per piece */
   uint32_t stream_lanes;            /* worker lanes (1..SLAI_STREAM_LANES) */
+  uint32_t batch_lanes;             /* sla_hip_encode_batch: worker lanes a big batch is dealt out to (1: none; default 4) */
+  pthread_mutex_t* upload_gate;     /* a lane of a batch: uploads take turns (the parent's mutex), everything behind them overlaps */
+  double   batch_stamp[4];          /* last encode_batch_pass: upload begun / done, analysed, delivered (ms, now_ms) */
   struct SLAEncoder* lane[SLAI_STREAM_LANES];
   int      is_lane;
   struct slai_pool* upload_pool;    /* a lane's staging copies of its upload run on the parent's (otherwise idle, larger) pool: uploads take turns */
@@ -377,7 +380,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   e->prelaunch = 1;
   e->device_expand = 1; e->expand_silence = 1;
   e->upload24 = 1;      /* profiles/r3_pack24_ab_*.json: plain path +13 % (C3) / +15 % (C5) from pageable memory, streamed path +1..3 % */
-  e->stream_mode = 1; e->stream_piece = 32u << 20; e->stream_lanes = 6;
+  e->stream_mode = 1; e->stream_piece = 32u << 20; e->stream_lanes = 6; e->batch_lanes = 4;
   /* measured on C2: the lattice inside k_lpc_blocks costs 0.6 ms per step (9 wave-chunks on the 8 waves of a workgroup
    * that has nothing else left to overlap them with), its own launch 0.27 ms: separate by default */
   e->fuse_lattice = 0;
@@ -2162,6 +2165,7 @@ int sla_hip_encoder_set_option(struct SLAEncoder* e, const char* name, double va
   else if (strcmp(name, "single_tail") == 0)       { OPT_RANGE(0, 1); e->single_tail = (int)iv; }
   else if (strcmp(name, "stream") == 0)            { OPT_RANGE(0, 1); e->stream_mode = (int)iv; }
   else if (strcmp(name, "stream_piece") == 0)      { OPT_RANGE(1024, 1 << 30); e->stream_piece = (uint32_t)iv; }
+  else if (strcmp(name, "batch_lanes") == 0)       { OPT_RANGE(1, SLAI_STREAM_LANES); e->batch_lanes = (uint32_t)iv; }
   else if (strcmp(name, "stream_lanes") == 0)      { OPT_RANGE(1, SLAI_STREAM_LANES); e->stream_lanes = (uint32_t)iv; }
   else if (strcmp(name, "first_chunk") == 0)       { OPT_RANGE(0, 999); e->first_chunk = (uint32_t)iv; }
   else if (strcmp(name, "alt_streams") == 0)       { OPT_RANGE(0, 2); e->alt_streams = (int)iv; }
@@ -3326,7 +3330,7 @@ static int upload_batch_pass(struct SLAEncoder* e, const sla_hip_batch_item* ite
       ctx.ch = ch; ctx.plane_lo = o; ctx.n = n;
       ctx.dst16 = mode16 ? (int16_t*)e->h_stage[slot].ptr : NULL;
       ctx.dst32 = mode16 ? NULL : (int32_t*)e->h_stage[slot].ptr;
-      parallel_for(e->pool, (uint32_t)((n + XFER_GRAIN - 1) / XFER_GRAIN), stage_batch_one, &ctx);
+      parallel_for(e->upload_pool != NULL ? e->upload_pool : e->pool, (uint32_t)((n + XFER_GRAIN - 1) / XFER_GRAIN), stage_batch_one, &ctx);
       if (mode16) {
         HIPCHK(hipMemcpyAsync(e->d_stage[slot].ptr, e->h_stage[slot].ptr, n * 2, hipMemcpyHostToDevice, e->stream));
         RCCHK(sla_hip_launch_unpack16((const int16_t*)e->d_stage[slot].ptr, dst, n, e->stream));
@@ -3423,8 +3427,13 @@ static int encode_batch_pass(struct SLAEncoder* e, sla_hip_batch_item* items, ui
 #define BATCH_HIP(call) do { if ((call) != hipSuccess) { rc = SLA_APIRESULT_NG; goto done; } } while (0)
   BATCH_CHK(dev_reserve(&e->d_pcm, sizeof(int32_t) * (size_t)C * (stride + 64)));
   for (i = 0; i < 2; i++) { BATCH_CHK(pin_reserve(&e->h_stage[i], XFER_SLOT_BYTES)); BATCH_CHK(dev_reserve(&e->d_stage[i], XFER_SLOT_BYTES)); }
-  BATCH_CHK(upload_batch_pass(e, items, start, first, count, (size_t)span, stride, mode16, &lowbits));
-  if (mode16 && lowbits != 0) { BATCH_CHK(upload_batch_pass(e, items, start, first, count, (size_t)span, stride, 0, &lowbits)); }
+  if (e->upload_gate != NULL) { pthread_mutex_lock(e->upload_gate); }
+  e->batch_stamp[0] = now_ms();
+  rc = upload_batch_pass(e, items, start, first, count, (size_t)span, stride, mode16, &lowbits);
+  if (rc == 0 && mode16 && lowbits != 0) { rc = upload_batch_pass(e, items, start, first, count, (size_t)span, stride, 0, &lowbits); }
+  e->batch_stamp[1] = now_ms();
+  if (e->upload_gate != NULL) { pthread_mutex_unlock(e->upload_gate); }
+  if (rc != 0) { goto done; }
   e->pcm_dev = (const int32_t*)e->d_pcm.ptr; e->stride = stride; e->num_samples = (uint32_t)span;
 
   /* prepass over everything: silence mask, offset_lshift per file */
@@ -3457,6 +3466,7 @@ static int encode_batch_pass(struct SLAEncoder* e, sla_hip_batch_item* items, ui
     if (rc != 0) { goto done; }
     e->wave_format.offset_lshift = (uint8_t)e->lshift;
     e->analysed = 1;
+    e->batch_stamp[2] = now_ms();
     for (s = 0; s < ns; s++) {
       memset(&segs[s], 0, sizeof(segs[s]));
       segs[s].lo = seg_start[s]; segs[s].hi = seg_start[s] + seg_len[s];
@@ -3468,6 +3478,7 @@ static int encode_batch_pass(struct SLAEncoder* e, sla_hip_batch_item* items, ui
     for (s = 0; s < ns; s++) { items[seg_item[s]].result = segs[s].result; items[seg_item[s]].output_size = (segs[s].result == 0) ? segs[s].out_size : 0; }
   }
 done:
+  e->batch_stamp[3] = now_ms();
   e->nsegs = 0; e->seg_start = NULL; e->seg_len = NULL;
   e->analysed = 0;                                        /* the planes hold a batch, not a file: no trace / pack afterwards */
   free(start); free(segs);
@@ -3531,6 +3542,103 @@ int sla_hip_analyze_batch_device(struct SLAEncoder* e, const int32_t* d_pcm, uin
   return 0;
 }
 
+/* A big batch on worker lanes (round 4).  Done in one piece, the legs of sla_hip_encode_batch follow one another -- staging and
+ * upload of every file, analysis, Rice walk + bit-pack, download of every file: 25.7 ms for 125 ten-second stereo clips whose
+ * analysis takes 3.1 -- with the bus idle under the kernels and the device idle under the bus.  Files are independent, so the
+ * batch is dealt out in groups of consecutive files to lanes (handles of their own on the same device, one host thread each;
+ * the lanes of the streamed SLAEncoder_EncodeWhole): a lane that has delivered its group takes the next one, uploads take turns
+ * (one mutex), and everything behind a group's upload -- kernels, pack, download -- runs beside the other lanes' uploads. */
+typedef struct {
+  struct SLAEncoder* parent; sla_hip_batch_item* items;
+  uint32_t ngroups, next; uint32_t lo[4 * SLAI_STREAM_LANES + 1];
+  pthread_mutex_t mu, gate; int failed;
+  double t0, stamp[4 * SLAI_STREAM_LANES][5]; uint8_t lane_of[4 * SLAI_STREAM_LANES];
+} batch_ctx_t;
+typedef struct { batch_ctx_t* bc; uint32_t lane; } batch_arg_t;
+
+static void* batch_lane_main(void* varg)
+{
+  batch_arg_t* ba = (batch_arg_t*)varg;
+  batch_ctx_t* bc = ba->bc;
+  struct SLAEncoder* l = bc->parent->lane[ba->lane];
+  for (;;) {
+    uint32_t g;
+    int rc;
+    pthread_mutex_lock(&bc->mu);
+    g = bc->next++;
+    if (bc->failed != 0) { g = bc->ngroups; }
+    pthread_mutex_unlock(&bc->mu);
+    if (g >= bc->ngroups) { break; }
+    bc->stamp[g][0] = now_ms() - bc->t0;
+    l->upload_gate = &bc->gate; l->upload_pool = bc->parent->pool;      /* (the gate also makes the parent's pool one lane's at a time) */
+    rc = sla_hip_encode_batch(l, bc->items + bc->lo[g], bc->lo[g + 1] - bc->lo[g]);
+    l->upload_gate = NULL; l->upload_pool = NULL;
+    { int q; for (q = 0; q < 4; q++) { bc->stamp[g][q + 1] = l->batch_stamp[q] - bc->t0; } bc->lane_of[g] = (uint8_t)ba->lane; }
+    if (rc != 0) {
+      pthread_mutex_lock(&bc->mu);
+      if (bc->failed == 0) { bc->failed = rc; }
+      pthread_mutex_unlock(&bc->mu);
+      break;
+    }
+  }
+  return NULL;
+}
+
+/* 0: done; < 0: not taken (small batch, switched off, a lane could not be made) -- the plain path; > 0: API result */
+static int encode_batch_on_lanes(struct SLAEncoder* e, sla_hip_batch_item* items, uint32_t num_items)
+{
+  const uint32_t C = e->wave_format.num_channels;
+  batch_ctx_t* bc;
+  batch_arg_t args[SLAI_STREAM_LANES];
+  pthread_t th[SLAI_STREAM_LANES];
+  uint64_t total = 0, acc = 0, target;
+  uint32_t L, G, g, i, t, started = 0;
+  int rc;
+  if (!e->stream_mode || e->is_lane || e->batch_lanes < 2 || num_items < 8) { return -1; }
+  for (i = 0; i < num_items; i++) { total += items[i].num_samples; }
+  if (total * C < (16ull << 20)) { return -1; }                  /* (below that the per-group latencies outweigh the overlap) */
+  L = e->batch_lanes;
+  G = 2 * L;                                                     /* two groups per lane: the second round starts out of step */
+  if (G > num_items / 2) { G = num_items / 2; }
+  if (G < 2) { return -1; }
+  if (L > G) { L = G; }
+  for (t = 0; t < L; t++) { if (stream_lane(e, t) == NULL) { return -1; } }
+  bc = (batch_ctx_t*)calloc(1, sizeof(*bc));
+  if (bc == NULL) { return SLA_APIRESULT_NG; }
+  bc->parent = e; bc->items = items;
+  /* groups of consecutive files, about equal in samples */
+  target = (total + G - 1) / G;
+  bc->lo[0] = 0; g = 0;
+  for (i = 0; i < num_items; i++) {
+    acc += items[i].num_samples;
+    if (acc >= target * (g + 1) && g + 1 < G && i + 1 < num_items) { bc->lo[++g] = i + 1; }
+  }
+  bc->lo[++g] = num_items; bc->ngroups = g;
+  pthread_mutex_init(&bc->mu, NULL); pthread_mutex_init(&bc->gate, NULL);
+  bc->t0 = now_ms();
+  for (t = 0; t < L; t++) {
+    args[t].bc = bc; args[t].lane = t;
+    if (pthread_create(&th[t], NULL, batch_lane_main, &args[t]) != 0) {
+      pthread_mutex_lock(&bc->mu); if (bc->failed == 0) { bc->failed = SLA_APIRESULT_NG; } pthread_mutex_unlock(&bc->mu);
+      break;
+    }
+    started++;
+  }
+  for (t = 0; t < started; t++) { pthread_join(th[t], NULL); }
+  (void)enter(e);                                         /* the lanes named their own knobs on their threads; this thread is ours */
+  rc = bc->failed;
+  if (e->trace) {
+    for (g = 0; g < bc->ngroups; g++) {
+      fprintf(stderr, "[sla_hip] group %2u (files %u..%u) lane %u: taken %7.3f upload %7.3f..%7.3f analysed %7.3f delivered %7.3f ms\n", g, bc->lo[g], bc->lo[g + 1],
+              (uint32_t)bc->lane_of[g], bc->stamp[g][0], bc->stamp[g][1], bc->stamp[g][2], bc->stamp[g][3], bc->stamp[g][4]);
+    }
+  }
+  pthread_mutex_destroy(&bc->mu); pthread_mutex_destroy(&bc->gate);
+  free(bc);
+  e->analysed = 0;
+  return (rc > 0) ? rc : (rc < 0 ? SLA_APIRESULT_NG : 0);
+}
+
 int sla_hip_encode_batch(struct SLAEncoder* e, sla_hip_batch_item* items, uint32_t num_items)
 {
   uint32_t first = 0, i, ch;
@@ -3543,6 +3651,8 @@ int sla_hip_encode_batch(struct SLAEncoder* e, sla_hip_batch_item* items, uint32
     for (ch = 0; ch < e->wave_format.num_channels; ch++) { if (items[i].input[ch] == NULL) { return SLA_APIRESULT_INVALID_ARGUMENT; } }
     if (items[i].num_samples > BATCH_MAX_SPAN - SLA_HIP_PREPASS_TILE) { return SLA_APIRESULT_EXCEED_HANDLE_CAPACITY; }
   }
+  rc = encode_batch_on_lanes(e, items, num_items);
+  if (rc >= 0) { return rc; }
   while (first < num_items) {
     uint64_t span = 0;
     uint32_t count = 0;

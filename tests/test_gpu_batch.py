@@ -322,3 +322,43 @@ def test_batch_with_a_silent_tail_or_a_zero_word_takes_the_mask(oracle, hip):
         _check_trace(oracle, p, enc.trace(), starts, [g, f])
     finally:
         enc.close()
+
+
+def test_big_batch_on_lanes(oracle, hip):
+    """a batch big enough for the worker lanes (round 4: groups of consecutive files dealt out to handles of their own, uploads
+    taking turns, everything behind them overlapping): every file's bytes are the one-piece batch's and the oracle's -- files
+    of different lengths, one with silence, one whose low bits give another offset_lshift, one empty, one too small a buffer"""
+    p = S.make_params(2, 16, 48000, 16, 1, 8, 1, 1, 4096, cap=(2, 4096, 16, 1, 8))
+    rng = np.random.default_rng(77)
+    lens = [int(x) for x in rng.integers(500000, 800000, size=18)]
+    lens[5] = 4097
+    lens[11] = 0
+    pcms = [S.synth_pcm(2, max(n, 1), 16, 48000, seed=300 + i) if i % 3 else W.music_like(2, max(n, 1), 16, seed=300 + i) for i, n in enumerate(lens)]
+    pcms[11] = np.zeros((2, 0), np.int32)
+    pcms[3][:, 100000:160000] = 0
+    pcms[7] = (pcms[7] >> 18) << 18                           # two more zero bits at the bottom: offset_lshift 2
+    assert sum(lens) * 2 >= (16 << 20)
+    caps = [8 * 2 * n + 65536 for n in lens]
+    caps[9] = 1000                                            # too small: that file fails, the others do not
+    enc = make_encoder(hip, p)
+    one = make_encoder(hip, p)
+    try:
+        one.set_option("batch_lanes", 1)
+        want = one.encode_batch(pcms, capacities=caps)
+        for lanes in (4, 2, 6):
+            enc.set_option("batch_lanes", lanes)
+            got = enc.encode_batch(pcms, capacities=caps)
+            assert [rc for rc, _ in got] == [rc for rc, _ in want], lanes
+            assert [d for _, d in got] == [d for _, d in want], lanes
+        assert want[9][0] != 0 and all(rc == 0 for i, (rc, _) in enumerate(want) if i != 9)
+        for i in (0, 3, 5, 7, 11, 17):
+            ret, ref = oracle.encode_whole(p, pcms[i])
+            assert ret == 0 and got[i][1] == ref, i
+        # the handle goes on: a small batch (plain path) and a single file
+        again = enc.encode_batch(pcms[4:7])
+        assert [d for _, d in again] == [d for _, d in want[4:7]]
+        assert enc.encode_whole(pcms[5]) == want[5][1]
+    finally:
+        enc.close()
+        one.close()
+
