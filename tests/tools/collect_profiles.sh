@@ -2,7 +2,7 @@
 set -e
 cd "$(dirname "$0")/../.."
 for c in c2 c3 c5; do
-  case $c in c2) tag=c2;; c3) tag=c3_600s;; c5) tag=c5_120s;; esac
+  case $c in c2) tag=c2;; c3) tag=c3;; c5) tag=c5_120s;; esac
   U=$(echo $c | tr a-z A-Z)                              # prof_pmc.sh writes gpurun_out/pmc_<CFG>
   f=$(ls -t $(find gpurun_out/kt_$c -name "*kernel_stats.csv" 2>/dev/null) 2>/dev/null | head -1)
   [ -n "$f" ] && cp "$f" profiles/r4_kernel_stats_$tag.csv
