@@ -123,7 +123,6 @@ struct SLAEncoder {
   size_t nz_ones_cap; uint64_t nz_ones_words;    /* h_nz words [0, nz_ones_words) are known to be all ones (h_nz.cap == nz_ones_cap) */
   pinbuf_t h_stage[2]; devbuf_t d_stage[2]; hipEvent_t ev_stage[2];
   hipEvent_t ev_prep;               /* the prepass result has reached the host */
-  hipEvent_t ev_tables;             /* the search tables have reached the device (upload stream) */
   int      groups_valid;            /* d_groups holds the sliced search groups of the current tables (search_groups_ready) */
   hipEvent_t ev_pack[4];            /* device pack: the blocks of a quarter of the image are written and checksummed */
 
@@ -365,7 +364,7 @@ struct SLAEncoder* SLAEncoder_Create(const struct SLAEncoderConfig* config)
   e->own_copy_streams = 1;
   for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { if (hipEventCreate(&e->ev[i]) != hipSuccess) { goto fail; } }
   if (hipEventCreate(&e->ev_stage[0]) != hipSuccess || hipEventCreate(&e->ev_stage[1]) != hipSuccess
-      || hipEventCreate(&e->ev_prep) != hipSuccess || hipEventCreateWithFlags(&e->ev_tables, hipEventDisableTiming) != hipSuccess) { goto fail; }
+      || hipEventCreate(&e->ev_prep) != hipSuccess) { goto fail; }
   for (i = 0; i < 4; i++) { if (hipEventCreate(&e->ev_pack[i]) != hipSuccess) { goto fail; } }
   /* the defaults of every knob; sla_hip_encoder_set_option changes them afterwards.  Nothing but SLA_HIP_TRACE comes from the
    * environment (rounds 1 - 3 read some thirty variables here) */
@@ -462,7 +461,6 @@ void SLAEncoder_Destroy(struct SLAEncoder* e)
   }
   for (i = 0; i < (int)(sizeof(e->ev) / sizeof(e->ev[0])); i++) { if (e->ev[i] != NULL) { (void)hipEventDestroy(e->ev[i]); } }
   if (e->ev_prep != NULL) { (void)hipEventDestroy(e->ev_prep); }
-  if (e->ev_tables != NULL) { (void)hipEventDestroy(e->ev_tables); }
   for (i = 0; i < 4; i++) { if (e->ev_pack[i] != NULL) { (void)hipEventDestroy(e->ev_pack[i]); } }
   if (e->own_copy_streams) {
     if (e->stream_up != NULL) { (void)hipStreamDestroy(e->stream_up); }
@@ -897,14 +895,14 @@ static int search_groups_ready(struct SLAEncoder* e, const actx_t* a)
 }
 
 /* candidate and group tables of the partition search -> device (in order on the search stream) */
-/* beside: 0 = in order on the search stream, behind the prepass (every caller today); 1 = on the block-stage stream beside it,
- * the search stream waiting for an event.  The second form was measured (round 4, tests/tools/nocache_ab.sh): the typical C3
- * step without kept tables got another 0.15 ms shorter, but in one step of three a later launch call of the same analysis
- * then blocked for milliseconds (the block stage went out 7 ms late, the step took 12.6 instead of 9.5 ms) -- on the upload
- * stream and on the block-stage stream alike; not understood, not used. */
-static int upload_search_tables(struct SLAEncoder* e, const actx_t* a, int beside)
+/* In order on the search stream, behind the prepass.  Sending them beside the prepass on another stream, the search stream waiting
+ * for an event, was measured (round 4, tests/tools/nocache_ab.sh): the typical C3 step without kept tables got another 0.15 ms
+ * shorter, but in one step of three a later launch call of the same analysis then blocked for milliseconds (the block stage went
+ * out 7 ms late, the step took 12.6 instead of 9.5 ms) -- on the upload stream and on the block-stage stream alike; not
+ * understood, not kept. */
+static int upload_search_tables(struct SLAEncoder* e, const actx_t* a)
 {
-  const hipStream_t us = beside ? e->stream2 : e->stream;
+  const hipStream_t us = e->stream;
   if (a->ncands > 0) {
     HIPCHK(hipMemcpyAsync(e->d_cands.ptr, e->h_cands.ptr, sizeof(sla_hip_lpc_cand) * a->ncands, hipMemcpyHostToDevice, us));
   }
@@ -932,10 +930,6 @@ static int upload_search_tables(struct SLAEncoder* e, const actx_t* a, int besid
     HIPCHK(hipMemcpyAsync(e->d_winmap.ptr, hw, sizeof(uint32_t) * 2 * e->win_entries, hipMemcpyHostToDevice, us));
     e->winmap_entries = e->win_entries;
   }
-  if (beside) {
-    HIPCHK(hipEventRecord(e->ev_tables, us));
-    HIPCHK(hipStreamWaitEvent(e->stream, e->ev_tables, 0));
-  }
   return 0;
 }
 
@@ -959,7 +953,7 @@ static int tables_no_silence(struct SLAEncoder* e, actx_t* a)
   free(e->tab_sf); free(e->tab_shapes); e->tab_sf = NULL; e->tab_shapes = NULL;
   RCCHK(build_tables(e, a, NULL));
   RCCHK(pipeline_reserve(e, a));
-  RCCHK(upload_search_tables(e, a, 0));
+  RCCHK(upload_search_tables(e, a));
   if (e->table_cache) {
     uint32_t* c = e->tab_cnt;
     /* (the window list may have grown while the tables were built: the key holds what it is now) */
@@ -997,7 +991,7 @@ static int tables_batch_no_silence(struct SLAEncoder* e, actx_t* a)
   free(e->tab_sf); free(e->tab_shapes); e->tab_sf = NULL; e->tab_shapes = NULL;
   RCCHK(build_tables(e, a, NULL));                         /* no mask: nothing is silent */
   RCCHK(pipeline_reserve(e, a));
-  RCCHK(upload_search_tables(e, a, 0));
+  RCCHK(upload_search_tables(e, a));
   if (e->table_cache) {
     uint32_t* c = e->tab_cnt;
     uint32_t* segs = (uint32_t*)realloc(e->tab_segs, seg_bytes ? seg_bytes : 4);
@@ -1076,7 +1070,7 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
     e->tab_valid = 0;                                     /* the batch's tables take the place of the kept ones */
     RCCHK(build_tables(e, a, (const uint64_t*)e->h_nz.ptr));
     RCCHK(pipeline_reserve(e, a));
-    RCCHK(upload_search_tables(e, a, 0));
+    RCCHK(upload_search_tables(e, a));
     decide_routes(e, a, e->h_or[0], 1);
     return 0;
   }
@@ -1168,7 +1162,7 @@ static int pipeline_prepare(struct SLAEncoder* e, actx_t* a)
     a->blocks_bound = 0; a->lchunks_bound = 0;
     RCCHK(build_tables(e, a, nz));
     RCCHK(pipeline_reserve(e, a));
-    RCCHK(upload_search_tables(e, a, 0));
+    RCCHK(upload_search_tables(e, a));
   }
   {
     const int silence = (rebuild || e->h_or[1] != 0);
