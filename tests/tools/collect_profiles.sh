@@ -23,6 +23,7 @@ for k, (n, v) in sorted(agg.items()):
     print('"%s",%d,%s,%.3f' % (k, n, sys.argv[2], v / n))
 PY
   done
-  [ -f gpurun_out/sq_$c.txt ] && cp gpurun_out/sq_$c.txt profiles/r4_sq_counters_$tag.csv
+  sqtag=$tag; [ $c = c3 ] && sqtag=c3_600s                 # (prof_sq.sh is run on a 600 s cut of C3)
+  [ -f gpurun_out/sq_$c.txt ] && cp gpurun_out/sq_$c.txt profiles/r4_sq_counters_$sqtag.csv
 done
 ls -la profiles | tail -20
